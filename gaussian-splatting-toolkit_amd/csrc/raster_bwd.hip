@@ -1,0 +1,479 @@
+// raster_bwd.hip -- VJP of the per-tile alpha compositing (gfx950).
+//
+// Rule restated from rasterizer/cuda/csrc/backward.cu:133-303 (3 channels) and
+// :23-131 (N channels): every pixel re-walks its tile's sorted splat list
+// back-to-front starting at its own final_idx, recomputes
+//   alpha = min(0.99, opac*exp(-sigma))      (0.99 here, 0.999 in the forward)
+//   ra = 1/(1-alpha); T *= ra; fac = alpha*T
+//   v_rgb   += fac * v_out
+//   v_alpha  = sum_c (rgb_c*T - buffer_c*ra) v_out_c
+//              + T_final*ra*v_out_alpha - T_final*ra*sum_c bg_c v_out_c
+//   buffer  += rgb*fac
+//   v_sigma  = -opac*vis*v_alpha,  v_opacity += vis*v_alpha
+//   v_conic += (.5 v_sigma dx^2, v_sigma dx dy, .5 v_sigma dy^2)
+//   v_xy    += v_sigma*(a dx + b dy, b dx + c dy)
+// and the per-pixel contributions are summed per Gaussian.
+//
+// tile16 mapping (block_width 16, 3 channels): one wave64 per tile, a 2x2
+// pixel quad per lane, splats staged 64 at a time in LDS.  The reference
+// reduces every splat across a 32-lane warp (9 values x 5 shuffle steps) and
+// issues 9 atomics per warp per splat (72 per tile-splat).  Here a lane first
+// folds its 4 pixels into six moments of w = vis*v_alpha (sum w, w dx, w dy,
+// w dx^2, w dx dy, w dy^2) + the rgb sums, turns them into the 9 gradient
+// components, and then 8 splats x 9 components = 72 lane-partials are reduced
+// together with a halving butterfly: v_permlane32_swap / v_permlane16_swap
+// (new on gfx950) and DPP row ops, every step halving the number of live
+// values, ~2 instructions per output instead of 6 per value.  The butterfly
+// ends with exactly one fully reduced (splat, component) per lane, so one
+// wave-wide global_atomic_add_f32 retires 64 components: 9 atomics per
+// tile-splat instead of 72.
+#include "gsr_common.h"
+
+namespace {
+
+constexpr int kChunk = 64;
+constexpr int kGroup = 8;  // splats reduced together
+
+struct __align__(16) SplatA { float x, y, ha, b; };
+struct __align__(16) SplatB { float hc, opac, r, g; };
+
+#define DPP_QUAD_XOR1 0xB1        // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E        // quad_perm:[2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141 // lane l <-> 7-l inside each 8 lanes
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+
+// After the call, lanes 0-31 hold (lo+hi) of `a`, lanes 32-63 hold (lo+hi) of `b`.
+__device__ __forceinline__ float fold32(float a, float b) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// Rows (16 lanes) 0,2 end with `a` summed over the row pair, rows 1,3 with `b`.
+__device__ __forceinline__ float fold16(float a, float b) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// 72 lane-partials P[9*j + c] (splat j<8, component c<9) -> per lane:
+//   `main`  = component comp_of_lane() of splat (lane>>3), summed over the wave
+//   `extra` = component 8 of splat (lane>>3), summed over the wave (all 8 lanes)
+__device__ __forceinline__ void butterfly72(float (&P)[72], int lane, float &main_v,
+                                            float &extra_v) {
+  float Q[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) Q[i] = fold32(P[i], P[i + 36]);  // lane bit 5 <-> splat bit 2
+  float R[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) R[i] = fold16(Q[i], Q[i + 18]);  // lane bit 4 <-> splat bit 1
+  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+  float S[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {  // lane bit 3 <-> splat bit 0 (row_ror:8 pairs l, l^8)
+    const float keep = b3 ? R[i + 9] : R[i];
+    const float send = b3 ? R[i] : R[i + 9];
+    S[i] = keep + dpp<0x128>(send);
+  }
+  // 8 lanes now share one splat: halve components 0..7 over lane bits 2,0,1
+  float U[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float keep = b2 ? S[i + 4] : S[i];
+    const float send = b2 ? S[i] : S[i + 4];
+    U[i] = keep + dpp<DPP_ROW_HALF_MIRROR>(send);
+  }
+  float V[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float keep = b0 ? U[i + 2] : U[i];
+    const float send = b0 ? U[i] : U[i + 2];
+    V[i] = keep + dpp<DPP_QUAD_XOR1>(send);
+  }
+  {
+    const float keep = b1 ? V[1] : V[0];
+    const float send = b1 ? V[0] : V[1];
+    main_v = keep + dpp<DPP_QUAD_XOR2>(send);
+  }
+  float e = S[8];
+  e += dpp<DPP_ROW_HALF_MIRROR>(e);
+  e += dpp<DPP_QUAD_XOR1>(e);
+  e += dpp<DPP_QUAD_XOR2>(e);
+  extra_v = e;
+}
+// component index that butterfly72 leaves in `main` for a lane
+__device__ __forceinline__ int comp_of_lane(int lane) {
+  return ((lane & 4) ? 4 : 0) + ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0);
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h,
+    const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
+    const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ background, const float *__restrict__ final_Ts,
+    const int *__restrict__ final_idx, const float *__restrict__ v_output,
+    const float *__restrict__ v_output_alpha, float *__restrict__ v_xy,
+    float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity) {
+  __shared__ SplatA sA[kChunk];
+  __shared__ SplatB sB[kChunk];
+  __shared__ float sBlue[kChunk];
+  __shared__ int sId[kChunk];
+
+  const int tile = (int)gsr_xcd_remap(blockIdx.x, (unsigned)num_tiles);
+  const int2 range = tile_bins[tile];
+  if (range.y <= range.x) return;
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int lane = threadIdx.x;
+  const int qx = tx * 16 + 2 * (lane & 7), qy = ty * 16 + 2 * (lane >> 3);
+  const float fx0 = (float)qx, fx1 = (float)(qx + 1);
+  const float fy0 = (float)qy, fy1 = (float)(qy + 1);
+  const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
+
+  float T[4], K[4], vr[4], vg[4], vb[4], br[4], bgr[4], bb[4];
+  int binf[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int col = qx + (p & 1), row = qy + (p >> 1);
+    const bool inside = col < img_w && row < img_h;
+    T[p] = 1.f;
+    K[p] = vr[p] = vg[p] = vb[p] = 0.f;
+    br[p] = bgr[p] = bb[p] = 0.f;
+    binf[p] = -1;  // `inside && idx <= bin_final` folds into one compare
+    if (inside) {
+      const size_t pid = (size_t)row * img_w + col;
+      const float Tf = final_Ts[pid];
+      T[p] = Tf;
+      vr[p] = v_output[3 * pid];
+      vg[p] = v_output[3 * pid + 1];
+      vb[p] = v_output[3 * pid + 2];
+      // T_final*ra*v_out_alpha - T_final*ra*(bg . v_out) = ra * K
+      K[p] = Tf * (v_output_alpha[pid] - (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p]));
+      binf[p] = final_idx[pid];
+    }
+  }
+  const int top = min(range.y - 1, wave_max(max(max(binf[0], binf[1]), max(binf[2], binf[3]))));
+  if (top < range.x) return;
+
+  // lane-constant destination of the `main` value
+  const int comp = comp_of_lane(lane);
+  float *const dst_base = comp < 2 ? v_xy : (comp < 5 ? v_conic : v_colors);
+  const int dst_stride = comp < 2 ? 2 : 3;
+  const int dst_off = comp < 2 ? comp : (comp < 5 ? comp - 2 : comp - 5);
+
+  for (int hi = top; hi >= range.x; hi -= kChunk) {
+    // slot t of the chunk holds sorted index hi - t (back to front)
+    const int idx = hi - lane;
+    if (idx >= range.x) {
+      const int g = ids_sorted[idx];
+      const float2 xy = xys[g];
+      const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+      sA[lane] = SplatA{xy.x, xy.y, 0.5f * a, b};
+      sB[lane] = SplatB{0.5f * c, opacities[g], colors[3 * g], colors[3 * g + 1]};
+      sBlue[lane] = colors[3 * g + 2];
+      sId[lane] = g;
+    }
+    __syncthreads();
+    const int count = min(kChunk, hi - range.x + 1);
+
+    for (int t0 = 0; t0 < count; t0 += kGroup) {
+      float P[72];
+      bool lane_any = false;
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j) {
+        const int t = t0 + j;
+        float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f;
+        float sr = 0.f, sg = 0.f, sb = 0.f;
+        float ha = 0.f, hc = 0.f, cb_ = 0.f, opac = 0.f;
+        if (t < count) {  // wave-uniform
+          const SplatA A = sA[t];
+          const SplatB B = sB[t];
+          const float blue = sBlue[t];
+          ha = A.ha;
+          hc = B.hc;
+          cb_ = A.b;
+          opac = B.opac;
+          const int sidx = hi - t;
+          const float dx0 = A.x - fx0, dx1 = A.x - fx1;
+          const float dy0 = A.y - fy0, dy1 = A.y - fy1;
+          const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
+          const float cy0 = B.hc * dy0 * dy0, cy1 = B.hc * dy1 * dy1;
+          const float bx0 = A.b * dx0, bx1 = A.b * dx1;
+          const float sig[4] = {(ax0 + cy0) + bx0 * dy0, (ax1 + cy0) + bx1 * dy0,
+                                (ax0 + cy1) + bx0 * dy1, (ax1 + cy1) + bx1 * dy1};
+          const float dxs[4] = {dx0, dx1, dx0, dx1};
+          const float dys[4] = {dy0, dy0, dy1, dy1};
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            const float sigma = sig[p];
+            const float vis = __expf(-sigma);
+            const float alpha = fminf(GSR_ALPHA_MAX_BWD, B.opac * vis);
+            const bool valid = (sidx <= binf[p]) && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+            const float ra = __frcp_rn(1.f - alpha);
+            const float Tn = T[p] * ra;
+            const float fac_ = alpha * Tn;
+            float v_alpha = (B.r * Tn - br[p] * ra) * vr[p];
+            v_alpha += (B.g * Tn - bgr[p] * ra) * vg[p];
+            v_alpha += (blue * Tn - bb[p] * ra) * vb[p];
+            v_alpha += K[p] * ra;
+            const float w = valid ? vis * v_alpha : 0.f;
+            const float fac = valid ? fac_ : 0.f;
+            T[p] = valid ? Tn : T[p];
+            br[p] += B.r * fac;
+            bgr[p] += B.g * fac;
+            bb[p] += blue * fac;
+            sr += fac * vr[p];
+            sg += fac * vg[p];
+            sb += fac * vb[p];
+            const float wx = w * dxs[p], wy = w * dys[p];
+            m0 += w;
+            mx += wx;
+            my += wy;
+            mxx += wx * dxs[p];
+            mxy += wx * dys[p];
+            myy += wy * dys[p];
+            lane_any = lane_any || valid;
+          }
+        }
+        // v_sigma = -opac * w  ->  gradient components of this splat
+        const float a = 2.f * ha, c = 2.f * hc, nvs = -opac;
+        P[9 * j + 0] = nvs * (a * mx + cb_ * my);
+        P[9 * j + 1] = nvs * (cb_ * mx + c * my);
+        P[9 * j + 2] = nvs * 0.5f * mxx;
+        P[9 * j + 3] = nvs * mxy;
+        P[9 * j + 4] = nvs * 0.5f * myy;
+        P[9 * j + 5] = sr;
+        P[9 * j + 6] = sg;
+        P[9 * j + 7] = sb;
+        P[9 * j + 8] = m0;
+      }
+      if (!__any(lane_any)) continue;  // nothing in this group touched the tile
+
+      float main_v, extra_v;
+      butterfly72(P, lane, main_v, extra_v);
+      const int t = t0 + (lane >> 3);
+      if (t < count) {
+        const int g = sId[t];
+        if (main_v != 0.f) unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, main_v);
+        if ((lane & 7) == 0 && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------- generic
+// One lane per pixel; per-batch gradient accumulators live in LDS (ds_add_f32),
+// one global atomic per (tile, splat, component) at the end of the batch.
+template <int CMAX>
+__global__ __launch_bounds__(256) void raster_bwd_generic_kernel(
+    const int tiles_x, const int img_w, const int img_h, const int channels,
+    const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
+    const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ background, const float *__restrict__ final_Ts,
+    const int *__restrict__ final_idx, const float *__restrict__ v_output,
+    const float *__restrict__ v_output_alpha, float *__restrict__ v_xy,
+    float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity) {
+  extern __shared__ float s_dyn[];  // [bsize][6 + channels] accumulators
+  __shared__ int s_id[256];
+  __shared__ float s_x[256], s_y[256], s_o[256], s_a[256], s_b[256], s_c[256];
+  __shared__ int s_top;
+
+  const int bsize = blockDim.x * blockDim.y;
+  const int tr = threadIdx.y * blockDim.x + threadIdx.x;
+  const int tile = blockIdx.y * tiles_x + blockIdx.x;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y * blockDim.y + threadIdx.y;
+  const float px = (float)col, py = (float)row;
+  const bool inside = col < img_w && row < img_h;
+  const int stride = 6 + channels;
+
+  const int2 range = tile_bins[tile];
+  float vout[CMAX], buf[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) vout[c] = buf[c] = 0.f;
+  float T_final = 1.f, vout_alpha = 0.f, bgdot = 0.f;
+  int bin_final = -1;
+  if (inside) {
+    const size_t pid = (size_t)row * img_w + col;
+    T_final = final_Ts[pid];
+    vout_alpha = v_output_alpha[pid];
+    bin_final = final_idx[pid];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < channels) {
+        vout[c] = v_output[pid * channels + c];
+        bgdot += background[c] * vout[c];
+      }
+  }
+  float T = T_final;
+
+  if (tr == 0) s_top = -1;
+  __syncthreads();
+  atomicMax(&s_top, bin_final);
+  __syncthreads();
+  const int top = min(range.y - 1, s_top);
+
+  for (int hi = top; hi >= range.x; hi -= bsize) {
+    __syncthreads();  // previous batch fully flushed
+    const int idx = hi - tr;
+    if (idx >= range.x) {
+      const int g = ids_sorted[idx];
+      s_id[tr] = g;
+      const float2 xy = xys[g];
+      s_x[tr] = xy.x;
+      s_y[tr] = xy.y;
+      s_o[tr] = opacities[g];
+      s_a[tr] = conics[3 * g];
+      s_b[tr] = conics[3 * g + 1];
+      s_c[tr] = conics[3 * g + 2];
+    }
+    for (int k = 0; k < stride; ++k) s_dyn[tr * stride + k] = 0.f;
+    __syncthreads();
+    const int count = min(bsize, hi - range.x + 1);
+    for (int t = 0; t < count; ++t) {
+      if (hi - t > bin_final) continue;
+      const float dx = s_x[t] - px, dy = s_y[t] - py;
+      const float a = s_a[t], b = s_b[t], c = s_c[t], opac = s_o[t];
+      const float sigma = 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+      const float vis = __expf(-sigma);
+      const float alpha = fminf(GSR_ALPHA_MAX_BWD, opac * vis);
+      if (sigma < 0.f || alpha < GSR_ALPHA_MIN) continue;
+      const float ra = 1.f / (1.f - alpha);
+      T *= ra;
+      const float fac = alpha * T;
+      float v_alpha = 0.f;
+      float *acc = s_dyn + t * stride;
+      const float *rgb = colors + (size_t)s_id[t] * channels;
+#pragma unroll
+      for (int ch = 0; ch < CMAX; ++ch)
+        if (ch < channels) {
+          const float cval = rgb[ch];
+          atomicAdd(acc + 6 + ch, fac * vout[ch]);
+          v_alpha += (cval * T - buf[ch] * ra) * vout[ch];
+          buf[ch] += cval * fac;
+        }
+      v_alpha += T_final * ra * vout_alpha;
+      v_alpha += -T_final * ra * bgdot;
+      const float v_sigma = -opac * vis * v_alpha;
+      atomicAdd(acc + 0, v_sigma * (a * dx + b * dy));
+      atomicAdd(acc + 1, v_sigma * (b * dx + c * dy));
+      atomicAdd(acc + 2, 0.5f * v_sigma * dx * dx);
+      atomicAdd(acc + 3, v_sigma * dx * dy);
+      atomicAdd(acc + 4, 0.5f * v_sigma * dy * dy);
+      atomicAdd(acc + 5, vis * v_alpha);
+    }
+    __syncthreads();
+    if (tr < count) {
+      const int g = s_id[tr];
+      const float *acc = s_dyn + tr * stride;
+      if (acc[0] != 0.f) unsafeAtomicAdd(v_xy + 2 * (size_t)g, acc[0]);
+      if (acc[1] != 0.f) unsafeAtomicAdd(v_xy + 2 * (size_t)g + 1, acc[1]);
+      if (acc[2] != 0.f) unsafeAtomicAdd(v_conic + 3 * (size_t)g, acc[2]);
+      if (acc[3] != 0.f) unsafeAtomicAdd(v_conic + 3 * (size_t)g + 1, acc[3]);
+      if (acc[4] != 0.f) unsafeAtomicAdd(v_conic + 3 * (size_t)g + 2, acc[4]);
+      if (acc[5] != 0.f) unsafeAtomicAdd(v_opacity + g, acc[5]);
+      for (int ch = 0; ch < channels; ++ch)
+        if (acc[6 + ch] != 0.f) unsafeAtomicAdd(v_colors + (size_t)g * channels + ch, acc[6 + ch]);
+    }
+  }
+}
+
+int launch_generic(unsigned img_h, unsigned img_w, unsigned bw, unsigned channels, const int32_t *ids,
+                   const int32_t *bins, const float *xys, const float *conics, const float *colors,
+                   const float *opac, const float *background, const float *final_Ts,
+                   const int32_t *final_idx, const float *v_output, const float *v_output_alpha,
+                   float *v_xy, float *v_conic, float *v_colors, float *v_opacity, hipStream_t s) {
+  const int tiles_x = (int)gsr_cdiv(img_w, bw), tiles_y = (int)gsr_cdiv(img_h, bw);
+  const dim3 grd(tiles_x, tiles_y), blk(bw, bw);
+  const size_t dyn = (size_t)bw * bw * (6 + channels) * sizeof(float);
+#define GSR_LAUNCH_BWD(CM)                                                                        \
+  hipLaunchKernelGGL(raster_bwd_generic_kernel<CM>, grd, blk, dyn, s, tiles_x, (int)img_w,        \
+                     (int)img_h, (int)channels, ids, reinterpret_cast<const int2 *>(bins),        \
+                     reinterpret_cast<const float2 *>(xys), conics, colors, opac, background,     \
+                     final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,      \
+                     v_opacity)
+  if (channels <= 4) GSR_LAUNCH_BWD(4);
+  else if (channels <= 8) GSR_LAUNCH_BWD(8);
+  else if (channels <= 16) GSR_LAUNCH_BWD(16);
+  else GSR_LAUNCH_BWD(32);
+#undef GSR_LAUNCH_BWD
+  GSR_CHECK_LAUNCH("rasterize_backward(generic)");
+  return GSR_OK;
+}
+
+int zero_grads(int n, unsigned channels, float *v_xy, float *v_conic, float *v_colors,
+               float *v_opacity, hipStream_t s) {
+  GSR_CHECK_HIP(hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * (size_t)n, s));
+  GSR_CHECK_HIP(hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * (size_t)n, s));
+  GSR_CHECK_HIP(hipMemsetAsync(v_colors, 0, sizeof(float) * channels * (size_t)n, s));
+  GSR_CHECK_HIP(hipMemsetAsync(v_opacity, 0, sizeof(float) * (size_t)n, s));
+  return GSR_OK;
+}
+
+}  // namespace
+
+GSR_EXPORT int gsr_rasterize_backward_nd(
+    unsigned img_height, unsigned img_width, unsigned block_width, unsigned channels,
+    int num_points, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+    const float *conics, const float *colors, const float *opacities, const float *background,
+    const float *final_Ts, const int32_t *final_idx, const float *v_output,
+    const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+    gsr_stream_t stream) {
+  GSR_REQUIRE(block_width >= 2 && block_width <= 16, "rasterize_backward: block_width must be in [2,16]");
+  GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward: empty image");
+  GSR_REQUIRE(channels >= 1 && channels <= GSR_MAX_CHANNELS, "rasterize_backward: channels must be in [1,%d]", GSR_MAX_CHANNELS);
+  GSR_REQUIRE(num_points >= 0, "rasterize_backward: num_points < 0");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
+                  background && final_Ts && final_idx && v_output && v_output_alpha && v_xy &&
+                  v_conic && v_colors && v_opacity,
+              "rasterize_backward: null pointer");
+  int rc = zero_grads(num_points, channels, v_xy, v_conic, v_colors, v_opacity, (hipStream_t)stream);
+  if (rc != GSR_OK) return rc;
+  return launch_generic(img_height, img_width, block_width, channels, gaussian_ids_sorted, tile_bins,
+                        xys, conics, colors, opacities, background, final_Ts, final_idx, v_output,
+                        v_output_alpha, v_xy, v_conic, v_colors, v_opacity, (hipStream_t)stream);
+}
+
+GSR_EXPORT int gsr_rasterize_backward(
+    unsigned img_height, unsigned img_width, unsigned block_width, int num_points,
+    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+    const float *conics, const float *colors, const float *opacities, const float *background,
+    const float *final_Ts, const int32_t *final_idx, const float *v_output,
+    const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+    gsr_stream_t stream) {
+  if (block_width != 16)
+    return gsr_rasterize_backward_nd(img_height, img_width, block_width, 3, num_points,
+                                     gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
+                                     background, final_Ts, final_idx, v_output, v_output_alpha, v_xy,
+                                     v_conic, v_colors, v_opacity, stream);
+  GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward: empty image");
+  GSR_REQUIRE(num_points >= 0, "rasterize_backward: num_points < 0");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
+                  background && final_Ts && final_idx && v_output && v_output_alpha && v_xy &&
+                  v_conic && v_colors && v_opacity,
+              "rasterize_backward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
+  if (rc != GSR_OK) return rc;
+  const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
+  const int num_tiles = tiles_x * tiles_y;
+  hipLaunchKernelGGL(raster_bwd_tile16_kernel, dim3(num_tiles), dim3(64), 0, s, tiles_x, num_tiles,
+                     (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins),
+                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
+                     final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,
+                     v_opacity);
+  GSR_CHECK_LAUNCH("rasterize_backward(tile16)");
+  return GSR_OK;
+}

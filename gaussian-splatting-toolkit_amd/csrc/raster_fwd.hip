@@ -1,0 +1,278 @@
+// raster_fwd.hip -- front-to-back alpha compositing of depth-sorted splats per
+// tile (gfx950).
+//
+// Compositing rule restated from rasterizer/cuda/csrc/forward.cu:278-395
+// (3 channels) and :159-276 (N channels):
+//   sigma = .5(a dx^2 + c dy^2) + b dx dy,  d = xy - (col,row)   (no +0.5)
+//   alpha = min(0.999, opac * exp(-sigma)); skip if sigma<0 or alpha<1/255
+//   if T(1-alpha) <= 1e-4 the pixel is finished (that splat is NOT drawn)
+//   C += rgb*alpha*T; T *= 1-alpha; final_idx = index in the sorted list
+//   out = C + T*background
+//
+// Two mappings:
+//  * tile16 (block_width 16, 3 channels -- what the models use): ONE wave64 per
+//    16x16 tile, each lane owns a 2x2 pixel quad.  Splats are staged 64 at a
+//    time through LDS (one gather per lane, coalesced index read) and consumed
+//    by wave-uniform broadcast reads, so every LDS word feeds 4 pixels per lane
+//    and no workgroup barrier is ever waited on by a second wave.  dx/dy terms
+//    are shared across the quad.  Workgroups are remapped so that each XCD
+//    rasterises a contiguous band of tiles (shared splats stay in one L2).
+//  * generic (any block_width in [2,16], any channel count <= 32): one lane
+//    per pixel, block_width^2 lanes per tile.
+#include "gsr_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ tile16
+constexpr int kChunk = 64;
+
+struct __align__(16) SplatA { float x, y, ha, b; };      // ha = a/2
+struct __align__(16) SplatB { float hc, opac, r, g; };   // hc = c/2
+// (0.5*(a dx^2 + c dy^2) == (a/2) dx^2 + (c/2) dy^2 exactly: scaling by a
+//  power of two commutes with rounding)
+
+__global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h,
+    const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
+    const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ background, float *__restrict__ out_img,
+    float *__restrict__ final_Ts, int *__restrict__ final_idx) {
+  __shared__ SplatA sA[kChunk];
+  __shared__ SplatB sB[kChunk];
+  __shared__ float sBlue[kChunk];
+
+  const int tile = (int)gsr_xcd_remap(blockIdx.x, (unsigned)num_tiles);
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int lane = threadIdx.x;
+  const int qx = tx * 16 + 2 * (lane & 7), qy = ty * 16 + 2 * (lane >> 3);
+  const float fx0 = (float)qx, fx1 = (float)(qx + 1);
+  const float fy0 = (float)qy, fy1 = (float)(qy + 1);
+
+  // pixel p = (qx + (p&1), qy + (p>>1))
+  bool done[4];
+  float T[4], cr[4], cg[4], cb[4];
+  int last[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    done[p] = !((qx + (p & 1)) < img_w && (qy + (p >> 1)) < img_h);
+    T[p] = 1.f;
+    cr[p] = cg[p] = cb[p] = 0.f;
+    last[p] = 0;
+  }
+
+  const int2 range = tile_bins[tile];
+  for (int base = range.x; base < range.y; base += kChunk) {
+    if (__all(done[0] && done[1] && done[2] && done[3])) break;
+    const int idx = base + lane;
+    if (idx < range.y) {
+      const int g = ids_sorted[idx];
+      const float2 xy = xys[g];
+      const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+      sA[lane] = SplatA{xy.x, xy.y, 0.5f * a, b};
+      sB[lane] = SplatB{0.5f * c, opacities[g], colors[3 * g], colors[3 * g + 1]};
+      sBlue[lane] = colors[3 * g + 2];
+    }
+    __syncthreads();
+    const int count = min(kChunk, range.y - base);
+    for (int t = 0; t < count; ++t) {
+      if ((t & 7) == 0 && __all(done[0] && done[1] && done[2] && done[3])) break;
+      const SplatA A = sA[t];
+      const SplatB B = sB[t];
+      const float blue = sBlue[t];
+      const float dx0 = A.x - fx0, dx1 = A.x - fx1;
+      const float dy0 = A.y - fy0, dy1 = A.y - fy1;
+      const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
+      const float cy0 = B.hc * dy0 * dy0, cy1 = B.hc * dy1 * dy1;
+      const float bx0 = A.b * dx0, bx1 = A.b * dx1;
+      const float sig[4] = {(ax0 + cy0) + bx0 * dy0, (ax1 + cy0) + bx1 * dy0,
+                            (ax0 + cy1) + bx0 * dy1, (ax1 + cy1) + bx1 * dy1};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float sigma = sig[p];
+        const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
+        const bool hit = !done[p] && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+        const float next_T = T[p] * (1.f - alpha);
+        const bool stop = hit && (next_T <= GSR_T_EPS);
+        const bool draw = hit && !stop;
+        const float vis = draw ? alpha * T[p] : 0.f;
+        cr[p] += B.r * vis;
+        cg[p] += B.g * vis;
+        cb[p] += blue * vis;
+        T[p] = draw ? next_T : T[p];
+        last[p] = draw ? (base + t) : last[p];
+        done[p] = done[p] || stop;
+      }
+    }
+    __syncthreads();
+  }
+
+  // wave-uniform -> scalar loads
+  const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int col = qx + (p & 1), row = qy + (p >> 1);
+    if (col < img_w && row < img_h) {
+      const size_t pid = (size_t)row * img_w + col;
+      final_Ts[pid] = T[p];
+      final_idx[pid] = last[p];
+      out_img[3 * pid] = cr[p] + T[p] * bg0;
+      out_img[3 * pid + 1] = cg[p] + T[p] * bg1;
+      out_img[3 * pid + 2] = cb[p] + T[p] * bg2;
+    }
+  }
+}
+
+// ----------------------------------------------------------------- generic
+// One lane per pixel, bw*bw lanes per tile, batches of bw*bw splats in LDS.
+template <int CMAX>
+__global__ __launch_bounds__(256) void raster_fwd_generic_kernel(
+    const int tiles_x, const int img_w, const int img_h, const int channels,
+    const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
+    const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ background, float *__restrict__ out_img,
+    float *__restrict__ final_Ts, int *__restrict__ final_idx) {
+  __shared__ int s_id[256];
+  __shared__ float s_x[256], s_y[256], s_o[256], s_a[256], s_b[256], s_c[256];
+
+  const int bsize = blockDim.x * blockDim.y;
+  const int tr = threadIdx.y * blockDim.x + threadIdx.x;
+  const int tile = blockIdx.y * tiles_x + blockIdx.x;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y * blockDim.y + threadIdx.y;
+  const float px = (float)col, py = (float)row;
+  const bool inside = col < img_w && row < img_h;
+  bool done = !inside;
+
+  float acc[CMAX];
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
+  float T = 1.f;
+  int last = 0;
+
+  const int2 range = tile_bins[tile];
+  for (int base = range.x; base < range.y; base += bsize) {
+    if (__syncthreads_count(done ? 1 : 0) >= bsize) break;
+    const int idx = base + tr;
+    if (idx < range.y) {
+      const int g = ids_sorted[idx];
+      s_id[tr] = g;
+      const float2 xy = xys[g];
+      s_x[tr] = xy.x;
+      s_y[tr] = xy.y;
+      s_o[tr] = opacities[g];
+      s_a[tr] = conics[3 * g];
+      s_b[tr] = conics[3 * g + 1];
+      s_c[tr] = conics[3 * g + 2];
+    }
+    __syncthreads();
+    const int count = min(bsize, range.y - base);
+    for (int t = 0; t < count && !done; ++t) {
+      const float dx = s_x[t] - px, dy = s_y[t] - py;
+      const float sigma = 0.5f * (s_a[t] * dx * dx + s_c[t] * dy * dy) + s_b[t] * dx * dy;
+      const float alpha = fminf(GSR_ALPHA_MAX_FWD, s_o[t] * __expf(-sigma));
+      if (sigma < 0.f || alpha < GSR_ALPHA_MIN) continue;
+      const float next_T = T * (1.f - alpha);
+      if (next_T <= GSR_T_EPS) {
+        done = true;
+        break;
+      }
+      const float vis = alpha * T;
+      const float *col_g = colors + (size_t)s_id[t] * channels;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < channels) acc[c] += col_g[c] * vis;
+      T = next_T;
+      last = base + t;
+    }
+  }
+
+  if (inside) {
+    const size_t pid = (size_t)row * img_w + col;
+    final_Ts[pid] = T;
+    final_idx[pid] = last;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < channels) out_img[pid * channels + c] = acc[c] + T * background[c];
+  }
+}
+
+int launch_generic(int tiles_x, int tiles_y, unsigned bw, unsigned img_w, unsigned img_h,
+                   unsigned channels, const int32_t *ids, const int32_t *bins, const float *xys,
+                   const float *conics, const float *colors, const float *opac,
+                   const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
+                   hipStream_t s) {
+  const dim3 grd(tiles_x, tiles_y), blk(bw, bw);
+#define GSR_LAUNCH_FWD(CM)                                                                      \
+  hipLaunchKernelGGL(raster_fwd_generic_kernel<CM>, grd, blk, 0, s, tiles_x, (int)img_w,        \
+                     (int)img_h, (int)channels, ids, reinterpret_cast<const int2 *>(bins),      \
+                     reinterpret_cast<const float2 *>(xys), conics, colors, opac, background,   \
+                     out_img, final_Ts, final_idx)
+  if (channels <= 4) GSR_LAUNCH_FWD(4);
+  else if (channels <= 8) GSR_LAUNCH_FWD(8);
+  else if (channels <= 16) GSR_LAUNCH_FWD(16);
+  else GSR_LAUNCH_FWD(32);
+#undef GSR_LAUNCH_FWD
+  GSR_CHECK_LAUNCH("rasterize_forward(generic)");
+  return GSR_OK;
+}
+
+int check_common(const char *who, int tiles_x, int tiles_y, unsigned bw, unsigned img_w,
+                 unsigned img_h, unsigned channels) {
+  GSR_REQUIRE(bw >= 2 && bw <= 16, "%s: block_width must be in [2,16]", who);
+  GSR_REQUIRE(img_w > 0 && img_h > 0, "%s: empty image", who);
+  GSR_REQUIRE(tiles_x == (int)gsr_cdiv(img_w, bw) && tiles_y == (int)gsr_cdiv(img_h, bw),
+              "%s: tile bounds (%d,%d) do not match image %ux%u / block %u", who, tiles_x, tiles_y,
+              img_w, img_h, bw);
+  GSR_REQUIRE(channels >= 1 && channels <= GSR_MAX_CHANNELS, "%s: channels must be in [1,%d]", who,
+              GSR_MAX_CHANNELS);
+  return GSR_OK;
+}
+
+}  // namespace
+
+GSR_EXPORT int gsr_rasterize_forward_nd(int tiles_x, int tiles_y, unsigned block_width,
+                                        unsigned img_width, unsigned img_height, unsigned channels,
+                                        const int32_t *gaussian_ids_sorted,
+                                        const int32_t *tile_bins, const float *xys,
+                                        const float *conics, const float *colors,
+                                        const float *opacities, const float *background,
+                                        float *out_img, float *final_Ts, int32_t *final_idx,
+                                        gsr_stream_t stream) {
+  int rc = check_common("rasterize_forward", tiles_x, tiles_y, block_width, img_width, img_height,
+                        channels);
+  if (rc != GSR_OK) return rc;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
+                  background && out_img && final_Ts && final_idx,
+              "rasterize_forward: null pointer");
+  return launch_generic(tiles_x, tiles_y, block_width, img_width, img_height, channels,
+                        gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background,
+                        out_img, final_Ts, final_idx, (hipStream_t)stream);
+}
+
+GSR_EXPORT int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_width,
+                                     unsigned img_width, unsigned img_height,
+                                     const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                                     const float *xys, const float *conics, const float *colors,
+                                     const float *opacities, const float *background,
+                                     float *out_img, float *final_Ts, int32_t *final_idx,
+                                     gsr_stream_t stream) {
+  int rc = check_common("rasterize_forward", tiles_x, tiles_y, block_width, img_width, img_height, 3);
+  if (rc != GSR_OK) return rc;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
+                  background && out_img && final_Ts && final_idx,
+              "rasterize_forward: null pointer");
+  if (block_width != 16)
+    return launch_generic(tiles_x, tiles_y, block_width, img_width, img_height, 3,
+                          gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
+                          background, out_img, final_Ts, final_idx, (hipStream_t)stream);
+  const int num_tiles = tiles_x * tiles_y;
+  hipLaunchKernelGGL(raster_fwd_tile16_kernel, dim3(num_tiles), dim3(64), 0, (hipStream_t)stream,
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins),
+                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
+                     out_img, final_Ts, final_idx);
+  GSR_CHECK_LAUNCH("rasterize_forward(tile16)");
+  return GSR_OK;
+}

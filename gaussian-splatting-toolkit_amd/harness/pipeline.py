@@ -1,0 +1,91 @@
+"""The render call the toolkit's models make, reproduced outside the toolkit.
+
+``render_view`` follows ``GaussianSplattingModel.get_outputs``
+(gs_toolkit/models/vanilla_gs.py:765-855) / ``DepthGSModel.get_outputs``
+(gs_toolkit/models/depth_gs.py:225-363) step by step, using only the public
+``rasterizer`` API: project -> (retain xys grad) -> SH -> clamp(+0.5) ->
+rasterize(return_alpha) -> optional second rasterisation of depths.
+gs_toolkit itself cannot be imported in this image (tyro, jaxtyping, viser,
+open3d ... are absent), so the contract is restated here for tests and bench.
+"""
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from rasterizer.project_gaussians import project_gaussians
+from rasterizer.rasterize import rasterize_gaussians
+from rasterizer.sh import spherical_harmonics
+
+BLOCK_WIDTH = 16  # vanilla_gs.py:762-764
+
+
+@dataclass
+class CameraTensors:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    viewmat: torch.Tensor  # [4,4]
+    projmat: torch.Tensor  # [4,4] = P @ V
+    campos: torch.Tensor  # [3]
+
+    @staticmethod
+    def from_numpy(cam, device) -> "CameraTensors":
+        t = lambda a: torch.from_numpy(a).to(device)
+        return CameraTensors(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
+                             t(cam.viewmat), t(cam.projmat), t(cam.campos))
+
+
+def render_view(
+    means3d: torch.Tensor,      # [N,3]
+    scales: torch.Tensor,       # [N,3] already exp()'d
+    quats: torch.Tensor,        # [N,4] already normalised
+    opacities: torch.Tensor,    # [N,1] already sigmoid()'d
+    sh_coeffs: torch.Tensor,    # [N,K,3] (features_dc ++ features_rest)
+    cam: CameraTensors,
+    background: torch.Tensor,   # [3]
+    sh_degree_to_use: int,
+    rasterize_mode: str = "classic",
+    render_depth: bool = False,
+    retain_xys_grad: bool = False,
+    clamp_rgb: bool = True,
+) -> Dict[str, Optional[torch.Tensor]]:
+    H, W = cam.height, cam.width
+    xys, depths, radii, conics, comp, num_tiles_hit, cov3d = project_gaussians(
+        means3d, scales, 1, quats, cam.viewmat[:3, :], cam.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+        H, W, BLOCK_WIDTH,
+    )
+    if retain_xys_grad and xys.requires_grad:
+        xys.retain_grad()  # densification reads xys.grad (vanilla_gs.py:352-353,797-798)
+
+    viewdirs = means3d.detach() - cam.campos
+    viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+    rgbs = spherical_harmonics(sh_degree_to_use, viewdirs, sh_coeffs)
+    rgbs = torch.clamp(rgbs + 0.5, min=0.0)
+
+    if rasterize_mode == "antialiased":
+        opac = opacities * comp[:, None]
+    elif rasterize_mode == "classic":
+        opac = opacities
+    else:
+        raise ValueError("Unknown rasterize_mode: %s" % rasterize_mode)
+
+    rgb, alpha = rasterize_gaussians(
+        xys, depths, radii, conics, num_tiles_hit, rgbs, opac, H, W, BLOCK_WIDTH,
+        background=background, return_alpha=True,
+    )
+    alpha = alpha[..., None]
+    if clamp_rgb:
+        rgb = torch.clamp(rgb, max=1.0)
+    depth_im = None
+    if render_depth:
+        depth_im = rasterize_gaussians(
+            xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opac, H, W,
+            BLOCK_WIDTH, background=torch.zeros(3, device=means3d.device),
+        )[..., 0:1]
+        depth_im = torch.where(alpha > 0, depth_im / alpha, depth_im.detach().max())
+    return {"rgb": rgb, "alpha": alpha, "depth": depth_im, "xys": xys, "radii": radii,
+            "depths": depths, "conics": conics, "num_tiles_hit": num_tiles_hit, "rgbs": rgbs}

@@ -1,0 +1,134 @@
+"""Synthetic scenes and cameras with the reference's conventions.
+
+Camera: rasterizer convention (x right, y down, z forward), pinhole, the
+projection matrix of ``gs_toolkit/utils/comms.py:103-123`` (OpenGL-style,
+``w_clip = z_view``).  Scene statistics follow SURVEY.md section 8(d):
+``z ~ U(2,10)``, ``x,y ~ U(-1,1) * 1.1 * tan(fov/2) * z`` (about 10 % of the
+splats fall outside the frustum), log-uniform scales in [0.005, 0.05],
+random unit quaternions, opacity ~ U(0.1, 0.9), SH dc ~ U(-1,1)*0.5/C0,
+higher bands ~ N(0, 0.1^2).  Everything is generated with numpy from a seed so
+that CPU oracle and GPU see bit-identical inputs.
+"""
+import math
+from dataclasses import dataclass
+from typing import Dict
+
+import numpy as np
+
+SH_C0 = 0.28209479177387814
+BACKGROUND = (0.1490, 0.1647, 0.2157)
+
+
+def projection_matrix(znear: float, zfar: float, fovx: float, fovy: float) -> np.ndarray:
+    t = znear * math.tan(0.5 * fovy)
+    b = -t
+    r = znear * math.tan(0.5 * fovx)
+    l = -r
+    n, f = znear, zfar
+    return np.array(
+        [
+            [2 * n / (r - l), 0.0, (r + l) / (r - l), 0.0],
+            [0.0, 2 * n / (t - b), (t + b) / (t - b), 0.0],
+            [0.0, 0.0, (f + n) / (f - n), -1.0 * f * n / (f - n)],
+            [0.0, 0.0, 1.0, 0.0],
+        ],
+        dtype=np.float32,
+    )
+
+
+@dataclass
+class Camera:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    viewmat: np.ndarray  # [4,4] world->camera, row-major
+    projmat: np.ndarray  # [4,4] P @ V
+
+    @property
+    def campos(self) -> np.ndarray:
+        R, t = self.viewmat[:3, :3], self.viewmat[:3, 3]
+        return (-R.T @ t).astype(np.float32)
+
+
+def make_camera(width: int, height: int, fov_x_deg: float = 60.0, yaw: float = 0.0,
+                pitch: float = 0.0, roll: float = 0.0, trans=(0.0, 0.0, 0.0)) -> Camera:
+    fovx = math.radians(fov_x_deg)
+    fx = width / (2.0 * math.tan(fovx / 2.0))
+    fy = fx
+    fovy = 2.0 * math.atan(height / (2.0 * fy))
+    cy_, sy_ = math.cos(yaw), math.sin(yaw)
+    cp, sp = math.cos(pitch), math.sin(pitch)
+    cr, sr = math.cos(roll), math.sin(roll)
+    Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]])
+    V = np.eye(4, dtype=np.float32)
+    V[:3, :3] = (Rz @ Rx @ Ry).astype(np.float32)
+    V[:3, 3] = np.asarray(trans, dtype=np.float32)
+    P = projection_matrix(0.001, 1000.0, fovx, fovy) @ V
+    return Camera(width, height, fx, fy, width / 2.0, height / 2.0, V, P.astype(np.float32))
+
+
+def num_sh_bases(degree: int) -> int:
+    return {0: 1, 1: 4, 2: 9, 3: 16}.get(degree, 25)
+
+
+def make_scene(n: int, cam: Camera, sh_degree: int = 3, seed: int = 42,
+               scale_lo: float = 0.005, scale_hi: float = 0.05,
+               z_lo: float = 2.0, z_hi: float = 10.0) -> Dict[str, np.ndarray]:
+    """Random Gaussian cloud in front of `cam`."""
+    rng = np.random.default_rng(seed)
+    tanx = 0.5 * cam.width / cam.fx
+    tany = 0.5 * cam.height / cam.fy
+    z = rng.uniform(z_lo, z_hi, n)
+    x = rng.uniform(-1, 1, n) * 1.1 * tanx * z
+    y = rng.uniform(-1, 1, n) * 1.1 * tany * z
+    p_cam = np.stack([x, y, z], -1)
+    R, t = cam.viewmat[:3, :3].astype(np.float64), cam.viewmat[:3, 3].astype(np.float64)
+    means = (p_cam - t) @ R  # R^T (p - t)
+    scales = np.exp(rng.uniform(math.log(scale_lo), math.log(scale_hi), (n, 3)))
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    opac = rng.uniform(0.1, 0.9, (n, 1))
+    K = num_sh_bases(sh_degree)
+    sh = np.empty((n, K, 3))
+    sh[:, 0, :] = rng.uniform(-1, 1, (n, 3)) * 0.5 / SH_C0
+    if K > 1:
+        sh[:, 1:, :] = rng.standard_normal((n, K - 1, 3)) * 0.1
+    f32 = np.float32
+    return dict(means3d=means.astype(f32), scales=scales.astype(f32), quats=q.astype(f32),
+                opacities=opac.astype(f32), sh_coeffs=sh.astype(f32))
+
+
+def make_cotangents(cam: Camera, seed: int = 43):
+    rng = np.random.default_rng(seed)
+    v_img = rng.uniform(-1, 1, (cam.height, cam.width, 3)).astype(np.float32)
+    v_alpha = rng.uniform(-1, 1, (cam.height, cam.width)).astype(np.float32)
+    return v_img, v_alpha
+
+
+def viewdirs_for(scene: Dict[str, np.ndarray], cam: Camera) -> np.ndarray:
+    d = scene["means3d"] - cam.campos[None]
+    return (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def algorithmic_bytes(n: int, num_intersects: int, pixels: int, tiles: int, sh_bases: int):
+    """Compulsory HBM traffic per fwd+bwd, per kernel."""
+    N, I, P, T, K = n, num_intersects, pixels, tiles, sh_bases
+    per = {
+        "project_fwd": 100 * N,
+        "sh_fwd": (12 + 12 * K) * N + 12 * N,
+        "scan": 8 * N,
+        "map": 20 * N + 12 * I,
+        "sort": 24 * I,
+        "bin_edges": 8 * I + 8 * T,
+        "raster_fwd": 40 * I + 20 * P,
+        "raster_bwd": 40 * I + 24 * P + 36 * I,
+        "project_bwd": 188 * N,
+        "sh_bwd": 24 * N + 12 * K * N,
+    }
+    per["total"] = sum(per.values())
+    return per

@@ -1,0 +1,348 @@
+"""``rasterizer.cuda`` -- the native module of the rasterizer, MI355X edition.
+
+The reference exposes an 11-function pybind module under this name
+(``rasterizer/cuda/csrc/ext.cpp:6-17``; every Python module of the package does
+``import rasterizer.cuda as _C``).  The module name is kept so that those
+imports keep working; the implementation is hand-written HIP for gfx950 behind
+the C ABI of ``include/gsraster.h``, bound here with ctypes.  Each function has
+the reference's name, argument order, returned tuple order, dtypes, shapes and
+error type (``RuntimeError`` for what ``TORCH_CHECK``/``AT_ERROR`` raise there).
+
+PyTorch is used for device memory and streams only: outputs are allocated with
+``torch.empty`` on the inputs' device (the kernels write every element, so the
+reference's ``torch::zeros`` pre-fill is not needed) and kernels are enqueued
+on the *current* HIP stream of that device.  There is no CPU path.
+"""
+import ctypes as C
+from typing import Tuple
+
+import torch
+from torch import Tensor
+
+from ._backend import lib as _lib
+
+_f32, _i32, _i64 = torch.float32, torch.int32, torch.int64
+
+
+def _check(t: Tensor, name: str, dtype=None) -> Tensor:
+    # CHECK_INPUT of the reference (bindings.h:10-15)
+    if not isinstance(t, Tensor):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must have dtype {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _call(fn_name: str, *args) -> None:
+    rc = getattr(_lib(), fn_name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{fn_name} failed ({rc}): {_lib().gsr_last_error().decode()}")
+
+
+def _cf(v) -> C.c_float:
+    return C.c_float(float(v))
+
+
+def project_gaussians_forward(
+    num_points: int, means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
+    viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
+    img_height: int, img_width: int, block_width: int, clip_thresh: float,
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """-> (cov3d, xys, depths, radii, conics, compensation, num_tiles_hit);
+    replaces ``project_gaussians_forward_tensor`` (bindings.cu:107-160)."""
+    for t, nm in ((means3d, "means3d"), (scales, "scales"), (quats, "quats"),
+                  (viewmat, "viewmat"), (projmat, "projmat")):
+        _check(t, nm, _f32)
+    n = int(num_points)
+    if viewmat.numel() < 12 or projmat.numel() != 16:
+        raise RuntimeError("viewmat must hold at least 3x4 and projmat 4x4 values")
+    if means3d.numel() != 3 * n or scales.numel() != 3 * n or quats.numel() != 4 * n:
+        raise RuntimeError("means3d/scales/quats do not match num_points")
+    dev = means3d.device
+    with torch.cuda.device(dev):
+        cov3d = torch.empty((n, 6), dtype=_f32, device=dev)
+        xys = torch.empty((n, 2), dtype=_f32, device=dev)
+        depths = torch.empty((n,), dtype=_f32, device=dev)
+        radii = torch.empty((n,), dtype=_i32, device=dev)
+        conics = torch.empty((n, 3), dtype=_f32, device=dev)
+        compensation = torch.empty((n,), dtype=_f32, device=dev)
+        num_tiles_hit = torch.empty((n,), dtype=_i32, device=dev)
+        _call(
+            "gsr_project_forward", C.c_int(n), _ptr(means3d), _ptr(scales), _cf(glob_scale),
+            _ptr(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
+            C.c_uint(img_height), C.c_uint(img_width), C.c_uint(block_width), _cf(clip_thresh),
+            _ptr(cov3d), _ptr(xys), _ptr(depths), _ptr(radii), _ptr(conics), _ptr(compensation),
+            _ptr(num_tiles_hit), _stream(dev),
+        )
+    return cov3d, xys, depths, radii, conics, compensation, num_tiles_hit
+
+
+def project_gaussians_backward(
+    num_points: int, means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
+    viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
+    img_height: int, img_width: int, cov3d: Tensor, radii: Tensor, conics: Tensor,
+    compensation: Tensor, v_xy: Tensor, v_depth: Tensor, v_conic: Tensor, v_compensation: Tensor,
+) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+    """-> (v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat);
+    replaces ``project_gaussians_backward_tensor`` (bindings.cu:164-216)."""
+    n = int(num_points)
+    dev = means3d.device
+    for t, nm in ((means3d, "means3d"), (scales, "scales"), (quats, "quats"), (viewmat, "viewmat"),
+                  (projmat, "projmat"), (cov3d, "cov3d"), (conics, "conics"),
+                  (compensation, "compensation")):
+        _check(t, nm, _f32)
+    _check(radii, "radii", _i32)
+    # cotangents may arrive non-contiguous / expanded from autograd
+    v_xy, v_depth, v_conic, v_compensation = (
+        _check(t.contiguous(), nm, _f32)
+        for t, nm in ((v_xy, "v_xy"), (v_depth, "v_depth"), (v_conic, "v_conic"),
+                      (v_compensation, "v_compensation"))
+    )
+    with torch.cuda.device(dev):
+        v_cov2d = torch.empty((n, 3), dtype=_f32, device=dev)
+        v_cov3d = torch.empty((n, 6), dtype=_f32, device=dev)
+        v_mean3d = torch.empty((n, 3), dtype=_f32, device=dev)
+        v_scale = torch.empty((n, 3), dtype=_f32, device=dev)
+        v_quat = torch.empty((n, 4), dtype=_f32, device=dev)
+        _call(
+            "gsr_project_backward", C.c_int(n), _ptr(means3d), _ptr(scales), _cf(glob_scale),
+            _ptr(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
+            C.c_uint(img_height), C.c_uint(img_width), _ptr(cov3d), _ptr(radii), _ptr(conics),
+            _ptr(compensation), _ptr(v_xy), _ptr(v_depth), _ptr(v_conic), _ptr(v_compensation),
+            _ptr(v_cov2d), _ptr(v_cov3d), _ptr(v_mean3d), _ptr(v_scale), _ptr(v_quat),
+            _stream(dev),
+        )
+    return v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat
+
+
+def _num_sh_bases(degree: int) -> int:
+    return {0: 1, 1: 4, 2: 9, 3: 16}.get(int(degree), 25)
+
+
+def compute_sh_forward(num_points: int, degree: int, degrees_to_use: int, viewdirs: Tensor,
+                       coeffs: Tensor) -> Tensor:
+    """-> colors [N,3]; replaces ``compute_sh_forward_tensor`` (bindings.cu:58-77)."""
+    n = int(num_points)
+    if coeffs.dim() != 3 or coeffs.size(0) != n or coeffs.size(1) != _num_sh_bases(degree) \
+            or coeffs.size(2) != 3:
+        raise RuntimeError("coeffs must have dimensions (N, D, 3)")
+    _check(viewdirs, "viewdirs", _f32)
+    _check(coeffs, "coeffs", _f32)
+    dev = coeffs.device
+    with torch.cuda.device(dev):
+        colors = torch.empty((n, 3), dtype=_f32, device=dev)
+        _call("gsr_sh_forward", C.c_uint(n), C.c_uint(degree), C.c_uint(degrees_to_use),
+              _ptr(viewdirs), _ptr(coeffs), _ptr(colors), _stream(dev))
+    return colors
+
+
+def compute_sh_backward(num_points: int, degree: int, degrees_to_use: int, viewdirs: Tensor,
+                        v_colors: Tensor) -> Tensor:
+    """-> v_coeffs [N,K,3]; replaces ``compute_sh_backward_tensor`` (bindings.cu:79-103)."""
+    n = int(num_points)
+    if viewdirs.dim() != 2 or viewdirs.size(0) != n or viewdirs.size(1) != 3:
+        raise RuntimeError("viewdirs must have dimensions (N, 3)")
+    if v_colors.dim() != 2 or v_colors.size(0) != n or v_colors.size(1) != 3:
+        raise RuntimeError("v_colors must have dimensions (N, 3)")
+    _check(viewdirs, "viewdirs", _f32)
+    v_colors = _check(v_colors.contiguous(), "v_colors", _f32)
+    dev = viewdirs.device
+    with torch.cuda.device(dev):
+        v_coeffs = torch.empty((n, _num_sh_bases(degree), 3), dtype=_f32, device=dev)
+        _call("gsr_sh_backward", C.c_uint(n), C.c_uint(degree), C.c_uint(degrees_to_use),
+              _ptr(viewdirs), _ptr(v_colors), _ptr(v_coeffs), _stream(dev))
+    return v_coeffs
+
+
+def cumsum_tiles(num_tiles_hit: Tensor) -> Tensor:
+    """Inclusive int32 scan (not part of the reference's native module, which
+    uses ``torch.cumsum``; exported for ``utils.compute_cumulative_intersects``)."""
+    _check(num_tiles_hit, "num_tiles_hit", _i32)
+    n = num_tiles_hit.numel()
+    dev = num_tiles_hit.device
+    with torch.cuda.device(dev):
+        cum = torch.empty_like(num_tiles_hit)
+        nbytes = int(_lib().gsr_cumsum_workspace_bytes(C.c_int(n)))
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _call("gsr_cumsum_tiles", C.c_int(n), _ptr(num_tiles_hit), _ptr(cum), _ptr(ws),
+              C.c_size_t(nbytes), _stream(dev))
+    return cum
+
+
+def map_gaussian_to_intersects(
+    num_points: int, num_intersects: int, xys: Tensor, depths: Tensor, radii: Tensor,
+    cum_tiles_hit: Tensor, tile_bounds: Tuple[int, int, int], block_width: int,
+) -> Tuple[Tensor, Tensor]:
+    """-> (isect_ids i64[I], gaussian_ids i32[I]);
+    replaces ``map_gaussian_to_intersects_tensor`` (bindings.cu:218-251)."""
+    _check(xys, "xys", _f32)
+    _check(depths, "depths", _f32)
+    _check(radii, "radii", _i32)
+    _check(cum_tiles_hit, "cum_tiles_hit", _i32)
+    dev = xys.device
+    I = int(num_intersects)
+    with torch.cuda.device(dev):
+        # zero-filled like the reference: slots not claimed by any splat stay 0
+        isect_ids = torch.zeros((I,), dtype=_i64, device=dev)
+        gaussian_ids = torch.zeros((I,), dtype=_i32, device=dev)
+        _call("gsr_map_intersects", C.c_int(int(num_points)), C.c_int(I), _ptr(xys), _ptr(depths),
+              _ptr(radii), _ptr(cum_tiles_hit), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
+              C.c_uint(block_width), _ptr(isect_ids), _ptr(gaussian_ids), _stream(dev))
+    return isect_ids, gaussian_ids
+
+
+def sort_intersects(isect_ids: Tensor, gaussian_ids: Tensor, num_tiles: int) -> Tuple[Tensor, Tensor]:
+    """Stable radix sort of the (tile|depth) keys with their Gaussian ids (the
+    reference's ``torch.sort`` + ``torch.gather``, utils.py:179-180)."""
+    _check(isect_ids, "isect_ids", _i64)
+    _check(gaussian_ids, "gaussian_ids", _i32)
+    I = isect_ids.numel()
+    dev = isect_ids.device
+    with torch.cuda.device(dev):
+        keys = torch.empty_like(isect_ids)
+        vals = torch.empty_like(gaussian_ids)
+        nbytes = int(_lib().gsr_sort_workspace_bytes(C.c_int(I)))
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _call("gsr_sort_intersects", C.c_int(I), C.c_int(max(int(num_tiles), 1)), _ptr(isect_ids),
+              _ptr(gaussian_ids), _ptr(keys), _ptr(vals), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+    return keys, vals
+
+
+def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: Tensor,
+                       tile_bounds: Tuple[int, int, int]) -> Tensor:
+    """-> tile_bins i32[T,2]; replaces ``get_tile_bin_edges_tensor`` (bindings.cu:253-267)."""
+    _check(isect_ids_sorted, "isect_ids_sorted", _i64)
+    dev = isect_ids_sorted.device
+    nt = int(tile_bounds[0]) * int(tile_bounds[1])
+    with torch.cuda.device(dev):
+        tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
+        _call("gsr_tile_bin_edges", C.c_int(int(num_intersects)), _ptr(isect_ids_sorted),
+              C.c_int(nt), _ptr(tile_bins), _stream(dev))
+    return tile_bins
+
+
+def _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background):
+    _check(gaussian_ids_sorted, "gaussian_ids_sorted", _i32)
+    _check(tile_bins, "tile_bins", _i32)
+    for t, nm in ((xys, "xys"), (conics, "conics"), (colors, "colors"), (opacities, "opacities"),
+                  (background, "background")):
+        _check(t, nm, _f32)
+    if xys.dim() != 2 or xys.size(1) != 2:
+        raise RuntimeError("xys must have dimensions (num_points, 2)")
+    if colors.dim() != 2:
+        raise RuntimeError("colors must have 2 dimensions")
+    if background.numel() != colors.size(1):
+        raise RuntimeError("background must have one value per channel")
+
+
+def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
+                       colors, opacities, background, nd: bool):
+    _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
+    channels = colors.size(1)
+    W, H = int(img_size[0]), int(img_size[1])
+    dev = xys.device
+    with torch.cuda.device(dev):
+        out_img = torch.empty((H, W, channels), dtype=_f32, device=dev)
+        final_Ts = torch.empty((H, W), dtype=_f32, device=dev)
+        final_idx = torch.empty((H, W), dtype=_i32, device=dev)
+        head = (C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(block[0]), C.c_uint(W),
+                C.c_uint(H))
+        tail = (_ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
+                _ptr(opacities), _ptr(background), _ptr(out_img), _ptr(final_Ts), _ptr(final_idx),
+                _stream(dev))
+        if nd:
+            _call("gsr_rasterize_forward_nd", *head, C.c_uint(channels), *tail)
+        else:
+            if channels != 3:
+                raise RuntimeError("rasterize_forward expects 3 channels; use nd_rasterize_forward")
+            _call("gsr_rasterize_forward", *head, *tail)
+    return out_img, final_Ts, final_idx
+
+
+def rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
+                      colors, opacities, background):
+    """-> (out_img [H,W,3], final_Ts [H,W], final_idx i32[H,W]);
+    replaces ``rasterize_forward_tensor`` (bindings.cu:269-328)."""
+    return _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys,
+                              conics, colors, opacities, background, nd=False)
+
+
+def nd_rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
+                         colors, opacities, background):
+    """Generic channel count; replaces ``nd_rasterize_forward_tensor``
+    (bindings.cu:330-399).  Accumulates in fp32 (the reference uses fp16)."""
+    return _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys,
+                              conics, colors, opacities, background, nd=True)
+
+
+def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
+                        conics, colors, opacities, background, final_Ts, final_idx, v_output,
+                        v_output_alpha, nd: bool):
+    _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
+    if not nd and colors.size(1) != 3:
+        raise RuntimeError("colors must have 2 dimensions")  # message of bindings.cu:494-496
+    _check(final_Ts, "final_Ts", _f32)
+    _check(final_idx, "final_idx", _i32)
+    v_output = _check(v_output.contiguous(), "v_output", _f32)
+    v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
+    n, channels = xys.size(0), colors.size(1)
+    dev = xys.device
+    with torch.cuda.device(dev):
+        v_xy = torch.empty((n, 2), dtype=_f32, device=dev)
+        v_conic = torch.empty((n, 3), dtype=_f32, device=dev)
+        v_colors = torch.empty((n, channels), dtype=_f32, device=dev)
+        v_opacity = torch.empty((n, 1), dtype=_f32, device=dev)
+        head = (C.c_uint(img_height), C.c_uint(img_width), C.c_uint(block_width))
+        tail = (C.c_int(n), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics),
+                _ptr(colors), _ptr(opacities), _ptr(background), _ptr(final_Ts), _ptr(final_idx),
+                _ptr(v_output), _ptr(v_output_alpha), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
+                _ptr(v_opacity), _stream(dev))
+        if nd:
+            _call("gsr_rasterize_backward_nd", *head, C.c_uint(channels), *tail)
+        else:
+            _call("gsr_rasterize_backward", *head, *tail)
+    return v_xy, v_conic, v_colors, v_opacity
+
+
+def rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
+                       conics, colors, opacities, background, final_Ts, final_idx, v_output,
+                       v_output_alpha):
+    """-> (v_xy, v_conic, v_colors, v_opacity [N,1]);
+    replaces ``rasterize_backward_tensor`` (bindings.cu:476-528)."""
+    return _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins,
+                               xys, conics, colors, opacities, background, final_Ts, final_idx,
+                               v_output, v_output_alpha, nd=False)
+
+
+def nd_rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
+                          conics, colors, opacities, background, final_Ts, final_idx, v_output,
+                          v_output_alpha):
+    """Generic channel count; replaces ``nd_rasterize_backward_tensor`` (bindings.cu:406-469)."""
+    return _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins,
+                               xys, conics, colors, opacities, background, final_Ts, final_idx,
+                               v_output, v_output_alpha, nd=True)
+
+
+def compute_cov2d_bounds(num_pts: int, cov2d: Tensor) -> Tuple[Tensor, Tensor]:
+    """-> (conics [N,3], radii [N,1] f32); replaces ``compute_cov2d_bounds_tensor``
+    (bindings.cu:39-56)."""
+    _check(cov2d, "cov2d", _f32)
+    n = int(num_pts)
+    dev = cov2d.device
+    with torch.cuda.device(dev):
+        conics = torch.empty((n, cov2d.size(1)), dtype=_f32, device=dev)
+        radii = torch.empty((n, 1), dtype=_f32, device=dev)
+        _call("gsr_cov2d_bounds", C.c_int(n), _ptr(cov2d), _ptr(conics), _ptr(radii), _stream(dev))
+    return conics, radii

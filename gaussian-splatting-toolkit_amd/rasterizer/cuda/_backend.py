@@ -1,0 +1,73 @@
+"""Loader of the native library behind ``rasterizer.cuda``.
+
+Counterpart of the reference's ``rasterizer/cuda/_backend.py`` (prebuilt
+extension first, nvcc JIT otherwise).  Here there is exactly one backend: the
+HIP library ``libgsraster.so`` (C ABI in ``include/gsraster.h``) built in-tree
+for gfx950 by ``csrc/Makefile``.  There is no CPU or eager-PyTorch fallback: if
+the library is missing the first native call raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+PATH = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PATH, "libgsraster.so")
+CSRC = os.path.normpath(os.path.join(PATH, "..", "..", "csrc"))
+
+# every symbol include/gsraster.h declares
+SYMBOLS = (
+    "gsr_version",
+    "gsr_last_error",
+    "gsr_project_forward",
+    "gsr_project_backward",
+    "gsr_sh_forward",
+    "gsr_sh_backward",
+    "gsr_cumsum_workspace_bytes",
+    "gsr_cumsum_tiles",
+    "gsr_map_intersects",
+    "gsr_sort_workspace_bytes",
+    "gsr_sort_intersects",
+    "gsr_tile_bin_edges",
+    "gsr_rasterize_forward",
+    "gsr_rasterize_backward",
+    "gsr_rasterize_forward_nd",
+    "gsr_rasterize_backward_nd",
+    "gsr_cov2d_bounds",
+)
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"rasterizer: native library {LIB_PATH} not found. Build it with "
+            f"`make -C {CSRC}` (needs hipcc); there is no fallback implementation."
+        )
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError(f"rasterizer: {LIB_PATH} lacks symbols {missing}")
+    lib.gsr_last_error.restype = C.c_char_p
+    lib.gsr_version.restype = C.c_int
+    lib.gsr_cumsum_workspace_bytes.restype = C.c_size_t
+    lib.gsr_sort_workspace_bytes.restype = C.c_size_t
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+__all__ = ["lib", "build", "LIB_PATH", "SYMBOLS"]

@@ -1,0 +1,160 @@
+"""Tile-based alpha compositing of projected Gaussians (differentiable).
+
+Mirror of the reference's ``rasterizer/rasterize.py`` (``rasterize_gaussians``
+:14-86, ``_RasterizeGaussians`` :89-247): same signature, checks, outputs,
+saved tensors and gradient tuple.
+
+One addition that is invisible to the caller: the models call
+``rasterize_gaussians`` twice per view with identical geometry (RGB, then
+depth; gs_toolkit/models/vanilla_gs.py:822,840).  The second call reuses the
+sorted intersection list and tile ranges of the first instead of running the
+scan + key emission + radix sort again.  The cache holds one entry, keyed on
+the storage address, shape and version counter of the four geometry tensors.
+It keeps detached aliases of them alive, so their storage cannot be recycled
+for another tensor while the entry exists (an address match therefore means
+the same memory), and an in-place update bumps the version and misses.
+"""
+from typing import Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+import rasterizer.cuda as _C
+from .utils import bin_and_sort_gaussians, compute_cumulative_intersects
+
+_bin_cache = {"key": None, "value": None, "keepalive": None}
+
+
+def _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (xys, depths, radii, num_tiles_hit)) + (
+        img_height, img_width, block_width, xys.device,
+    )
+
+
+def rasterize_gaussians(
+    xys: Tensor,
+    depths: Tensor,
+    radii: Tensor,
+    conics: Tensor,
+    num_tiles_hit: Tensor,
+    colors: Tensor,
+    opacity: Tensor,
+    img_height: int,
+    img_width: int,
+    block_width: int,
+    background: Optional[Tensor] = None,
+    return_alpha: Optional[bool] = False,
+) -> Tensor:
+    """Sort the Gaussians per tile by depth and composite them front to back.
+
+    Differentiable w.r.t. ``xys``, ``conics``, ``colors`` and ``opacity``.
+
+    Args:
+        xys [N,2], depths [N], radii [N] int32, conics [N,3], num_tiles_hit [N]
+        int32: outputs of :func:`project_gaussians` (same ``block_width``).
+        colors: [N,C] float (uint8 is rescaled to [0,1]).  opacity: [N,1].
+        background: [C]; defaults to ones.  return_alpha: also return 1-T.
+
+    Returns:
+        ``out_img`` [H,W,C], or ``(out_img, out_alpha [H,W])``.
+    """
+    assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
+    if colors.dtype == torch.uint8:
+        colors = colors.float() / 255
+
+    if background is not None:
+        assert (
+            background.shape[0] == colors.shape[-1]
+        ), f"incorrect shape of background color tensor, expected shape {colors.shape[-1]}"
+    else:
+        background = torch.ones(colors.shape[-1], dtype=torch.float32, device=colors.device)
+
+    if xys.ndimension() != 2 or xys.size(1) != 2:
+        raise ValueError("xys must have dimensions (N, 2)")
+    if colors.ndimension() != 2:
+        raise ValueError("colors must have dimensions (N, D)")
+
+    return _RasterizeGaussians.apply(
+        xys.contiguous(), depths.contiguous(), radii.contiguous(), conics.contiguous(),
+        num_tiles_hit.contiguous(), colors.contiguous(), opacity.contiguous(), img_height,
+        img_width, block_width, background.contiguous(), return_alpha,
+    )
+
+
+class _RasterizeGaussians(Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
+                img_width, block_width, background=None, return_alpha=False):
+        num_points = xys.size(0)
+        tile_bounds = (
+            (img_width + block_width - 1) // block_width,
+            (img_height + block_width - 1) // block_width,
+            1,
+        )
+        block = (block_width, block_width, 1)
+        img_size = (img_width, img_height, 1)
+
+        key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
+        if _bin_cache["key"] == key:
+            num_intersects, gaussian_ids_sorted, tile_bins = _bin_cache["value"]
+        else:
+            num_intersects, cum_tiles_hit = compute_cumulative_intersects(num_tiles_hit)
+            gaussian_ids_sorted = tile_bins = None
+            if num_intersects >= 1:
+                _, _, _, gaussian_ids_sorted, tile_bins = bin_and_sort_gaussians(
+                    num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds,
+                    block_width,
+                )
+            _bin_cache["key"] = key
+            _bin_cache["value"] = (num_intersects, gaussian_ids_sorted, tile_bins)
+            _bin_cache["keepalive"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
+
+        if num_intersects < 1:
+            # nothing on screen: background everywhere (rasterize.py:119-127)
+            out_img = torch.ones(img_height, img_width, colors.shape[-1], device=xys.device) * background
+            gaussian_ids_sorted = torch.zeros(0, 1, device=xys.device)
+            tile_bins = torch.zeros(0, 2, device=xys.device)
+            final_Ts = torch.zeros(img_height, img_width, device=xys.device)
+            final_idx = torch.zeros(img_height, img_width, device=xys.device)
+        else:
+            rasterize_fn = _C.rasterize_forward if colors.shape[-1] == 3 else _C.nd_rasterize_forward
+            out_img, final_Ts, final_idx = rasterize_fn(
+                tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                opacity, background,
+            )
+
+        ctx.img_width = img_width
+        ctx.img_height = img_height
+        ctx.num_intersects = num_intersects
+        ctx.block_width = block_width
+        ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity,
+                              background, final_Ts, final_idx)
+
+        if return_alpha:
+            return out_img, 1 - final_Ts
+        return out_img
+
+    @staticmethod
+    def backward(ctx, v_out_img, v_out_alpha=None):
+        (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
+         final_idx) = ctx.saved_tensors
+
+        if v_out_alpha is None:
+            v_out_alpha = torch.zeros_like(v_out_img[..., 0])
+
+        if ctx.num_intersects < 1:
+            v_xy = torch.zeros_like(xys)
+            v_conic = torch.zeros_like(conics)
+            v_colors = torch.zeros_like(colors)
+            v_opacity = torch.zeros_like(opacity)
+        else:
+            rasterize_fn = _C.rasterize_backward if colors.shape[-1] == 3 else _C.nd_rasterize_backward
+            v_xy, v_conic, v_colors, v_opacity = rasterize_fn(
+                ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
+                conics, colors, opacity, background, final_Ts, final_idx, v_out_img, v_out_alpha,
+            )
+            v_opacity = v_opacity.reshape(opacity.shape)
+
+        # xys, depths, radii, conics, num_tiles_hit, colors, opacity, then 5 non-differentiable
+        return (v_xy, None, None, v_conic, None, v_colors, v_opacity) + (None,) * 5

@@ -1,0 +1,187 @@
+/*
+ * gsraster.h -- C ABI of the MI355X-native Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for the reference's native module
+ * `rasterizer.cuda` (pybind module `rasterizer_cuda` / `rasterizer.csrc`,
+ * gs_toolkit/gs_components/rasterizer/cuda/csrc/ext.cpp:4-18, prototypes in
+ * cuda/csrc/bindings.h:19-115).  The reference has no C ABI -- its boundary is
+ * pybind11 + torch::Tensor; every entry point below names the `*_tensor`
+ * wrapper it replaces.  The Python mirror of the reference's package
+ * (`gaussian-splatting-toolkit_amd/rasterizer`) binds these with ctypes.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc'd, fp32 / int32 / int64 as
+ *     named), contiguous, row-major, owned by the caller; inputs are never
+ *     written; nothing is allocated or freed inside the library;
+ *   - every output element is written by the call (the reference relies on
+ *     torch::zeros pre-fill + early returns; here the kernels write the zeros
+ *     themselves), EXCEPT the four gradient accumulators of
+ *     gsr_rasterize_backward* which the call zero-fills itself before
+ *     accumulating;
+ *   - `stream` is a hipStream_t (NULL = the default stream); calls are
+ *     asynchronous on that stream and never synchronise the device;
+ *   - return value: 0 on success, a negative GSR_E* code otherwise, with a
+ *     human-readable message available from gsr_last_error() (thread-local).
+ *   - matrices are row-major; quaternions are (w,x,y,z); conics are the upper
+ *     triangle (a,b,c) of the inverse 2-D covariance; tile id = ty*tiles_x+tx.
+ */
+#ifndef GSRASTER_H_
+#define GSRASTER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 100 /* 0.1.0 */
+
+#define GSR_OK 0
+#define GSR_EINVAL -1   /* bad argument (shape / range / null pointer) */
+#define GSR_ELAUNCH -2  /* HIP reported a launch / runtime error */
+#define GSR_ENOMEM -3   /* workspace too small */
+
+typedef void *gsr_stream_t; /* hipStream_t */
+
+int gsr_version(void);
+/* message of the most recent failing call on this thread ("" if none) */
+const char *gsr_last_error(void);
+
+/* ---- projection -------------------------------------------------------
+ * replaces project_gaussians_forward_tensor (bindings.cu:107-160), kernel
+ * forward.cu:13-90.  viewmat: >= 12 floats (top 3x4), projmat: 16 floats.
+ * outputs: cov3d[n,6] xys[n,2] depths[n] radii[n](i32) conics[n,3]
+ *          compensation[n] num_tiles_hit[n](i32) */
+int gsr_project_forward(int num_points, const float *means3d,
+                        const float *scales, float glob_scale,
+                        const float *quats, const float *viewmat,
+                        const float *projmat, float fx, float fy, float cx,
+                        float cy, unsigned img_height, unsigned img_width,
+                        unsigned block_width, float clip_thresh, float *cov3d,
+                        float *xys, float *depths, int32_t *radii,
+                        float *conics, float *compensation,
+                        int32_t *num_tiles_hit, gsr_stream_t stream);
+
+/* replaces project_gaussians_backward_tensor (bindings.cu:164-216), kernel
+ * backward.cu:305-347.  outputs: v_cov2d[n,3] v_cov3d[n,6] v_mean3d[n,3]
+ * v_scale[n,3] v_quat[n,4] */
+int gsr_project_backward(int num_points, const float *means3d,
+                         const float *scales, float glob_scale,
+                         const float *quats, const float *viewmat,
+                         const float *projmat, float fx, float fy, float cx,
+                         float cy, unsigned img_height, unsigned img_width,
+                         const float *cov3d, const int32_t *radii,
+                         const float *conics, const float *compensation,
+                         const float *v_xy, const float *v_depth,
+                         const float *v_conic, const float *v_compensation,
+                         float *v_cov2d, float *v_cov3d, float *v_mean3d,
+                         float *v_scale, float *v_quat, gsr_stream_t stream);
+
+/* ---- spherical harmonics ----------------------------------------------
+ * replaces compute_sh_forward_tensor / compute_sh_backward_tensor
+ * (bindings.cu:58-103), kernels sh.cuh:188-224.  degree in 0..4 fixes the
+ * coefficient layout [n, (degree+1)^2, 3]; degrees_to_use <= degree. */
+int gsr_sh_forward(unsigned num_points, unsigned degree,
+                   unsigned degrees_to_use, const float *viewdirs,
+                   const float *coeffs, float *colors, gsr_stream_t stream);
+int gsr_sh_backward(unsigned num_points, unsigned degree,
+                    unsigned degrees_to_use, const float *viewdirs,
+                    const float *v_colors, float *v_coeffs,
+                    gsr_stream_t stream);
+
+/* ---- binning ------------------------------------------------------------
+ * inclusive int32 scan of num_tiles_hit; replaces the torch.cumsum of
+ * compute_cumulative_intersects (utils.py:106-125).  The total is cum[n-1]
+ * (device memory; the caller decides when to read it back). */
+size_t gsr_cumsum_workspace_bytes(int num_points);
+int gsr_cumsum_tiles(int num_points, const int32_t *num_tiles_hit,
+                     int32_t *cum_tiles_hit, void *workspace,
+                     size_t workspace_bytes, gsr_stream_t stream);
+
+/* replaces map_gaussian_to_intersects_tensor (bindings.cu:218-251), kernel
+ * forward.cu:94-127.  isect_ids[I] (i64) gaussian_ids[I] (i32). */
+int gsr_map_intersects(int num_points, int num_intersects, const float *xys,
+                       const float *depths, const int32_t *radii,
+                       const int32_t *cum_tiles_hit, int tiles_x, int tiles_y,
+                       unsigned block_width, int64_t *isect_ids,
+                       int32_t *gaussian_ids, gsr_stream_t stream);
+
+/* replaces torch.sort + torch.gather in bin_and_sort_gaussians
+ * (utils.py:179-180): stable ascending radix sort of the (tile|depth) keys
+ * over the significant bits only (32 depth bits + ceil(log2(num_tiles))). */
+size_t gsr_sort_workspace_bytes(int num_intersects);
+int gsr_sort_intersects(int num_intersects, int num_tiles,
+                        const int64_t *isect_ids, const int32_t *gaussian_ids,
+                        int64_t *isect_ids_sorted,
+                        int32_t *gaussian_ids_sorted, void *workspace,
+                        size_t workspace_bytes, gsr_stream_t stream);
+
+/* replaces get_tile_bin_edges_tensor (bindings.cu:253-267), kernel
+ * forward.cu:132-154.  tile_bins[num_tiles,2] (i32), (0,0) for empty tiles. */
+int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
+                       int num_tiles, int32_t *tile_bins, gsr_stream_t stream);
+
+/* ---- compositing ----------------------------------------------------------
+ * replaces rasterize_forward_tensor (bindings.cu:269-328), kernel
+ * forward.cu:278-395 (3 channels, fp32).  out_img[H,W,3] final_Ts[H,W]
+ * final_idx[H,W](i32). */
+int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_width,
+                          unsigned img_width, unsigned img_height,
+                          const int32_t *gaussian_ids_sorted,
+                          const int32_t *tile_bins, const float *xys,
+                          const float *conics, const float *colors,
+                          const float *opacities, const float *background,
+                          float *out_img, float *final_Ts, int32_t *final_idx,
+                          gsr_stream_t stream);
+
+/* replaces rasterize_backward_tensor (bindings.cu:476-528), kernel
+ * backward.cu:133-303.  v_xy[n,2] v_conic[n,3] v_colors[n,3] v_opacity[n]
+ * are zero-filled by the call, then accumulated with fp32 atomics. */
+int gsr_rasterize_backward(unsigned img_height, unsigned img_width,
+                           unsigned block_width, int num_points,
+                           const int32_t *gaussian_ids_sorted,
+                           const int32_t *tile_bins, const float *xys,
+                           const float *conics, const float *colors,
+                           const float *opacities, const float *background,
+                           const float *final_Ts, const int32_t *final_idx,
+                           const float *v_output, const float *v_output_alpha,
+                           float *v_xy, float *v_conic, float *v_colors,
+                           float *v_opacity, gsr_stream_t stream);
+
+/* generic channel count; replace nd_rasterize_forward_tensor /
+ * nd_rasterize_backward_tensor (bindings.cu:330-469), kernels
+ * forward.cu:159-276 / backward.cu:23-131.  Accumulation is fp32 here (the
+ * reference accumulates in __half). 1 <= channels <= GSR_MAX_CHANNELS. */
+#define GSR_MAX_CHANNELS 32
+int gsr_rasterize_forward_nd(int tiles_x, int tiles_y, unsigned block_width,
+                             unsigned img_width, unsigned img_height,
+                             unsigned channels,
+                             const int32_t *gaussian_ids_sorted,
+                             const int32_t *tile_bins, const float *xys,
+                             const float *conics, const float *colors,
+                             const float *opacities, const float *background,
+                             float *out_img, float *final_Ts,
+                             int32_t *final_idx, gsr_stream_t stream);
+int gsr_rasterize_backward_nd(unsigned img_height, unsigned img_width,
+                              unsigned block_width, unsigned channels,
+                              int num_points,
+                              const int32_t *gaussian_ids_sorted,
+                              const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors,
+                              const float *opacities, const float *background,
+                              const float *final_Ts, const int32_t *final_idx,
+                              const float *v_output,
+                              const float *v_output_alpha, float *v_xy,
+                              float *v_conic, float *v_colors,
+                              float *v_opacity, gsr_stream_t stream);
+
+/* replaces compute_cov2d_bounds_tensor (bindings.cu:39-56).
+ * conics[n,3] radii[n] (fp32) */
+int gsr_cov2d_bounds(int num_pts, const float *cov2d, float *conics,
+                     float *radii, gsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRASTER_H_ */
