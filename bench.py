@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- raster fwd+bwd Mpix/s @1080p, 1 M Gaussians, SH degree 3.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one view, through the public
+drop-in API (the three autograd Functions of `rasterizer`):
+  forward : project_gaussians -> spherical_harmonics -> clamp(+0.5)
+            -> rasterize_gaussians(return_alpha=True)   [scan, key emission,
+               radix sort, bin edges, compositing]
+  backward: rasterize backward -> SH backward -> project backward
+            for fixed cotangents (v_out_img, v_out_alpha)
+Inputs (Gaussian parameters, camera, cotangents) are resident in HBM before the
+timed region.  Multi-GPU: per-view data parallel -- every rank holds the full
+Gaussian set, renders its own camera, and the 59-float/Gaussian gradient is
+summed across ranks with one RCCL all-reduce per step (weak scaling).
+
+Prints ONE JSON line on rank 0 (see the keys at the bottom).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "gaussian-splatting-toolkit_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from harness import scene as S  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 measured copy
+
+KERNELS = (
+    # rasterizer.cuda attribute, key in the algorithmic-bytes table
+    ("project_gaussians_forward", "project_fwd"),
+    ("compute_sh_forward", "sh_fwd"),
+    ("cumsum_tiles", "scan"),
+    ("map_gaussian_to_intersects", "map"),
+    ("sort_intersects", "sort"),
+    ("get_tile_bin_edges", "bin_edges"),
+    ("rasterize_forward", "raster_fwd"),
+    ("rasterize_backward", "raster_bwd"),
+    ("compute_sh_backward", "sh_bwd"),
+    ("project_gaussians_backward", "project_bwd"),
+)
+
+
+class KernelTimers:
+    """HIP-event brackets around every native call.  The native calls enqueue
+    on torch's current stream, which is where these events are recorded."""
+
+    def __init__(self):
+        import rasterizer.cuda as C
+
+        self.C = C
+        self.pairs = {k: [] for _, k in KERNELS}
+        self.enabled = False
+        self._orig = {}
+        for attr, key in KERNELS:
+            fn = getattr(C, attr)
+            self._orig[attr] = fn
+            setattr(C, attr, self._wrap(fn, key))
+
+    def _wrap(self, fn, key):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pairs[key].append((e0, e1))
+            return out
+
+        return timed
+
+    def summary_ms(self):
+        return {k: (float(np.mean([a.elapsed_time(b) for a, b in v])) if v else 0.0)
+                for k, v in self.pairs.items()}
+
+
+def cpu_baseline(sc, cam, bg, v_img, v_alpha, deg):
+    """The CPU oracle (a port of the reference algorithm, oracle/gsr_oracle.c)
+    timed on the host cores over the same workload (one full fwd+bwd)."""
+    from oracle import oracle as O
+
+    n = sc["means3d"].shape[0]
+    threads = O.num_threads()
+    dirs = S.viewdirs_for(sc, cam)
+    t0 = time.perf_counter()
+    sh = O.compute_sh_forward(n, deg, deg, dirs, sc["sh_coeffs"])
+    rgbs = np.maximum(sh + 0.5, 0).astype(np.float32)
+    r = O.render_forward(sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat,
+                         cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width, 16, rgbs,
+                         sc["opacities"], bg)
+    t1 = time.perf_counter()
+    vxy, vconic, vcol, vop = O.rasterize_backward(
+        cam.height, cam.width, 16, r["gaussian_ids_sorted"], r["tile_bins"], r["xys"], r["conics"], rgbs,
+        sc["opacities"], bg, r["final_Ts"], r["final_idx"], v_img, v_alpha)
+    O.compute_sh_backward(n, deg, deg, dirs, (vcol * (sh + 0.5 > 0)).astype(np.float32))
+    zeros = np.zeros(n, np.float32)
+    O.project_gaussians_backward(n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3],
+                                 cam.projmat, cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width,
+                                 r["cov3d"], r["radii"], r["conics"], r["compensation"], vxy, zeros, vconic,
+                                 zeros)
+    t2 = time.perf_counter()
+    pix = cam.width * cam.height
+    return {
+        "value": pix / (t2 - t0) / 1e6,
+        "unit": "Mpix/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"1 full fwd+bwd of the same workload ({n} Gaussians, {cam.width}x{cam.height}); "
+                  f"fwd {t1 - t0:.2f}s bwd {t2 - t1:.2f}s; host has {os.cpu_count()} logical CPUs",
+    }, r["num_intersects"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from harness.parallel import allreduce_gradients
+    from harness.pipeline import CameraTensors, render_view
+
+    timers = KernelTimers()
+
+    # ---- workload: SURVEY.md 8(d), seed 42; one scene, one camera per rank
+    W, H, N, deg = args.width, args.height, args.gaussians, args.sh_degree
+    cam0 = S.make_camera(W, H)
+    sc = S.make_scene(N, cam0, sh_degree=deg, seed=42)
+    # rank r looks at the same cloud from a slightly different direction
+    cam = cam0 if rank == 0 else S.make_camera(W, H, yaw=0.02 * rank, pitch=0.01 * (rank % 3))
+    bg_np = np.array(S.BACKGROUND, np.float32)
+    v_img_np, v_alpha_np = S.make_cotangents(cam)
+
+    t = lambda a: torch.from_numpy(a).to(dev)
+    params = {k: t(v).requires_grad_(True) for k, v in sc.items()}
+    plist = [params[k] for k in ("means3d", "scales", "quats", "opacities", "sh_coeffs")]
+    camt = CameraTensors.from_numpy(cam, dev)
+    bg, v_img, v_alpha = t(bg_np), t(v_img_np), t(v_alpha_np)
+
+    def step():
+        for p in plist:
+            p.grad = None
+        out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
+                          params["sh_coeffs"], camt, bg, deg, clamp_rgb=False)
+        torch.autograd.backward([out["rgb"], out["alpha"]], [v_img, v_alpha[..., None]])
+        if world > 1:
+            allreduce_gradients(plist, average=True)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    num_intersects = int(out["num_tiles_hit"].sum().item())
+    n_visible = int((out["radii"] > 0).sum().item())
+
+    barrier()
+    timers.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timers.enabled = False
+
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    pixels = W * H
+    value = world * pixels / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        kern_ms = timers.summary_ms()
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        K = S.num_sh_bases(deg)
+        alg = S.algorithmic_bytes(N, num_intersects, pixels, tiles, K)
+        dominant = max(kern_ms, key=lambda k: kern_ms[k])
+        ach = alg[dominant] / (kern_ms[dominant] * 1e-3) / 1e9 if kern_ms[dominant] > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dominant)
+            except Exception:
+                traffic = None
+        roofline = {
+            "kernel": dominant, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "algorithmic_bytes": alg[dominant], "kernel_ms": round(kern_ms[dominant], 4),
+        }
+        # every kernel's own fraction, and the end-to-end figure from SURVEY 8(d)
+        per_kernel = {
+            k: {"ms": round(kern_ms[k], 4), "GBps": round(alg[k] / (kern_ms[k] * 1e-3) / 1e9, 1) if kern_ms[k] > 0 else 0.0}
+            for k in kern_ms
+        }
+        end_to_end = alg["total"] / (ms_per_step * 1e-3) / 1e9
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, _ = cpu_baseline(sc, cam, bg_np, v_img_np, v_alpha_np, deg)
+            cpu["value"] = round(cpu["value"], 4)
+
+        line = {
+            "metric": "raster fwd+bwd Mpix/s @1080p (1M Gaussians, SH3)",
+            "value": round(value, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{N} random Gaussians (SURVEY 8d, seed 42), SH degree {deg}, "
+                            f"{W}x{H}, block 16, fwd+bwd through the rasterizer autograd API",
+                "gaussians": N, "visible": n_visible, "intersections": num_intersects,
+                "mean_gaussians_per_tile": round(num_intersects / tiles, 1),
+                "parallelism": f"dp{world} (per-view; one flat-gradient all-reduce/step)" if world > 1 else "single",
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": per_kernel,
+            "end_to_end_algorithmic_GBps": round(end_to_end, 1),
+        }
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""CPU, world_size 2, gloo: the per-view data-parallel gradient exchange
+(harness/parallel.py) equals single-process accumulation over both views."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _view_grads(view):
+    """Per-view 'gradients' from the CPU oracle (the checker stands in for the
+    GPU kernels here: this test is about the exchange, not the rasterizer)."""
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from harness import scene as S
+    from oracle import oracle as O
+
+    cam = S.make_camera(48, 32, yaw=0.05 * view)
+    sc = S.make_scene(300, S.make_camera(48, 32), sh_degree=0, seed=9, scale_lo=0.03, scale_hi=0.2)
+    n = 300
+    colors = np.random.default_rng(1).uniform(0, 1, (n, 3)).astype(np.float32)
+    bg = np.zeros(3, np.float32)
+    r = O.render_forward(sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat, cam.fx,
+                         cam.fy, cam.cx, cam.cy, 32, 48, 16, colors, sc["opacities"], bg)
+    v_img, v_alpha = S.make_cotangents(cam, seed=100 + view)
+    vxy, vconic, vcol, vop = O.rasterize_backward(32, 48, 16, r["gaussian_ids_sorted"], r["tile_bins"], r["xys"],
+                                                  r["conics"], colors, sc["opacities"], bg, r["final_Ts"],
+                                                  r["final_idx"], v_img, v_alpha)
+    z = np.zeros(n, np.float32)
+    _, _, vmean, vscale, vquat = O.project_gaussians_backward(
+        n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat, cam.fx, cam.fy, cam.cx,
+        cam.cy, 32, 48, r["cov3d"], r["radii"], r["conics"], r["compensation"], vxy, z, vconic, z)
+    grads = [vmean, vscale, vquat, vop, vcol]
+    radii = r["radii"]
+    return [torch.from_numpy(g.copy()) for g in grads], torch.from_numpy(radii.copy())
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness.parallel import allreduce_densify_stats, allreduce_gradients, view_for_rank
+
+    view = view_for_rank(step=0, rank=rank, world_size=world, num_views=8)
+    grads, radii = _view_grads(view)
+    params = [torch.zeros_like(g).requires_grad_(True) for g in grads]
+    for p, g in zip(params, grads):
+        p.grad = g.clone()
+    params[3].grad = None  # a parameter without gradient is reduced as zeros
+    flat = allreduce_gradients(params, average=False)
+    # densification statistics: sum / sum / max
+    gn = torch.full((5,), float(rank + 1))
+    vc = torch.full((5,), rank + 1, dtype=torch.int32)
+    mx = torch.tensor([float(rank), 3.0 - rank])
+    allreduce_densify_stats(gn, vc, mx)
+    q.put((rank, view, [p.grad.clone() for p in params], flat.numel(), gn, vc, mx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_equals_accumulation():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    views = [r[1] for r in results]
+    assert views[0] != views[1]
+    g0, _ = _view_grads(views[0])
+    g1, _ = _view_grads(views[1])
+    expect = [a + b for a, b in zip(g0, g1)]
+    expect[3] = g1[3] * 0  # both ranks had grad=None for that parameter
+    for rank_res in results:
+        for got, exp in zip(rank_res[2], expect):
+            assert torch.allclose(got, exp, rtol=1e-6, atol=1e-7)
+        assert rank_res[3] == sum(e.numel() for e in expect)
+        assert torch.equal(rank_res[4], torch.full((5,), 3.0))
+        assert torch.equal(rank_res[5], torch.full((5,), 3, dtype=torch.int32))
+        assert torch.equal(rank_res[6], torch.tensor([1.0, 3.0]))
+    # both ranks hold bit-identical reduced gradients (replicas stay in sync)
+    for a, b in zip(results[0][2], results[1][2]):
+        assert torch.equal(a, b)
+
+
+def test_flatten_roundtrip_single_process():
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness.parallel import allreduce_gradients, flatten_grads, unflatten_to_grads
+
+    ps = [torch.randn(7, 3, requires_grad=True), torch.randn(7, 16, 3, requires_grad=True)]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    before = [p.grad.clone() for p in ps]
+    flat = flatten_grads(ps)
+    assert flat.numel() == 7 * 3 + 7 * 48
+    unflatten_to_grads(flat * 2, ps)
+    for p, b in zip(ps, before):
+        assert torch.equal(p.grad, b * 2)
+    allreduce_gradients(ps)  # no process group: identity
+    for p, b in zip(ps, before):
+        assert torch.equal(p.grad, b * 2)

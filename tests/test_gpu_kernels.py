@@ -1,0 +1,340 @@
+"""GPU: every HIP kernel, called through the C ABI (via `rasterizer.cuda`),
+against the CPU oracle on the same seeded inputs.
+
+Tolerances: integer / index outputs bit-exact; fp32 images 1e-4 abs on pixels
+whose discrete decisions are numerically stable (the oracle flags the others:
+|alpha - 1/255|, |T(1-alpha) - 1e-4| or |sigma| within 1e-5 relative -- a
+1-ulp difference in exp() legitimately flips those); gradients 1e-3 relative
+with an absolute floor of 1e-3 x max|grad| (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from harness import scene as S
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def rel_err(a, b, floor):
+    return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+
+def grad_close(mine, ref, tol=1e-3, name=""):
+    floor = 1e-3 * max(1e-6, float(np.abs(ref).max()))
+    e = rel_err(mine, ref, floor)
+    assert e.max() < tol, f"{name}: max rel err {e.max():.3e} at {np.unravel_index(e.argmax(), e.shape)}"
+
+
+def make(n, W, H, deg=3, seed=1, cam_kw=None, **kw):
+    cam = S.make_camera(W, H, **(cam_kw or {}))
+    sc = S.make_scene(n, cam, sh_degree=deg, seed=seed, **kw)
+    return cam, sc
+
+
+def project_cpu(cam, sc, bw=16, clip=0.01, glob=1.0):
+    n = sc["means3d"].shape[0]
+    return O.project_gaussians_forward(n, sc["means3d"], sc["scales"], glob, sc["quats"],
+                                       cam.viewmat[:3], cam.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+                                       cam.height, cam.width, bw, clip)
+
+
+def project_gpu(cam, sc, bw=16, clip=0.01, glob=1.0):
+    import rasterizer.cuda as C
+
+    n = sc["means3d"].shape[0]
+    return C.project_gaussians_forward(n, cu(sc["means3d"]), cu(sc["scales"]), glob, cu(sc["quats"]),
+                                       cu(cam.viewmat[:3]), cu(cam.projmat), cam.fx, cam.fy, cam.cx,
+                                       cam.cy, cam.height, cam.width, bw, clip)
+
+
+CASES = [
+    # n, W, H, bw, camera kwargs
+    (10_000, 256, 256, 16, {}),
+    (3_000, 200, 120, 16, dict(yaw=0.2, pitch=-0.1, roll=0.05, trans=(0.3, -0.2, 0.5))),
+    (2_000, 97, 61, 8, dict(yaw=-0.3)),
+    (500, 33, 47, 5, {}),
+]
+
+
+@pytest.mark.parametrize("n,W,H,bw,ck", CASES)
+def test_project_forward(n, W, H, bw, ck):
+    cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2)
+    ref = project_cpu(cam, sc, bw)
+    out = [npy(t) for t in project_gpu(cam, sc, bw)]
+    names = ["cov3d", "xys", "depths", "radii", "conics", "compensation", "num_tiles_hit"]
+    r = dict(zip(names, ref))
+    o = dict(zip(names, out))
+    # the radius is ceil(3 sqrt(lambda)): 1-ulp differences may move it by one
+    # on exact integers; such Gaussians are excluded from the exact checks.
+    same = o["radii"] == r["radii"]
+    assert same.mean() > 0.999
+    vis = (r["radii"] > 0) & same
+    assert np.array_equal(o["num_tiles_hit"][same], r["num_tiles_hit"][same])
+    np.testing.assert_allclose(o["xys"][vis], r["xys"][vis], rtol=1e-5, atol=2e-3)
+    np.testing.assert_allclose(o["depths"][vis], r["depths"][vis], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(o["cov3d"][vis], r["cov3d"][vis], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(o["conics"][vis], r["conics"][vis], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(o["compensation"][vis], r["compensation"][vis], rtol=1e-3, atol=1e-5)
+    # culled splats: everything the consumers read is zero
+    cul = (r["radii"] == 0) & same
+    for k in ("xys", "depths", "compensation", "num_tiles_hit"):
+        assert np.all(o[k][cul] == 0), k
+
+
+@pytest.mark.parametrize("n,W,H,bw,ck", CASES)
+def test_project_backward(n, W, H, bw, ck):
+    import rasterizer.cuda as C
+
+    cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    rng = np.random.default_rng(5)
+    v_xy = rng.standard_normal((n, 2)).astype(np.float32)
+    v_depth = rng.standard_normal(n).astype(np.float32)
+    v_conic = rng.standard_normal((n, 3)).astype(np.float32)
+    v_comp = rng.standard_normal(n).astype(np.float32)
+    ref = O.project_gaussians_backward(n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3],
+                                       cam.projmat, cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width,
+                                       cov3d, radii, conics, comp, v_xy, v_depth, v_conic, v_comp)
+    out = C.project_gaussians_backward(n, cu(sc["means3d"]), cu(sc["scales"]), 1.0, cu(sc["quats"]),
+                                       cu(cam.viewmat[:3]), cu(cam.projmat), cam.fx, cam.fy, cam.cx, cam.cy,
+                                       cam.height, cam.width, cu(cov3d), cu(radii), cu(conics), cu(comp),
+                                       cu(v_xy), cu(v_depth), cu(v_conic), cu(v_comp))
+    for o, r, nm in zip(out, ref, ["v_cov2d", "v_cov3d", "v_mean3d", "v_scale", "v_quat"]):
+        o = npy(o)
+        assert np.all(o[radii <= 0] == 0), nm
+        # per-row relative error (gradient magnitudes span many decades)
+        rowmax = np.abs(r).max(axis=-1, keepdims=True)
+        e = np.abs(o - r) / np.maximum(rowmax, 1e-6 * np.abs(r).max())
+        assert e.max() < 1e-3, f"{nm}: {e.max():.3e}"
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 63, 4097])
+def test_sh(deg, n):
+    import rasterizer.cuda as C
+
+    rng = np.random.default_rng(deg * 100 + n)
+    K = (deg + 1) ** 2
+    dirs = rng.standard_normal((n, 3)).astype(np.float32) * 3.0  # un-normalised on purpose
+    coeffs = rng.standard_normal((n, K, 3)).astype(np.float32)
+    v = rng.standard_normal((n, 3)).astype(np.float32)
+    for use in range(deg + 1):
+        ref = O.compute_sh_forward(n, deg, use, dirs, coeffs)
+        out = npy(C.compute_sh_forward(n, deg, use, cu(dirs), cu(coeffs)))
+        np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-5)
+        refb = O.compute_sh_backward(n, deg, use, dirs, v)
+        outb = npy(C.compute_sh_backward(n, deg, use, cu(dirs), cu(v)))
+        np.testing.assert_allclose(outb, refb, rtol=1e-4, atol=1e-6)
+        assert np.all(outb[:, (use + 1) ** 2:] == 0)
+
+
+@pytest.mark.parametrize("n,W,H,bw,ck", CASES)
+def test_binning_bit_exact(n, W, H, bw, ck):
+    """scan, key emission, sort, bin edges: integer work, bit-exact."""
+    import rasterizer.cuda as C
+    from rasterizer import utils as U
+
+    cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    I, cum = O.compute_cumulative_intersects(tiles)
+    I_g, cum_g = U.compute_cumulative_intersects(cu(tiles))
+    assert I_g == I and np.array_equal(npy(cum_g), cum)
+    ref = O.bin_and_sort_gaussians(n, I, xys, depths, radii, cum, tb, bw)
+    out = U.bin_and_sort_gaussians(n, I, cu(xys), cu(depths), cu(radii), cum_g, tb, bw)
+    for o, r, nm in zip(out, ref, ["isect", "gids", "isect_sorted", "gids_sorted", "tile_bins"]):
+        assert np.array_equal(npy(o), r), nm
+    ks = npy(out[2])
+    assert np.all(np.diff(ks) >= 0)
+    assert out[2].dtype == torch.int64 and out[3].dtype == torch.int32 and out[4].dtype == torch.int32
+
+
+def test_sort_is_stable_on_ties():
+    """Equal (tile, depth) keys keep emission order (ascending Gaussian id)."""
+    import rasterizer.cuda as C
+
+    rng = np.random.default_rng(0)
+    I = 100_000
+    tiles = rng.integers(0, 37, I).astype(np.int64)
+    depth = rng.integers(1, 9, I).astype(np.int64)  # many duplicates
+    keys = (tiles << 32) | depth
+    vals = np.arange(I, dtype=np.int32)
+    ks, vs = C.sort_intersects(cu(keys), cu(vals), 37)
+    rk, rv = O.sort_intersects(keys, vals)
+    assert np.array_equal(npy(ks), rk) and np.array_equal(npy(vs), rv)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(rv, vals[order])
+
+
+def raster_inputs(n, W, H, bw, ck, channels=3, seed=1, **kw):
+    cam, sc = make(n, W, H, cam_kw=ck, seed=seed, **kw)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    I, cum = O.compute_cumulative_intersects(tiles)
+    _, _, ks, vs, bins = O.bin_and_sort_gaussians(n, I, xys, depths, radii, cum, tb, bw)
+    rng = np.random.default_rng(seed + 7)
+    colors = rng.uniform(0, 1, (n, channels)).astype(np.float32)
+    bg = rng.uniform(0, 1, channels).astype(np.float32)
+    return dict(cam=cam, tb=tb, bw=bw, I=I, vs=vs, bins=bins, xys=xys, conics=conics, colors=colors,
+                opac=sc["opacities"], bg=bg, n=n, W=W, H=H)
+
+
+RASTER_CASES = [
+    (10_000, 256, 256, 16, {}, dict(scale_lo=0.005, scale_hi=0.05)),
+    (4_000, 200, 120, 16, dict(yaw=0.2, pitch=-0.1), dict(scale_lo=0.02, scale_hi=0.3)),  # dense: T<=1e-4 path
+    (20_000, 97, 61, 16, {}, dict(scale_lo=0.01, scale_hi=0.1)),  # ragged edges, long lists
+    (2_000, 97, 61, 8, dict(yaw=-0.3), dict(scale_lo=0.02, scale_hi=0.2)),
+    (500, 33, 47, 5, {}, dict(scale_lo=0.02, scale_hi=0.2)),
+]
+
+
+def check_image(out, Ts, ref, amb):
+    ok = ~amb
+    assert ok.mean() > 0.98
+    np.testing.assert_allclose(out[ok], ref[0][ok], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(Ts[ok], ref[1][ok], rtol=0, atol=1e-4)
+    # unstable pixels may differ by one splat's contribution, never by garbage
+    assert np.abs(out - ref[0]).max() < 0.05
+
+
+@pytest.mark.parametrize("n,W,H,bw,ck,kw", RASTER_CASES)
+def test_rasterize_forward(n, W, H, bw, ck, kw):
+    import rasterizer.cuda as C
+
+    d = raster_inputs(n, W, H, bw, ck, **kw)
+    ref = O.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), d["vs"], d["bins"], d["xys"], d["conics"],
+                              d["colors"], d["opac"], d["bg"], ambig_eps=1e-5)
+    out, Ts, idx = C.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), cu(d["vs"]), cu(d["bins"]),
+                                       cu(d["xys"]), cu(d["conics"]), cu(d["colors"]), cu(d["opac"]),
+                                       cu(d["bg"]))
+    check_image(npy(out), npy(Ts), ref, ref[3])
+    ok = ~ref[3]
+    assert np.array_equal(npy(idx)[ok], ref[2][ok])  # index of the last contributing splat
+    assert idx.dtype == torch.int32
+
+
+@pytest.mark.parametrize("n,W,H,bw,ck,kw", RASTER_CASES)
+def test_rasterize_backward(n, W, H, bw, ck, kw):
+    import rasterizer.cuda as C
+
+    d = raster_inputs(n, W, H, bw, ck, **kw)
+    out, Ts, idx = O.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), d["vs"], d["bins"], d["xys"],
+                                       d["conics"], d["colors"], d["opac"], d["bg"])
+    rng = np.random.default_rng(11)
+    v_img = rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)
+    v_alpha = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    ref = O.rasterize_backward(H, W, bw, d["vs"], d["bins"], d["xys"], d["conics"], d["colors"], d["opac"],
+                               d["bg"], Ts, idx, v_img, v_alpha)
+    got = C.rasterize_backward(H, W, bw, cu(d["vs"]), cu(d["bins"]), cu(d["xys"]), cu(d["conics"]),
+                               cu(d["colors"]), cu(d["opac"]), cu(d["bg"]), cu(Ts), cu(idx), cu(v_img),
+                               cu(v_alpha))
+    assert got[3].shape == (n, 1)
+    for g, r, nm in zip(got, ref, ["v_xy", "v_conic", "v_colors", "v_opacity"]):
+        grad_close(npy(g), r, name=nm)
+
+
+@pytest.mark.parametrize("channels", [1, 4, 7, 32])
+def test_nd_rasterize(channels):
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 3000, 120, 90, 16
+    d = raster_inputs(n, W, H, bw, {}, channels=channels, scale_lo=0.02, scale_hi=0.2)
+    ref = O.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), d["vs"], d["bins"], d["xys"], d["conics"],
+                              d["colors"], d["opac"], d["bg"], ambig_eps=1e-5)
+    out, Ts, idx = C.nd_rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), cu(d["vs"]), cu(d["bins"]),
+                                          cu(d["xys"]), cu(d["conics"]), cu(d["colors"]), cu(d["opac"]),
+                                          cu(d["bg"]))
+    check_image(npy(out), npy(Ts), ref, ref[3])
+    rng = np.random.default_rng(3)
+    v_img = rng.uniform(-1, 1, (H, W, channels)).astype(np.float32)
+    v_alpha = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    refb = O.rasterize_backward(H, W, bw, d["vs"], d["bins"], d["xys"], d["conics"], d["colors"], d["opac"],
+                                d["bg"], ref[1], ref[2], v_img, v_alpha)
+    got = C.nd_rasterize_backward(H, W, bw, cu(d["vs"]), cu(d["bins"]), cu(d["xys"]), cu(d["conics"]),
+                                  cu(d["colors"]), cu(d["opac"]), cu(d["bg"]), cu(ref[1]), cu(ref[2]),
+                                  cu(v_img), cu(v_alpha))
+    for g, r, nm in zip(got, refb, ["v_xy", "v_conic", "v_colors", "v_opacity"]):
+        grad_close(npy(g), r, name=nm)
+
+
+def test_tile16_matches_generic_kernel():
+    """The wave-per-tile kernels and the lane-per-pixel kernels implement the same rule."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 8000, 160, 112, 16
+    d = raster_inputs(n, W, H, bw, {}, scale_lo=0.01, scale_hi=0.15)
+    a = (d["tb"], (bw, bw, 1), (W, H, 1), cu(d["vs"]), cu(d["bins"]), cu(d["xys"]), cu(d["conics"]),
+         cu(d["colors"]), cu(d["opac"]), cu(d["bg"]))
+    o1 = C.rasterize_forward(*a)
+    o2 = C.nd_rasterize_forward(*a)
+    assert (o1[0] - o2[0]).abs().max().item() < 1e-5
+    assert (o1[2] == o2[2]).float().mean().item() > 0.9999
+    v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
+    v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
+    b = (H, W, bw) + a[3:] + (o1[1], o1[2], v_img, v_alpha)
+    g1 = C.rasterize_backward(*b)
+    g2 = C.nd_rasterize_backward(*b)
+    for x, y in zip(g1, g2):
+        grad_close(npy(x), npy(y), tol=2e-3)
+
+
+def test_backward_alpha_saturation_follows_cuda_rule():
+    """opacity*exp(-sigma) > 0.99: forward clamps at 0.999, backward at 0.99
+    (forward.cu:360 vs backward.cu:232).  Unpinned by the torch oracle; the C
+    oracle follows the CUDA source and the HIP kernel must follow it too."""
+    import rasterizer.cuda as C
+
+    W = H = 32
+    bw = 16
+    n = 6
+    xys = np.array([[8.2, 8.1], [9.0, 7.5], [20.3, 20.2], [21.0, 19.0], [8.0, 24.0], [24.0, 8.0]], np.float32)
+    conics = np.tile(np.array([[0.05, 0.0, 0.05]], np.float32), (n, 1))
+    opac = np.array([[0.9999], [0.6], [0.9999], [0.9999], [0.995], [0.5]], np.float32)
+    colors = np.random.default_rng(0).uniform(0, 1, (n, 3)).astype(np.float32)
+    depths = np.linspace(1, 2, n).astype(np.float32)
+    radii = np.full(n, 30, np.int32)
+    tb = (2, 2, 1)
+    tiles = np.full(n, 4, np.int32)
+    I, cum = O.compute_cumulative_intersects(tiles)
+    _, _, ks, vs, bins = O.bin_and_sort_gaussians(n, I, xys, depths, radii, cum, tb, bw)
+    bg = np.array([0.2, 0.3, 0.4], np.float32)
+    out, Ts, idx = O.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), vs, bins, xys, conics, colors, opac, bg)
+    rng = np.random.default_rng(2)
+    v_img = rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)
+    v_alpha = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    ref = O.rasterize_backward(H, W, bw, vs, bins, xys, conics, colors, opac, bg, Ts, idx, v_img, v_alpha)
+    o = C.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), cu(vs), cu(bins), cu(xys), cu(conics), cu(colors),
+                            cu(opac), cu(bg))
+    np.testing.assert_allclose(npy(o[0]), out, atol=1e-4)
+    got = C.rasterize_backward(H, W, bw, cu(vs), cu(bins), cu(xys), cu(conics), cu(colors), cu(opac), cu(bg),
+                               cu(Ts), cu(idx), cu(v_img), cu(v_alpha))
+    for g, r, nm in zip(got, ref, ["v_xy", "v_conic", "v_colors", "v_opacity"]):
+        grad_close(npy(g), r, name=nm)
+
+
+def test_cov2d_bounds():
+    import rasterizer.cuda as C
+
+    rng = np.random.default_rng(4)
+    n = 1000
+    a = rng.uniform(0.3, 50, n)
+    c = rng.uniform(0.3, 50, n)
+    b = rng.uniform(-0.9, 0.9, n) * np.sqrt(a * c)
+    cov = np.stack([a, b, c], -1).astype(np.float32)
+    ref = O.compute_cov2d_bounds(n, cov)
+    got = C.compute_cov2d_bounds(n, cu(cov))
+    np.testing.assert_allclose(npy(got[0]), ref[0], rtol=1e-4, atol=1e-7)
+    r_g, r_r = npy(got[1]), ref[1]
+    assert got[1].shape == (n, 1)
+    assert (r_g == r_r).mean() > 0.995 and np.abs(r_g - r_r).max() <= 1
