@@ -27,19 +27,22 @@
 // ends with exactly one fully reduced (splat, component) per lane, so one
 // wave-wide global_atomic_add_f32 retires 64 components: 9 atomics per
 // tile-splat instead of 72.
-#include "gsr_common.h"
+#include <stdlib.h>
+
+#include "raster_common.h"
+
+#ifndef GSR_BWD_GROUP
+#define GSR_BWD_GROUP 4
+#endif
 
 namespace {
 
-constexpr int kChunk = 64;
-constexpr int kGroup = 8;  // splats reduced together
+using namespace gsr;
 
-struct __align__(16) SplatA { float x, y, ha, b; };
-struct __align__(16) SplatB { float hc, opac, r, g; };
-
-#define DPP_QUAD_XOR1 0xB1        // quad_perm:[1,0,3,2]
-#define DPP_QUAD_XOR2 0x4E        // quad_perm:[2,3,0,1]
-#define DPP_ROW_HALF_MIRROR 0x141 // lane l <-> 7-l inside each 8 lanes
+#define DPP_QUAD_XOR1 0xB1         // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E         // quad_perm:[2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141  // lane l <-> 7-l inside each 8 lanes
+#define DPP_ROW_ROR8 0x128         // lane l <-> l^8 inside each row of 16
 
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
@@ -56,56 +59,90 @@ __device__ __forceinline__ float fold16(float a, float b) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// halving step inside a row: the lane keeps x if !bit else y, and receives the
+// same quantity from its DPP partner (whose `bit` is the opposite)
+template <int CTRL>
+__device__ __forceinline__ float halve(float x, float y, bool bit) {
+  const float keep = bit ? y : x;
+  const float send = bit ? x : y;
+  return keep + dpp<CTRL>(send);
+}
 
-// 72 lane-partials P[9*j + c] (splat j<8, component c<9) -> per lane:
-//   `main`  = component comp_of_lane() of splat (lane>>3), summed over the wave
-//   `extra` = component 8 of splat (lane>>3), summed over the wave (all 8 lanes)
-__device__ __forceinline__ void butterfly72(float (&P)[72], int lane, float &main_v,
-                                            float &extra_v) {
-  float Q[36];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) Q[i] = fold32(P[i], P[i + 36]);  // lane bit 5 <-> splat bit 2
-  float R[18];
-#pragma unroll
-  for (int i = 0; i < 18; ++i) R[i] = fold16(Q[i], Q[i + 18]);  // lane bit 4 <-> splat bit 1
-  const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
-  float S[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {  // lane bit 3 <-> splat bit 0 (row_ror:8 pairs l, l^8)
-    const float keep = b3 ? R[i + 9] : R[i];
-    const float send = b3 ? R[i] : R[i + 9];
-    S[i] = keep + dpp<0x128>(send);
+// Wave-wide sums of G*9 lane-partials P[9*j + c] (splat j < G, component c < 9).
+//  G == 8: lane l ends with component comp_of_lane(l) of splat l>>3 in `main_v`
+//          and component 8 of splat l>>3 in `extra_v` (all 8 lanes of a group).
+//  G == 4: lane l ends with component comp_of_lane(l) of splat l>>4 in `main_v`
+//          (duplicated in lanes l and l^2) and component 8 of splat l>>4 in
+//          `extra_v` (all 16 lanes of the row).
+template <int G>
+struct Butterfly;
+
+template <>
+struct Butterfly<8> {
+  static __device__ __forceinline__ int splat_of_lane(int lane) { return lane >> 3; }
+  static __device__ __forceinline__ int comp_of_lane(int lane) {
+    return ((lane & 4) ? 4 : 0) + ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0);
   }
-  // 8 lanes now share one splat: halve components 0..7 over lane bits 2,0,1
-  float U[4];
+  static __device__ __forceinline__ bool owns_main(int) { return true; }
+  static __device__ __forceinline__ bool owns_extra(int lane) { return (lane & 7) == 0; }
+  static __device__ __forceinline__ void run(float (&P)[72], int lane, float &main_v, float &extra_v) {
+    float Q[36];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float keep = b2 ? S[i + 4] : S[i];
-    const float send = b2 ? S[i] : S[i + 4];
-    U[i] = keep + dpp<DPP_ROW_HALF_MIRROR>(send);
-  }
-  float V[2];
+    for (int i = 0; i < 36; ++i) Q[i] = fold32(P[i], P[i + 36]);  // lane bit 5 <-> splat bit 2
+    float R[18];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float keep = b0 ? U[i + 2] : U[i];
-    const float send = b0 ? U[i] : U[i + 2];
-    V[i] = keep + dpp<DPP_QUAD_XOR1>(send);
+    for (int i = 0; i < 18; ++i) R[i] = fold16(Q[i], Q[i + 18]);  // lane bit 4 <-> splat bit 1
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float S[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) S[i] = halve<DPP_ROW_ROR8>(R[i], R[i + 9], b3);  // splat bit 0
+    float U[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) U[i] = halve<DPP_ROW_HALF_MIRROR>(S[i], S[i + 4], b2);
+    float V[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) V[i] = halve<DPP_QUAD_XOR1>(U[i], U[i + 2], b0);
+    main_v = halve<DPP_QUAD_XOR2>(V[0], V[1], b1);
+    float e = S[8];
+    e += dpp<DPP_ROW_HALF_MIRROR>(e);
+    e += dpp<DPP_QUAD_XOR1>(e);
+    e += dpp<DPP_QUAD_XOR2>(e);
+    extra_v = e;
   }
-  {
-    const float keep = b1 ? V[1] : V[0];
-    const float send = b1 ? V[0] : V[1];
-    main_v = keep + dpp<DPP_QUAD_XOR2>(send);
+};
+
+template <>
+struct Butterfly<4> {
+  static __device__ __forceinline__ int splat_of_lane(int lane) { return lane >> 4; }
+  static __device__ __forceinline__ int comp_of_lane(int lane) {
+    return ((lane & 8) ? 4 : 0) + ((lane & 4) ? 2 : 0) + ((lane & 1) ? 1 : 0);
   }
-  float e = S[8];
-  e += dpp<DPP_ROW_HALF_MIRROR>(e);
-  e += dpp<DPP_QUAD_XOR1>(e);
-  e += dpp<DPP_QUAD_XOR2>(e);
-  extra_v = e;
-}
-// component index that butterfly72 leaves in `main` for a lane
-__device__ __forceinline__ int comp_of_lane(int lane) {
-  return ((lane & 4) ? 4 : 0) + ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0);
-}
+  static __device__ __forceinline__ bool owns_main(int lane) { return (lane & 2) == 0; }
+  static __device__ __forceinline__ bool owns_extra(int lane) { return (lane & 15) == 0; }
+  static __device__ __forceinline__ void run(float (&P)[36], int lane, float &main_v, float &extra_v) {
+    float Q[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) Q[i] = fold32(P[i], P[i + 18]);  // lane bit 5 <-> splat bit 1
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = fold16(Q[i], Q[i + 9]);    // lane bit 4 <-> splat bit 0
+    const bool b3 = lane & 8, b2 = lane & 4, b0 = lane & 1;
+    float S[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[i] = halve<DPP_ROW_ROR8>(R[i], R[i + 4], b3);
+    float U[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) U[i] = halve<DPP_ROW_HALF_MIRROR>(S[i], S[i + 2], b2);
+    const float v = halve<DPP_QUAD_XOR1>(U[0], U[1], b0);
+    main_v = v + dpp<DPP_QUAD_XOR2>(v);
+    float e = R[8];
+    e += dpp<DPP_ROW_ROR8>(e);
+    e += dpp<DPP_ROW_HALF_MIRROR>(e);
+    e += dpp<DPP_QUAD_XOR1>(e);
+    e += dpp<DPP_QUAD_XOR2>(e);
+    extra_v = e;
+  }
+};
 
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
@@ -113,6 +150,7 @@ __device__ __forceinline__ int wave_max(int v) {
   return v;
 }
 
+template <int G>
 __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
@@ -124,8 +162,9 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity) {
   __shared__ SplatA sA[kChunk];
   __shared__ SplatB sB[kChunk];
-  __shared__ float sBlue[kChunk];
+  __shared__ SplatC sC[kChunk];
   __shared__ int sId[kChunk];
+  using BF = Butterfly<G>;
 
   const int tile = (int)gsr_xcd_remap(blockIdx.x, (unsigned)num_tiles);
   const int2 range = tile_bins[tile];
@@ -135,6 +174,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   const int qx = tx * 16 + 2 * (lane & 7), qy = ty * 16 + 2 * (lane >> 3);
   const float fx0 = (float)qx, fx1 = (float)(qx + 1);
   const float fy0 = (float)qy, fy1 = (float)(qy + 1);
+  const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
   const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
 
   float T[4], K[4], vr[4], vg[4], vb[4], br[4], bgr[4], bb[4];
@@ -163,31 +203,24 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   if (top < range.x) return;
 
   // lane-constant destination of the `main` value
-  const int comp = comp_of_lane(lane);
+  const int comp = BF::comp_of_lane(lane);
   float *const dst_base = comp < 2 ? v_xy : (comp < 5 ? v_conic : v_colors);
   const int dst_stride = comp < 2 ? 2 : 3;
   const int dst_off = comp < 2 ? comp : (comp < 5 ? comp - 2 : comp - 5);
+  const bool owns_main = BF::owns_main(lane), owns_extra = BF::owns_extra(lane);
 
   for (int hi = top; hi >= range.x; hi -= kChunk) {
-    // slot t of the chunk holds sorted index hi - t (back to front)
-    const int idx = hi - lane;
-    if (idx >= range.x) {
-      const int g = ids_sorted[idx];
-      const float2 xy = xys[g];
-      const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
-      sA[lane] = SplatA{xy.x, xy.y, 0.5f * a, b};
-      sB[lane] = SplatB{0.5f * c, opacities[g], colors[3 * g], colors[3 * g + 1]};
-      sBlue[lane] = colors[3 * g + 2];
-      sId[lane] = g;
-    }
+    // back to front: lane l fetches sorted index hi - l; kept splats stay in that order
+    const int sidx_l = hi - lane;
+    const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics,
+                                  colors, opacities, sA, sB, sC, sId);
     __syncthreads();
-    const int count = min(kChunk, hi - range.x + 1);
 
-    for (int t0 = 0; t0 < count; t0 += kGroup) {
-      float P[72];
+    for (int t0 = 0; t0 < count; t0 += G) {
+      float P[9 * G];
       bool lane_any = false;
 #pragma unroll
-      for (int j = 0; j < kGroup; ++j) {
+      for (int j = 0; j < G; ++j) {
         const int t = t0 + j;
         float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f;
         float sr = 0.f, sg = 0.f, sb = 0.f;
@@ -195,12 +228,11 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
         if (t < count) {  // wave-uniform
           const SplatA A = sA[t];
           const SplatB B = sB[t];
-          const float blue = sBlue[t];
+          const SplatC C = sC[t];
           ha = A.ha;
           hc = B.hc;
           cb_ = A.b;
           opac = B.opac;
-          const int sidx = hi - t;
           const float dx0 = A.x - fx0, dx1 = A.x - fx1;
           const float dy0 = A.y - fy0, dy1 = A.y - fy1;
           const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
@@ -215,20 +247,20 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             const float sigma = sig[p];
             const float vis = __expf(-sigma);
             const float alpha = fminf(GSR_ALPHA_MAX_BWD, B.opac * vis);
-            const bool valid = (sidx <= binf[p]) && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
-            const float ra = __frcp_rn(1.f - alpha);
+            const bool valid = (C.sidx <= binf[p]) && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
             const float Tn = T[p] * ra;
             const float fac_ = alpha * Tn;
             float v_alpha = (B.r * Tn - br[p] * ra) * vr[p];
             v_alpha += (B.g * Tn - bgr[p] * ra) * vg[p];
-            v_alpha += (blue * Tn - bb[p] * ra) * vb[p];
+            v_alpha += (C.blue * Tn - bb[p] * ra) * vb[p];
             v_alpha += K[p] * ra;
             const float w = valid ? vis * v_alpha : 0.f;
             const float fac = valid ? fac_ : 0.f;
             T[p] = valid ? Tn : T[p];
             br[p] += B.r * fac;
             bgr[p] += B.g * fac;
-            bb[p] += blue * fac;
+            bb[p] += C.blue * fac;
             sr += fac * vr[p];
             sg += fac * vg[p];
             sb += fac * vb[p];
@@ -254,15 +286,16 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
         P[9 * j + 7] = sb;
         P[9 * j + 8] = m0;
       }
-      if (!__any(lane_any)) continue;  // nothing in this group touched the tile
+      if (!__any(lane_any)) continue;  // nothing in this group touched a live pixel
 
       float main_v, extra_v;
-      butterfly72(P, lane, main_v, extra_v);
-      const int t = t0 + (lane >> 3);
+      BF::run(P, lane, main_v, extra_v);
+      const int t = t0 + BF::splat_of_lane(lane);
       if (t < count) {
         const int g = sId[t];
-        if (main_v != 0.f) unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, main_v);
-        if ((lane & 7) == 0 && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
+        if (owns_main && main_v != 0.f)
+          unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, main_v);
+        if (owns_extra && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
       }
     }
     __syncthreads();
@@ -468,12 +501,21 @@ GSR_EXPORT int gsr_rasterize_backward(
   if (rc != GSR_OK) return rc;
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
-  hipLaunchKernelGGL(raster_bwd_tile16_kernel, dim3(num_tiles), dim3(64), 0, s, tiles_x, num_tiles,
-                     (int)img_width, (int)img_height, gaussian_ids_sorted,
-                     reinterpret_cast<const int2 *>(tile_bins),
-                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
-                     final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,
-                     v_opacity);
+  // A/B knob for the reduction group size (4 or 8 splats per butterfly)
+  static const int group = [] {
+    const char *e = getenv("GSR_BWD_GROUP");
+    return (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : GSR_BWD_GROUP;
+  }();
+#define GSR_LAUNCH_T16(G)                                                                          \
+  hipLaunchKernelGGL(raster_bwd_tile16_kernel<G>, dim3(num_tiles), dim3(64), 0, s, tiles_x,         \
+                     num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,               \
+                     reinterpret_cast<const int2 *>(tile_bins),                                     \
+                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,  \
+                     final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,        \
+                     v_opacity)
+  if (group == 8) GSR_LAUNCH_T16(8);
+  else GSR_LAUNCH_T16(4);
+#undef GSR_LAUNCH_T16
   GSR_CHECK_LAUNCH("rasterize_backward(tile16)");
   return GSR_OK;
 }

@@ -1,0 +1,81 @@
+// raster_common.h -- pieces shared by the two wave-per-tile compositing kernels.
+#pragma once
+#include "gsr_common.h"
+
+namespace gsr {
+
+constexpr int kChunk = 64;  // splats staged per LDS fill (one per lane)
+
+// LDS record of one staged splat; consumed by wave-uniform broadcast reads.
+struct __align__(16) SplatA { float x, y, ha, b; };     // ha = a/2
+struct __align__(16) SplatB { float hc, opac, r, g; };  // hc = c/2
+struct __align__(8) SplatC { float blue; int sidx; };   // sidx = index in the sorted list
+// (0.5*(a dx^2 + c dy^2) == (a/2) dx^2 + (c/2) dy^2 exactly: scaling by a power
+//  of two commutes with rounding)
+
+// Can ANY pixel centre of the 16x16 tile whose first pixel is (tx0, ty0) get
+// alpha = opac*exp(-sigma) >= 1/255 from this splat?  The tile lists are built
+// from the 3-sigma *square* bounding box (forward.cu:73), so about half of the
+// entries of a tile never pass the alpha test at any of its pixels; they are
+// dropped here, once per tile, by the lane that fetched them.  Dropping them
+// cannot change a result: the compositing rule skips them pixel by pixel
+// (alpha < 1/255 -> continue).  The test is conservative: sigma is minimised
+// over the continuous rectangle (<= its minimum over the pixel centres) and the
+// threshold carries a 1 % margin in alpha, far above fp32 rounding.
+__device__ __forceinline__ bool splat_reaches_tile(float x, float y, float a, float b, float c,
+                                                   float opac, float tx0, float ty0) {
+  // alpha >= 1/255  <=>  sigma <= log(255*opac)
+  const float smax = __logf(255.f * opac) + 0.01f;
+  if (!(smax >= 0.f)) return !(opac == opac);  // too faint anywhere (NaN: keep, let the rule decide)
+  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;  // not positive definite: no culling
+  const float u0 = tx0 - x, u1 = u0 + 15.f, v0 = ty0 - y, v1 = v0 + 15.f;
+  if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;  // centre inside the tile
+  // convex quadratic, unconstrained minimum (0,0) outside the rectangle ->
+  // the minimum over the rectangle lies on one of its four edges
+  const float nb_c = -b / c, nb_a = -b / a;
+  auto edge_u = [&](float ue) {
+    const float v = fminf(fmaxf(nb_c * ue, v0), v1);
+    return 0.5f * (a * ue * ue + c * v * v) + b * ue * v;
+  };
+  auto edge_v = [&](float ve) {
+    const float u = fminf(fmaxf(nb_a * ve, u0), u1);
+    return 0.5f * (a * u * u + c * ve * ve) + b * u * ve;
+  };
+  const float smin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
+  return smin <= smax;
+}
+
+// Stage up to 64 splats (sorted indices first .. first+step*63, `live` lanes only)
+// into LDS, dropping the ones that cannot reach the tile; returns how many were kept.
+// Kept splats stay in list order.  Wave-synchronous (one wave per workgroup).
+__device__ __forceinline__ int stage_chunk(
+    const int lane, const bool live, const int sidx, const float tx0, const float ty0,
+    const int *__restrict__ ids_sorted, const float2 *__restrict__ xys,
+    const float *__restrict__ conics, const float *__restrict__ colors,
+    const float *__restrict__ opacities, SplatA *sA, SplatB *sB, SplatC *sC, int *sId) {
+  bool keep = false;
+  int g = 0;
+  float2 xy = make_float2(0.f, 0.f);
+  float a = 0.f, b = 0.f, c = 0.f, opac = 0.f;
+  if (live) {
+    g = ids_sorted[sidx];
+    xy = xys[g];
+    a = conics[3 * g];
+    b = conics[3 * g + 1];
+    c = conics[3 * g + 2];
+    opac = opacities[g];
+    keep = splat_reaches_tile(xy.x, xy.y, a, b, c, opac, tx0, ty0);
+  }
+  const unsigned long long mask = __ballot(keep);
+  if (keep) {
+    const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                               __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    sA[slot] = SplatA{xy.x, xy.y, 0.5f * a, b};
+    sB[slot] = SplatB{0.5f * c, opac, colors[3 * g], colors[3 * g + 1]};
+    sC[slot] = SplatC{colors[3 * g + 2], sidx};
+    if (sId) sId[slot] = g;
+  }
+  return __popcll(mask);
+}
+
+}  // namespace gsr

@@ -19,18 +19,16 @@
 //    rasterises a contiguous band of tiles (shared splats stay in one L2).
 //  * generic (any block_width in [2,16], any channel count <= 32): one lane
 //    per pixel, block_width^2 lanes per tile.
-#include "gsr_common.h"
+#include "raster_common.h"
 
 namespace {
 
+using namespace gsr;
+
 // ------------------------------------------------------------------ tile16
-constexpr int kChunk = 64;
-
-struct __align__(16) SplatA { float x, y, ha, b; };      // ha = a/2
-struct __align__(16) SplatB { float hc, opac, r, g; };   // hc = c/2
-// (0.5*(a dx^2 + c dy^2) == (a/2) dx^2 + (c/2) dy^2 exactly: scaling by a
-//  power of two commutes with rounding)
-
+// Per-pixel state: T is the live transmittance (0 once the pixel has finished
+// or lies outside the image, which makes every later splat a no-op), Tend keeps
+// the value to report.
 __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
@@ -40,7 +38,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     float *__restrict__ final_Ts, int *__restrict__ final_idx) {
   __shared__ SplatA sA[kChunk];
   __shared__ SplatB sB[kChunk];
-  __shared__ float sBlue[kChunk];
+  __shared__ SplatC sC[kChunk];
 
   const int tile = (int)gsr_xcd_remap(blockIdx.x, (unsigned)num_tiles);
   const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -48,38 +46,33 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   const int qx = tx * 16 + 2 * (lane & 7), qy = ty * 16 + 2 * (lane >> 3);
   const float fx0 = (float)qx, fx1 = (float)(qx + 1);
   const float fy0 = (float)qy, fy1 = (float)(qy + 1);
+  const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
 
   // pixel p = (qx + (p&1), qy + (p>>1))
-  bool done[4];
-  float T[4], cr[4], cg[4], cb[4];
+  float T[4], Tend[4], cr[4], cg[4], cb[4];
   int last[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    done[p] = !((qx + (p & 1)) < img_w && (qy + (p >> 1)) < img_h);
-    T[p] = 1.f;
+    const bool inside = (qx + (p & 1)) < img_w && (qy + (p >> 1)) < img_h;
+    T[p] = inside ? 1.f : 0.f;
+    Tend[p] = 1.f;
     cr[p] = cg[p] = cb[p] = 0.f;
     last[p] = 0;
   }
 
   const int2 range = tile_bins[tile];
   for (int base = range.x; base < range.y; base += kChunk) {
-    if (__all(done[0] && done[1] && done[2] && done[3])) break;
-    const int idx = base + lane;
-    if (idx < range.y) {
-      const int g = ids_sorted[idx];
-      const float2 xy = xys[g];
-      const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
-      sA[lane] = SplatA{xy.x, xy.y, 0.5f * a, b};
-      sB[lane] = SplatB{0.5f * c, opacities[g], colors[3 * g], colors[3 * g + 1]};
-      sBlue[lane] = colors[3 * g + 2];
-    }
+    // the whole tile is finished when no pixel has transmittance left
+    if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) == 0.f)) break;
+    const int sidx = base + lane;
+    const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics,
+                                  colors, opacities, sA, sB, sC, nullptr);
     __syncthreads();
-    const int count = min(kChunk, range.y - base);
     for (int t = 0; t < count; ++t) {
-      if ((t & 7) == 0 && __all(done[0] && done[1] && done[2] && done[3])) break;
+      if ((t & 7) == 7 && __all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) == 0.f)) break;
       const SplatA A = sA[t];
       const SplatB B = sB[t];
-      const float blue = sBlue[t];
+      const SplatC C = sC[t];
       const float dx0 = A.x - fx0, dx1 = A.x - fx1;
       const float dy0 = A.y - fy0, dy1 = A.y - fy1;
       const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
@@ -91,17 +84,18 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       for (int p = 0; p < 4; ++p) {
         const float sigma = sig[p];
         const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
-        const bool hit = !done[p] && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+        const bool hit = !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
         const float next_T = T[p] * (1.f - alpha);
-        const bool stop = hit && (next_T <= GSR_T_EPS);
-        const bool draw = hit && !stop;
+        // T == 0 (finished / outside) gives next_T == 0: neither drawn nor "stopped again"
+        const bool draw = hit && (next_T > GSR_T_EPS);
+        const bool stop = hit && !draw && (T[p] > 0.f);
         const float vis = draw ? alpha * T[p] : 0.f;
         cr[p] += B.r * vis;
         cg[p] += B.g * vis;
-        cb[p] += blue * vis;
-        T[p] = draw ? next_T : T[p];
-        last[p] = draw ? (base + t) : last[p];
-        done[p] = done[p] || stop;
+        cb[p] += C.blue * vis;
+        Tend[p] = draw ? next_T : Tend[p];
+        last[p] = draw ? C.sidx : last[p];
+        T[p] = draw ? next_T : (stop ? 0.f : T[p]);
       }
     }
     __syncthreads();
@@ -114,11 +108,11 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int col = qx + (p & 1), row = qy + (p >> 1);
     if (col < img_w && row < img_h) {
       const size_t pid = (size_t)row * img_w + col;
-      final_Ts[pid] = T[p];
+      final_Ts[pid] = Tend[p];
       final_idx[pid] = last[p];
-      out_img[3 * pid] = cr[p] + T[p] * bg0;
-      out_img[3 * pid + 1] = cg[p] + T[p] * bg1;
-      out_img[3 * pid + 2] = cb[p] + T[p] * bg2;
+      out_img[3 * pid] = cr[p] + Tend[p] * bg0;
+      out_img[3 * pid + 1] = cg[p] + Tend[p] * bg1;
+      out_img[3 * pid + 2] = cb[p] + Tend[p] * bg2;
     }
   }
 }

@@ -7,11 +7,14 @@
 // (forward) / zero (backward).
 //
 // HBM-bound streaming op; the coefficient tensor is the largest per-Gaussian
-// read of the whole path (192 B at degree 3).  For K == 16 the work is mapped
-// 16 lanes per Gaussian: lane (g,k) moves exactly one contiguous 12-B
-// coefficient triple, so a wave-wide load/store covers 768 contiguous bytes;
-// the 16-term dot product is a DPP row reduction (a row is 16 lanes on CDNA).
-// Other degrees use one lane per Gaussian.
+// read of the whole path (192 B at degree 3).  One lane per Gaussian; at K == 16
+// with 16-byte-aligned buffers each lane moves its 192 contiguous bytes as 12
+// dwordx4 accesses (every fetched 128-B line is fully consumed by the same lane
+// a few instructions later, so L1/L2 turn the stride into full-line traffic).
+// Design notes from tools/exp/shbench.hip on MI355X, 3 M Gaussians (576 MB,
+// larger than the 256 MiB Infinity Cache): lane-per-Gaussian dwordx4 4.5 TB/s,
+// 16-lanes-per-Gaussian dwordx3 + DPP row reduction 3.6 TB/s; the backward is
+// write-bound at 2.2-2.4 TB/s either way.
 #include "gsr_common.h"
 
 namespace {
@@ -40,112 +43,117 @@ namespace {
 #define C4_7 -1.7701307697799304f
 #define C4_8 0.6258357354491761f
 
-// basis vector up to `deg` for direction d (normalised here); B[k] = 0 above.
+// Basis vector for direction d (normalised here); bands above `deg` are zero.
+// Written branch-free over constant indices on purpose: with early returns the
+// compiler keeps B[] as a memory object and promotes it to LDS, which turned
+// this streaming op into an LDS-bank-conflict-bound one (measured 0.9 TB/s
+// instead of 3.6-4.5 TB/s).
 template <int KMAX>
 __device__ __forceinline__ void sh_basis(unsigned deg, float dx, float dy, float dz,
                                          float (&B)[KMAX]) {
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) B[k] = 0.f;
-  B[0] = C0;
-  if (deg < 1 || KMAX < 4) return;
-  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-  const float x = dx / nrm, y = dy / nrm, z = dz / nrm;
-  if constexpr (KMAX >= 4) {
-    B[1] = -C1 * y;
-    B[2] = C1 * z;
-    B[3] = -C1 * x;
-  }
-  if (deg < 2 || KMAX < 9) return;
+  const float inv = rsqrtf(dx * dx + dy * dy + dz * dz);
+  const float x = dx * inv, y = dy * inv, z = dz * inv;
   const float xx = x * x, xy = x * y, xz = x * z, yy = y * y, yz = y * z, zz = z * z;
+  const float m1 = deg >= 1 ? 1.f : 0.f, m2 = deg >= 2 ? 1.f : 0.f;
+  const float m3 = deg >= 3 ? 1.f : 0.f, m4 = deg >= 4 ? 1.f : 0.f;
+  B[0] = C0;
+  if constexpr (KMAX >= 4) {
+    B[1] = m1 * (-C1 * y);
+    B[2] = m1 * (C1 * z);
+    B[3] = m1 * (-C1 * x);
+  }
   if constexpr (KMAX >= 9) {
-    B[4] = C2_0 * xy;
-    B[5] = C2_1 * yz;
-    B[6] = C2_2 * (2.f * zz - xx - yy);
-    B[7] = C2_3 * xz;
-    B[8] = C2_4 * (xx - yy);
+    B[4] = m2 * (C2_0 * xy);
+    B[5] = m2 * (C2_1 * yz);
+    B[6] = m2 * (C2_2 * (2.f * zz - xx - yy));
+    B[7] = m2 * (C2_3 * xz);
+    B[8] = m2 * (C2_4 * (xx - yy));
   }
-  if (deg < 3 || KMAX < 16) return;
   if constexpr (KMAX >= 16) {
-    B[9] = C3_0 * y * (3.f * xx - yy);
-    B[10] = C3_1 * xy * z;
-    B[11] = C3_2 * y * (4.f * zz - xx - yy);
-    B[12] = C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
-    B[13] = C3_4 * x * (4.f * zz - xx - yy);
-    B[14] = C3_5 * z * (xx - yy);
-    B[15] = C3_6 * x * (xx - 3.f * yy);
+    B[9] = m3 * (C3_0 * y * (3.f * xx - yy));
+    B[10] = m3 * (C3_1 * xy * z);
+    B[11] = m3 * (C3_2 * y * (4.f * zz - xx - yy));
+    B[12] = m3 * (C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy));
+    B[13] = m3 * (C3_4 * x * (4.f * zz - xx - yy));
+    B[14] = m3 * (C3_5 * z * (xx - yy));
+    B[15] = m3 * (C3_6 * x * (xx - 3.f * yy));
   }
-  if (deg < 4 || KMAX < 25) return;
   if constexpr (KMAX >= 25) {
-    B[16] = C4_0 * xy * (xx - yy);
-    B[17] = C4_1 * yz * (3.f * xx - yy);
-    B[18] = C4_2 * xy * (7.f * zz - 1.f);
-    B[19] = C4_3 * yz * (7.f * zz - 3.f);
-    B[20] = C4_4 * (zz * (35.f * zz - 30.f) + 3.f);
-    B[21] = C4_5 * xz * (7.f * zz - 3.f);
-    B[22] = C4_6 * (xx - yy) * (7.f * zz - 1.f);
-    B[23] = C4_7 * xz * (xx - 3.f * yy);
-    B[24] = C4_8 * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy));
+    B[16] = m4 * (C4_0 * xy * (xx - yy));
+    B[17] = m4 * (C4_1 * yz * (3.f * xx - yy));
+    B[18] = m4 * (C4_2 * xy * (7.f * zz - 1.f));
+    B[19] = m4 * (C4_3 * yz * (7.f * zz - 3.f));
+    B[20] = m4 * (C4_4 * (zz * (35.f * zz - 30.f) + 3.f));
+    B[21] = m4 * (C4_5 * xz * (7.f * zz - 3.f));
+    B[22] = m4 * (C4_6 * (xx - yy) * (7.f * zz - 1.f));
+    B[23] = m4 * (C4_7 * xz * (xx - 3.f * yy));
+    B[24] = m4 * (C4_8 * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy)));
   }
 }
+// (a zero direction gives NaN in the bands >= 1 when they are in use, exactly
+//  like the reference's x / norm; with deg == 0 the masks multiply NaN by 0 ->
+//  guard: the degree-0 term never touches the direction)
 
-// select B[k] for a lane-varying k without indexing registers dynamically
-template <int KMAX>
-__device__ __forceinline__ float pick(const float (&B)[KMAX], int k) {
-  float r = B[0];
-#pragma unroll
-  for (int j = 1; j < KMAX; ++j) r = (k == j) ? B[j] : r;
-  return r;
-}
-
-// sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row
-__device__ __forceinline__ float row_sum16(float v) {
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x111, 0xf, 0xf, true));  // row_shr:1
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x112, 0xf, 0xf, true));  // row_shr:2
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x114, 0xf, 0xf, true));  // row_shr:4
-  v += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x118, 0xf, 0xf, true));  // row_shr:8
-  return v;
-}
-
-// ---- K == 16: 16 lanes per Gaussian ---------------------------------------
+// ---- K == 16, 16-byte aligned coefficients: one lane per Gaussian ----------
+// Each lane streams its own 192 contiguous bytes with 12 dwordx4 accesses
+// (measured 4.5 TB/s forward, 2.2 TB/s backward (write-bound) on 3 M Gaussians).
 __global__ __launch_bounds__(256) void sh16_fwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
-    const float *__restrict__ coeffs, float *__restrict__ colors) {
-  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;  // (g,k) flat
-  const unsigned g = e >> 4;
-  const int k = (int)(e & 15u);
-  const bool live = g < n;
-  const unsigned gs = live ? g : (n - 1);
+    const float4 *__restrict__ coeffs, float *__restrict__ colors) {
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const float4 *c = coeffs + (size_t)g * 12;
+  float4 q[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) q[i] = c[i];
   float B[16];
-  sh_basis<16>(deg_use, viewdirs[3 * gs], viewdirs[3 * gs + 1], viewdirs[3 * gs + 2], B);
-  const float bk = pick<16>(B, k);
-  const float *c = coeffs + (size_t)gs * 48 + 3 * k;
-  const float r = row_sum16(bk * c[0]);
-  const float gr = row_sum16(bk * c[1]);
-  const float b = row_sum16(bk * c[2]);
-  if (live && k == 15) {
-    colors[3 * g] = r;
-    colors[3 * g + 1] = gr;
-    colors[3 * g + 2] = b;
+  sh_basis<16>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+  if (deg_use == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) B[k] = 0.f;
   }
+  const float f[48] = {
+      q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w,
+      q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w,
+      q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w, q[8].x, q[8].y, q[8].z, q[8].w,
+      q[9].x, q[9].y, q[9].z, q[9].w, q[10].x, q[10].y, q[10].z, q[10].w, q[11].x, q[11].y, q[11].z, q[11].w};
+  float r = 0.f, gr = 0.f, b = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    r += B[k] * f[3 * k];
+    gr += B[k] * f[3 * k + 1];
+    b += B[k] * f[3 * k + 2];
+  }
+  colors[3 * g] = r;
+  colors[3 * g + 1] = gr;
+  colors[3 * g + 2] = b;
 }
 
 __global__ __launch_bounds__(256) void sh16_bwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
-    const float *__restrict__ v_colors, float *__restrict__ v_coeffs) {
-  const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned g = e >> 4;
-  const int k = (int)(e & 15u);
+    const float *__restrict__ v_colors, float4 *__restrict__ v_coeffs) {
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   float B[16];
   sh_basis<16>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
-  const float bk = pick<16>(B, k);
-  float *o = v_coeffs + (size_t)g * 48 + 3 * k;
-  o[0] = bk * v_colors[3 * g];
-  o[1] = bk * v_colors[3 * g + 1];
-  o[2] = bk * v_colors[3 * g + 2];
+  if (deg_use == 0) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) B[k] = 0.f;
+  }
+  const float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
+  float f[48];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    f[3 * k] = B[k] * vr;
+    f[3 * k + 1] = B[k] * vg;
+    f[3 * k + 2] = B[k] * vb;
+  }
+  float4 *o = v_coeffs + (size_t)g * 12;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) o[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
 }
 
-// ---- any degree: one lane per Gaussian -------------------------------------
+// ---- any degree / any alignment: one lane per Gaussian, dword accesses -----
 template <int K>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
@@ -154,6 +162,10 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(
   if (g >= n) return;
   float B[K];
   sh_basis<K>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+  if (deg_use == 0) {
+#pragma unroll
+    for (int k = 1; k < K; ++k) B[k] = 0.f;
+  }
   const float *c = coeffs + (size_t)g * K * 3;
   float r = 0.f, gr = 0.f, b = 0.f;
 #pragma unroll
@@ -175,6 +187,10 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(
   if (g >= n) return;
   float B[K];
   sh_basis<K>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+  if (deg_use == 0) {
+#pragma unroll
+    for (int k = 1; k < K; ++k) B[k] = 0.f;
+  }
   const float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
   float *o = v_coeffs + (size_t)g * K * 3;
 #pragma unroll
@@ -184,6 +200,8 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(
     o[3 * k + 2] = B[k] * vb;
   }
 }
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
@@ -201,8 +219,11 @@ GSR_EXPORT int gsr_sh_forward(unsigned num_points, unsigned degree, unsigned deg
     case 1: hipLaunchKernelGGL(sh_fwd_kernel<4>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors); break;
     case 2: hipLaunchKernelGGL(sh_fwd_kernel<9>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors); break;
     case 3:
-      hipLaunchKernelGGL(sh16_fwd_kernel, dim3(gsr_cdiv(num_points, 16)), blk, 0, s, num_points,
-                         degrees_to_use, viewdirs, coeffs, colors);
+      if (aligned16(coeffs))
+        hipLaunchKernelGGL(sh16_fwd_kernel, grd, blk, 0, s, num_points, degrees_to_use, viewdirs,
+                           reinterpret_cast<const float4 *>(coeffs), colors);
+      else
+        hipLaunchKernelGGL(sh_fwd_kernel<16>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors);
       break;
     default: hipLaunchKernelGGL(sh_fwd_kernel<25>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors); break;
   }
@@ -224,8 +245,11 @@ GSR_EXPORT int gsr_sh_backward(unsigned num_points, unsigned degree, unsigned de
     case 1: hipLaunchKernelGGL(sh_bwd_kernel<4>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs); break;
     case 2: hipLaunchKernelGGL(sh_bwd_kernel<9>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs); break;
     case 3:
-      hipLaunchKernelGGL(sh16_bwd_kernel, dim3(gsr_cdiv(num_points, 16)), blk, 0, s, num_points,
-                         degrees_to_use, viewdirs, v_colors, v_coeffs);
+      if (aligned16(v_coeffs))
+        hipLaunchKernelGGL(sh16_bwd_kernel, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors,
+                           reinterpret_cast<float4 *>(v_coeffs));
+      else
+        hipLaunchKernelGGL(sh_bwd_kernel<16>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs);
       break;
     default: hipLaunchKernelGGL(sh_bwd_kernel<25>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs); break;
   }

@@ -71,8 +71,11 @@ def test_golden_end_to_end(golden_dir, name):
 
     loss = (img * cu(g["v_out_img"])).sum() + (alpha * cu(g["v_out_alpha"])).sum()
     loss.backward()
-    if amb.any():
-        pytest.skip("scene has numerically unstable pixels; gradients compared in kernel tests")
+    # a numerically unstable pixel whose decision really flipped would also
+    # change the per-Gaussian gradient sums; only then is the comparison void
+    flipped = np.abs(npy(img) - g["out_img"]).max() > 1e-4
+    if flipped:
+        pytest.skip("an unstable pixel flipped; gradients are compared in the kernel tests")
     grad_close(npy(xys.grad), g["g_xys"], name="xys")
     grad_close(npy(conics.grad), g["g_conics"], name="conics")
     grad_close(npy(colors.grad), g["g_colors"], name="colors")
