@@ -43,10 +43,8 @@ KERNELS = (
     # rasterizer.cuda attribute, key in the algorithmic-bytes table
     ("project_gaussians_forward", "project_fwd"),
     ("compute_sh_forward", "sh_fwd"),
-    ("cumsum_tiles", "scan"),
-    ("map_gaussian_to_intersects", "map"),
-    ("sort_intersects", "sort"),
-    ("get_tile_bin_edges", "bin_edges"),
+    ("depth_order", "depth_order"),
+    ("bin_sorted", "bin_sorted"),
     ("rasterize_forward", "raster_fwd"),
     ("rasterize_backward", "raster_bwd"),
     ("compute_sh_backward", "sh_bwd"),

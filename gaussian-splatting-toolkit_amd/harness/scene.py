@@ -121,6 +121,7 @@ def algorithmic_bytes(n: int, num_intersects: int, pixels: int, tiles: int, sh_b
     per = {
         "project_fwd": 100 * N,
         "sh_fwd": (12 + 12 * K) * N + 12 * N,
+        # binning as the reference organises it (scan, map, sort, bin edges) ...
         "scan": 8 * N,
         "map": 20 * N + 12 * I,
         "sort": 24 * I,
@@ -130,5 +131,8 @@ def algorithmic_bytes(n: int, num_intersects: int, pixels: int, tiles: int, sh_b
         "project_bwd": 188 * N,
         "sh_bwd": 24 * N + 12 * K * N,
     }
-    per["total"] = sum(per.values())
+    # ... and grouped the way the fused pipeline launches it (same formula)
+    per["depth_order"] = per["scan"]
+    per["bin_sorted"] = per["map"] + per["sort"] + per["bin_edges"]
+    per["total"] = sum(v for k, v in per.items() if k not in ("depth_order", "bin_sorted"))
     return per

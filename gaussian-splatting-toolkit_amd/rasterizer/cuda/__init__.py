@@ -233,6 +233,47 @@ def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: Tensor,
     return tile_bins
 
 
+def depth_order(depths: Tensor, radii: Tensor, num_tiles_hit: Tensor) -> Tuple[Tensor, Tensor]:
+    """First half of the fused binning pipeline (``gsr_depth_order``):
+    -> (order i32[N], cum_sorted i32[N]); ``cum_sorted[-1]`` is the number of
+    intersections."""
+    _check(depths, "depths", _f32)
+    _check(radii, "radii", _i32)
+    _check(num_tiles_hit, "num_tiles_hit", _i32)
+    n = depths.numel()
+    dev = depths.device
+    with torch.cuda.device(dev):
+        order = torch.empty((n,), dtype=_i32, device=dev)
+        cum = torch.empty((n,), dtype=_i32, device=dev)
+        nbytes = int(_lib().gsr_depth_order_workspace_bytes(C.c_int(n)))
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _call("gsr_depth_order", C.c_int(n), _ptr(depths), _ptr(radii), _ptr(num_tiles_hit), _ptr(order),
+              _ptr(cum), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+    return order, cum
+
+
+def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Tensor, xys: Tensor,
+               radii: Tensor, tile_bounds: Tuple[int, int, int], block_width: int) -> Tuple[Tensor, Tensor]:
+    """Second half (``gsr_bin_sorted``): -> (gaussian_ids_sorted i32[I],
+    tile_bins i32[T,2]), identical to what ``bin_and_sort_gaussians`` returns."""
+    _check(order, "order", _i32)
+    _check(cum_sorted, "cum_sorted", _i32)
+    _check(xys, "xys", _f32)
+    _check(radii, "radii", _i32)
+    I = int(num_intersects)
+    nt = int(tile_bounds[0]) * int(tile_bounds[1])
+    dev = xys.device
+    with torch.cuda.device(dev):
+        ids = torch.empty((I,), dtype=_i32, device=dev)
+        tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
+        nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I)))
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _call("gsr_bin_sorted", C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted),
+              _ptr(xys), _ptr(radii), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
+              C.c_uint(block_width), _ptr(ids), _ptr(tile_bins), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+    return ids, tile_bins
+
+
 def _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background):
     _check(gaussian_ids_sorted, "gaussian_ids_sorted", _i32)
     _check(tile_bins, "tile_bins", _i32)

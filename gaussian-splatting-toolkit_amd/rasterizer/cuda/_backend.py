@@ -28,6 +28,10 @@ SYMBOLS = (
     "gsr_sort_workspace_bytes",
     "gsr_sort_intersects",
     "gsr_tile_bin_edges",
+    "gsr_depth_order_workspace_bytes",
+    "gsr_depth_order",
+    "gsr_bin_sorted_workspace_bytes",
+    "gsr_bin_sorted",
     "gsr_rasterize_forward",
     "gsr_rasterize_backward",
     "gsr_rasterize_forward_nd",
@@ -57,6 +61,8 @@ def _load():
     lib.gsr_version.restype = C.c_int
     lib.gsr_cumsum_workspace_bytes.restype = C.c_size_t
     lib.gsr_sort_workspace_bytes.restype = C.c_size_t
+    lib.gsr_depth_order_workspace_bytes.restype = C.c_size_t
+    lib.gsr_bin_sorted_workspace_bytes.restype = C.c_size_t
     return lib
 
 

@@ -21,7 +21,6 @@ from torch import Tensor
 from torch.autograd import Function
 
 import rasterizer.cuda as _C
-from .utils import bin_and_sort_gaussians, compute_cumulative_intersects
 
 _bin_cache = {"key": None, "value": None, "keepalive": None}
 
@@ -99,12 +98,15 @@ class _RasterizeGaussians(Function):
         if _bin_cache["key"] == key:
             num_intersects, gaussian_ids_sorted, tile_bins = _bin_cache["value"]
         else:
-            num_intersects, cum_tiles_hit = compute_cumulative_intersects(num_tiles_hit)
+            # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
+            # compute_cumulative_intersects + bin_and_sort_gaussians, bit for bit
+            # (tests/test_gpu_kernels.py::test_fused_binning_equals_reference_pipeline)
+            order, cum_sorted = _C.depth_order(depths, radii, num_tiles_hit)
+            num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
             gaussian_ids_sorted = tile_bins = None
             if num_intersects >= 1:
-                _, _, _, gaussian_ids_sorted, tile_bins = bin_and_sort_gaussians(
-                    num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds,
-                    block_width,
+                gaussian_ids_sorted, tile_bins = _C.bin_sorted(
+                    num_points, num_intersects, order, cum_sorted, xys, radii, tile_bounds, block_width
                 )
             _bin_cache["key"] = key
             _bin_cache["value"] = (num_intersects, gaussian_ids_sorted, tile_bins)

@@ -122,6 +122,29 @@ int gsr_sort_intersects(int num_intersects, int num_tiles,
 int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
                        int num_tiles, int32_t *tile_bins, gsr_stream_t stream);
 
+/* ---- binning, fused pipeline ---------------------------------------------
+ * What `_RasterizeGaussians.forward` needs from bin_and_sort_gaussians
+ * (utils.py:128-182) is only `gaussian_ids_sorted` and `tile_bins`.  These two
+ * calls produce exactly those (bit-identical to map + 64-bit sort + bin edges)
+ * with ~4x less HBM traffic: Gaussians are ordered by depth once, intersections
+ * are emitted in that order and then stably sorted by tile id only.
+ *   gsr_depth_order : order[n] = Gaussian indices by (depth, index), culled
+ *                     first; cum_sorted[n] = inclusive scan of num_tiles_hit in
+ *                     that order (cum_sorted[n-1] = number of intersections).
+ *   gsr_bin_sorted  : gaussian_ids_sorted[I], tile_bins[T,2]. */
+size_t gsr_depth_order_workspace_bytes(int num_points);
+int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
+                    const int32_t *num_tiles_hit, int32_t *order,
+                    int32_t *cum_sorted, void *workspace,
+                    size_t workspace_bytes, gsr_stream_t stream);
+size_t gsr_bin_sorted_workspace_bytes(int num_intersects);
+int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
+                   const int32_t *cum_sorted, const float *xys,
+                   const int32_t *radii, int tiles_x, int tiles_y,
+                   unsigned block_width, int32_t *gaussian_ids_sorted,
+                   int32_t *tile_bins, void *workspace, size_t workspace_bytes,
+                   gsr_stream_t stream);
+
 /* ---- compositing ----------------------------------------------------------
  * replaces rasterize_forward_tensor (bindings.cu:269-328), kernel
  * forward.cu:278-395 (3 channels, fp32).  out_img[H,W,3] final_Ts[H,W]

@@ -150,21 +150,23 @@ def test_depth_pass_and_binning_cache():
     cam = S.make_camera(160, 96, yaw=0.1)
     sc = S.make_scene(3000, cam, sh_degree=1, seed=3, scale_lo=0.01, scale_hi=0.1)
     params = {k: cu(v, True) for k, v in sc.items()}
+    import rasterizer.cuda as C
+
     R._bin_cache["key"] = None
     calls = {"n": 0}
-    orig = R.bin_and_sort_gaussians
+    orig = C.bin_sorted
 
     def counting(*a, **k):
         calls["n"] += 1
         return orig(*a, **k)
 
-    R.bin_and_sort_gaussians = counting
+    C.bin_sorted = counting
     try:
         out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
                           params["sh_coeffs"], CameraTensors.from_numpy(cam, DEV),
                           cu(np.array(S.BACKGROUND, np.float32)), 1, render_depth=True)
     finally:
-        R.bin_and_sort_gaussians = orig
+        C.bin_sorted = orig
     assert calls["n"] == 1
     depth = out["depth"]
     assert depth.shape == (96, 160, 1) and torch.isfinite(depth).all()

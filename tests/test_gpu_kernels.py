@@ -160,6 +160,31 @@ def test_binning_bit_exact(n, W, H, bw, ck):
     assert out[2].dtype == torch.int64 and out[3].dtype == torch.int32 and out[4].dtype == torch.int32
 
 
+@pytest.mark.parametrize("n,W,H,bw,ck", CASES + [(200_000, 640, 360, 16, {})])
+def test_fused_binning_equals_reference_pipeline(n, W, H, bw, ck):
+    """depth_order + bin_sorted (what rasterize_gaussians runs) produce the same
+    gaussian_ids_sorted / tile_bins as scan + map + 64-bit sort + bin edges."""
+    import rasterizer.cuda as C
+
+    cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    # force depth ties: equal keys must keep ascending Gaussian id
+    depths = depths.copy()
+    depths[radii > 0] = np.round(depths[radii > 0] * 4) / 4
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    I, cum = O.compute_cumulative_intersects(tiles)
+    _, _, ks, vs, bins = O.bin_and_sort_gaussians(n, I, xys, depths, radii, cum, tb, bw)
+    order, cum_sorted = C.depth_order(cu(depths), cu(radii), cu(tiles))
+    assert int(cum_sorted[-1].item()) == I
+    o = npy(order)
+    assert np.array_equal(np.sort(o), np.arange(n))
+    dkey = np.where(radii > 0, depths, 0).astype(np.float32)
+    assert np.all(np.diff(dkey[o]) >= 0)
+    ids, tile_bins = C.bin_sorted(n, I, order, cum_sorted, cu(xys), cu(radii), tb, bw)
+    assert np.array_equal(npy(ids), vs)
+    assert np.array_equal(npy(tile_bins), bins)
+
+
 def test_sort_is_stable_on_ties():
     """Equal (tile, depth) keys keep emission order (ascending Gaussian id)."""
     import rasterizer.cuda as C
