@@ -81,6 +81,12 @@ __global__ __launch_bounds__(256) void tile_bin_edges32_kernel(const int num_int
   }
 }
 
+// rocPRIM switches to block-sort + log2(n/4096) merge passes below 2^20 items
+// (21 launches, ~150 us for 1 M keys on MI355X); Onesweep (histogram + one
+// launch per 8-bit digit) is the better fit from ~64 k items on.
+using depth_sort_config =
+    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 inline unsigned tile_bits(int num_tiles) {
@@ -91,8 +97,9 @@ inline unsigned tile_bits(int num_tiles) {
 
 size_t depth_sort_temp(int n) {
   size_t b = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, b, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                  rocprim::counting_iterator<int>(0), (int *)nullptr, (size_t)n, 0, 31);
+  (void)rocprim::radix_sort_pairs<depth_sort_config>(nullptr, b, (const unsigned *)nullptr,
+                                                     (unsigned *)nullptr, rocprim::counting_iterator<int>(0),
+                                                     (int *)nullptr, (size_t)n, 0, 31);
   return b;
 }
 size_t scan_temp(int n) {
@@ -137,9 +144,9 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   hipLaunchKernelGGL(depth_keys_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, num_points,
                      depths, radii, keys_in);
   GSR_CHECK_LAUNCH("depth_order(keys)");
-  GSR_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned *)keys_in, keys_out,
-                                          rocprim::counting_iterator<int>(0), order, (size_t)num_points,
-                                          0u, 31u, s));
+  GSR_CHECK_HIP(rocprim::radix_sort_pairs<depth_sort_config>(
+      temp, temp_bytes, (const unsigned *)keys_in, keys_out, rocprim::counting_iterator<int>(0), order,
+      (size_t)num_points, 0u, 31u, s));
   auto in = rocprim::make_transform_iterator((const int *)order, TilesInOrder{num_tiles_hit});
   GSR_CHECK_HIP(rocprim::inclusive_scan(temp, temp_bytes, in, cum_sorted, (size_t)num_points,
                                         rocprim::plus<int>(), s));

@@ -171,9 +171,9 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   if (range.y <= range.x) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
-  const int qx = tx * 16 + 2 * (lane & 7), qy = ty * 16 + 2 * (lane >> 3);
-  const float fx0 = (float)qx, fx1 = (float)(qx + 1);
-  const float fy0 = (float)qy, fy1 = (float)(qy + 1);
+  const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
+  const float fx0 = (float)qx, fx1 = (float)(qx + 8);
+  const float fy0 = (float)qy, fy1 = (float)(qy + 8);
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
   const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   int binf[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int col = qx + (p & 1), row = qy + (p >> 1);
+    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
     const bool inside = col < img_w && row < img_h;
     T[p] = 1.f;
     K[p] = vr[p] = vg[p] = vb[p] = 0.f;
@@ -199,7 +199,11 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
       binf[p] = final_idx[pid];
     }
   }
-  const int top = min(range.y - 1, wave_max(max(max(binf[0], binf[1]), max(binf[2], binf[3]))));
+  // last sorted index any pixel of sub-tile p still needs (wave-uniform)
+  int topp[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) topp[p] = wave_max(binf[p]);
+  const int top = min(range.y - 1, max(max(topp[0], topp[1]), max(topp[2], topp[3])));
   if (top < range.x) return;
 
   // lane-constant destination of the `main` value
@@ -244,6 +248,9 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
           const float dys[4] = {dy0, dy0, dy1, dy1};
 #pragma unroll
           for (int p = 0; p < 4; ++p) {
+            // wave-uniform: sub-tile out of the splat's reach, or every pixel of
+            // it finished in front of this splat
+            if (!((C.mask >> p) & 1) || C.sidx > topp[p]) continue;
             const float sigma = sig[p];
             const float vis = __expf(-sigma);
             const float alpha = fminf(GSR_ALPHA_MAX_BWD, B.opac * vis);
@@ -445,6 +452,13 @@ int launch_generic(unsigned img_h, unsigned img_w, unsigned bw, unsigned channel
 
 int zero_grads(int n, unsigned channels, float *v_xy, float *v_conic, float *v_colors,
                float *v_opacity, hipStream_t s) {
+  // one fill when the four accumulators are slices of one allocation (the
+  // Python binding lays them out back to back), four otherwise
+  if (v_conic == v_xy + 2 * (size_t)n && v_colors == v_conic + 3 * (size_t)n &&
+      v_opacity == v_colors + (size_t)channels * n) {
+    GSR_CHECK_HIP(hipMemsetAsync(v_xy, 0, sizeof(float) * (6 + channels) * (size_t)n, s));
+    return GSR_OK;
+  }
   GSR_CHECK_HIP(hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * (size_t)n, s));
   GSR_CHECK_HIP(hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * (size_t)n, s));
   GSR_CHECK_HIP(hipMemsetAsync(v_colors, 0, sizeof(float) * channels * (size_t)n, s));

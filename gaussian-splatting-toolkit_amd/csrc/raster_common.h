@@ -9,30 +9,33 @@ constexpr int kChunk = 64;  // splats staged per LDS fill (one per lane)
 // LDS record of one staged splat; consumed by wave-uniform broadcast reads.
 struct __align__(16) SplatA { float x, y, ha, b; };     // ha = a/2
 struct __align__(16) SplatB { float hc, opac, r, g; };  // hc = c/2
-struct __align__(8) SplatC { float blue; int sidx; };   // sidx = index in the sorted list
+struct __align__(16) SplatC { float blue; int sidx; int mask; int pad; };
 // (0.5*(a dx^2 + c dy^2) == (a/2) dx^2 + (c/2) dy^2 exactly: scaling by a power
 //  of two commutes with rounding)
+// sidx = index in the sorted list; mask = which of the tile's four 8x8
+// sub-tiles the splat can reach (bit p <-> sub-tile (p&1, p>>1)).
 
-// Can ANY pixel centre of the 16x16 tile whose first pixel is (tx0, ty0) get
-// alpha = opac*exp(-sigma) >= 1/255 from this splat?  The tile lists are built
-// from the 3-sigma *square* bounding box (forward.cu:73), so about half of the
-// entries of a tile never pass the alpha test at any of its pixels; they are
-// dropped here, once per tile, by the lane that fetched them.  Dropping them
+// Pixel ownership inside a 16x16 tile: lane l sits at (l&7, l>>3) of EVERY 8x8
+// sub-tile, i.e. it owns the 4 pixels (l&7 + 8*(p&1), (l>>3) + 8*(p>>1)),
+// p = 0..3.  One wave-instruction therefore covers a whole sub-tile, and a
+// sub-tile a splat cannot reach is skipped with a scalar branch.
+
+// Can ANY pixel centre of the (w+1) x (w+1) pixel square whose first pixel is
+// (rx0, ry0) get alpha = opac*exp(-sigma) >= 1/255 from this splat?  The tile
+// lists are built from the 3-sigma *square* bounding box (forward.cu:73): about
+// half of a tile's entries never pass the alpha test at any of its pixels, and
+// of the rest ~1/3 of the (splat, sub-tile) pairs don't either.  Dropping them
 // cannot change a result: the compositing rule skips them pixel by pixel
 // (alpha < 1/255 -> continue).  The test is conservative: sigma is minimised
-// over the continuous rectangle (<= its minimum over the pixel centres) and the
-// threshold carries a 1 % margin in alpha, far above fp32 rounding.
-__device__ __forceinline__ bool splat_reaches_tile(float x, float y, float a, float b, float c,
-                                                   float opac, float tx0, float ty0) {
-  // alpha >= 1/255  <=>  sigma <= log(255*opac)
-  const float smax = __logf(255.f * opac) + 0.01f;
-  if (!(smax >= 0.f)) return !(opac == opac);  // too faint anywhere (NaN: keep, let the rule decide)
-  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;  // not positive definite: no culling
-  const float u0 = tx0 - x, u1 = u0 + 15.f, v0 = ty0 - y, v1 = v0 + 15.f;
-  if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;  // centre inside the tile
+// over the continuous rectangle (<= its minimum over the pixel centres) and
+// `smax` carries a 1 % margin in alpha, far above fp32 rounding.
+__device__ __forceinline__ bool reaches_rect(float x, float y, float a, float b, float c,
+                                             float nb_c, float nb_a, float smax, float rx0,
+                                             float ry0, float w) {
+  const float u0 = rx0 - x, u1 = u0 + w, v0 = ry0 - y, v1 = v0 + w;
+  if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;  // centre inside
   // convex quadratic, unconstrained minimum (0,0) outside the rectangle ->
   // the minimum over the rectangle lies on one of its four edges
-  const float nb_c = -b / c, nb_a = -b / a;
   auto edge_u = [&](float ue) {
     const float v = fminf(fmaxf(nb_c * ue, v0), v1);
     return 0.5f * (a * ue * ue + c * v * v) + b * ue * v;
@@ -45,15 +48,32 @@ __device__ __forceinline__ bool splat_reaches_tile(float x, float y, float a, fl
   return smin <= smax;
 }
 
-// Stage up to 64 splats (sorted indices first .. first+step*63, `live` lanes only)
-// into LDS, dropping the ones that cannot reach the tile; returns how many were kept.
-// Kept splats stay in list order.  Wave-synchronous (one wave per workgroup).
+// 4-bit reach mask over the sub-tiles of the tile at (tx0, ty0); 0 = drop.
+__device__ __forceinline__ int splat_reach_mask(float x, float y, float a, float b, float c,
+                                                float opac, float tx0, float ty0) {
+  // alpha >= 1/255  <=>  sigma <= log(255*opac)
+  const float smax = __logf(255.f * opac) + 0.01f;
+  if (!(smax >= 0.f)) return (opac == opac) ? 0 : 15;  // too faint anywhere (NaN: keep)
+  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return 15;  // not positive definite: no culling
+  const float nb_c = -b / c, nb_a = -b / a;
+  int m = 0;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    m |= reaches_rect(x, y, a, b, c, nb_c, nb_a, smax, tx0 + 8.f * (p & 1), ty0 + 8.f * (p >> 1), 7.f)
+             ? (1 << p)
+             : 0;
+  return m;
+}
+
+// Stage up to 64 splats (one per `live` lane, sorted index `sidx`) into LDS,
+// dropping the ones that cannot reach the tile; returns how many were kept.
+// Kept splats stay in lane order.  Wave-synchronous (one wave per workgroup).
 __device__ __forceinline__ int stage_chunk(
     const int lane, const bool live, const int sidx, const float tx0, const float ty0,
     const int *__restrict__ ids_sorted, const float2 *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacities, SplatA *sA, SplatB *sB, SplatC *sC, int *sId) {
-  bool keep = false;
+  int mask = 0;
   int g = 0;
   float2 xy = make_float2(0.f, 0.f);
   float a = 0.f, b = 0.f, c = 0.f, opac = 0.f;
@@ -64,18 +84,18 @@ __device__ __forceinline__ int stage_chunk(
     b = conics[3 * g + 1];
     c = conics[3 * g + 2];
     opac = opacities[g];
-    keep = splat_reaches_tile(xy.x, xy.y, a, b, c, opac, tx0, ty0);
+    mask = splat_reach_mask(xy.x, xy.y, a, b, c, opac, tx0, ty0);
   }
-  const unsigned long long mask = __ballot(keep);
-  if (keep) {
-    const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                               __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  const unsigned long long kept = __ballot(mask != 0);
+  if (mask != 0) {
+    const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(kept >> 32),
+                                               __builtin_amdgcn_mbcnt_lo((unsigned)kept, 0u));
     sA[slot] = SplatA{xy.x, xy.y, 0.5f * a, b};
     sB[slot] = SplatB{0.5f * c, opac, colors[3 * g], colors[3 * g + 1]};
-    sC[slot] = SplatC{colors[3 * g + 2], sidx};
+    sC[slot] = SplatC{colors[3 * g + 2], sidx, mask, 0};
     if (sId) sId[slot] = g;
   }
-  return __popcll(mask);
+  return __popcll(kept);
 }
 
 }  // namespace gsr

@@ -28,7 +28,7 @@ using namespace gsr;
 // ------------------------------------------------------------------ tile16
 // Per-pixel state: T is the live transmittance (0 once the pixel has finished
 // or lies outside the image, which makes every later splat a no-op), Tend keeps
-// the value to report.
+// the value to report.  Pixel p of a lane lives in sub-tile p (raster_common.h).
 __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
@@ -43,36 +43,48 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   const int tile = (int)gsr_xcd_remap(blockIdx.x, (unsigned)num_tiles);
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
-  const int qx = tx * 16 + 2 * (lane & 7), qy = ty * 16 + 2 * (lane >> 3);
-  const float fx0 = (float)qx, fx1 = (float)(qx + 1);
-  const float fy0 = (float)qy, fy1 = (float)(qy + 1);
+  const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
+  const float fx0 = (float)qx, fx1 = (float)(qx + 8);
+  const float fy0 = (float)qy, fy1 = (float)(qy + 8);
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
 
-  // pixel p = (qx + (p&1), qy + (p>>1))
+  // pixel p = (qx + 8*(p&1), qy + 8*(p>>1))
   float T[4], Tend[4], cr[4], cg[4], cb[4];
   int last[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const bool inside = (qx + (p & 1)) < img_w && (qy + (p >> 1)) < img_h;
+    const bool inside = (qx + 8 * (p & 1)) < img_w && (qy + 8 * (p >> 1)) < img_h;
     T[p] = inside ? 1.f : 0.f;
     Tend[p] = 1.f;
     cr[p] = cg[p] = cb[p] = 0.f;
     last[p] = 0;
   }
 
+  // sub-tiles that still have a pixel with transmittance left (wave-uniform)
+  auto live_subtiles = [&]() {
+    int m = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m |= __any(T[p] > 0.f) ? (1 << p) : 0;
+    return m;
+  };
+
   const int2 range = tile_bins[tile];
-  for (int base = range.x; base < range.y; base += kChunk) {
-    // the whole tile is finished when no pixel has transmittance left
-    if (__all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) == 0.f)) break;
+  int live = live_subtiles();
+  for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
     const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics,
                                   colors, opacities, sA, sB, sC, nullptr);
     __syncthreads();
     for (int t = 0; t < count; ++t) {
-      if ((t & 7) == 7 && __all(fmaxf(fmaxf(T[0], T[1]), fmaxf(T[2], T[3])) == 0.f)) break;
+      if ((t & 7) == 7) {
+        live = live_subtiles();
+        if (live == 0) break;
+      }
+      const SplatC C = sC[t];
+      const int m = C.mask & live;
+      if (m == 0) continue;
       const SplatA A = sA[t];
       const SplatB B = sB[t];
-      const SplatC C = sC[t];
       const float dx0 = A.x - fx0, dx1 = A.x - fx1;
       const float dy0 = A.y - fy0, dy1 = A.y - fy1;
       const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
@@ -82,6 +94,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
                             (ax0 + cy1) + bx0 * dy1, (ax1 + cy1) + bx1 * dy1};
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
+        if (!(m & (1 << p))) continue;  // wave-uniform: whole sub-tile out of reach / finished
         const float sigma = sig[p];
         const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
         const bool hit = !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
@@ -99,13 +112,14 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       }
     }
     __syncthreads();
+    live = live_subtiles();
   }
 
   // wave-uniform -> scalar loads
   const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int col = qx + (p & 1), row = qy + (p >> 1);
+    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
     if (col < img_w && row < img_h) {
       const size_t pid = (size_t)row * img_w + col;
       final_Ts[pid] = Tend[p];

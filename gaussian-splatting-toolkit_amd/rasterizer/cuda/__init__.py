@@ -341,10 +341,13 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
     n, channels = xys.size(0), colors.size(1)
     dev = xys.device
     with torch.cuda.device(dev):
-        v_xy = torch.empty((n, 2), dtype=_f32, device=dev)
-        v_conic = torch.empty((n, 3), dtype=_f32, device=dev)
-        v_colors = torch.empty((n, channels), dtype=_f32, device=dev)
-        v_opacity = torch.empty((n, 1), dtype=_f32, device=dev)
+        # four contiguous tensors carved out of one allocation: the library
+        # zero-fills them with a single memset when they are back to back
+        flat = torch.empty((n * (6 + channels),), dtype=_f32, device=dev)
+        v_xy = flat[: 2 * n].view(n, 2)
+        v_conic = flat[2 * n: 5 * n].view(n, 3)
+        v_colors = flat[5 * n: (5 + channels) * n].view(n, channels)
+        v_opacity = flat[(5 + channels) * n:].view(n, 1)
         head = (C.c_uint(img_height), C.c_uint(img_width), C.c_uint(block_width))
         tail = (C.c_int(n), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics),
                 _ptr(colors), _ptr(opacities), _ptr(background), _ptr(final_Ts), _ptr(final_idx),

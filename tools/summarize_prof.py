@@ -37,6 +37,20 @@ def main(d, out):
         for row in csv.DictReader(open(f)):
             k = short(row["Kernel_Name"])
             res["counters"][k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if len(sys.argv) > 3:
+        rows = []
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            rows += list(csv.DictReader(open(f)))
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        prev_end = None
+        for r in rows[-int(sys.argv[3]):]:
+            st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            gap = (st - prev_end) / 1e3 if prev_end else 0.0
+            prev_end = en
+            grid = r.get("Grid_Size") or r.get("Grid_Size_X", "?")
+            wg = r.get("Workgroup_Size") or r.get("Workgroup_Size_X", "?")
+            print(f"  {short(r['Kernel_Name']):50s} grid={grid:>9s} wg={wg:>4s} "
+                  f"vgpr={r.get('VGPR_Count', '?'):>4s} dur={(en - st) / 1e3:8.1f}us gap={gap:7.1f}us")
     summ = {"kernels": {}, "counters": {}}
     for k, v in res["kernels"].items():
         ds = v["dur_ns"]
