@@ -81,11 +81,13 @@ __global__ __launch_bounds__(256) void tile_bin_edges32_kernel(const int num_int
   }
 }
 
-// rocPRIM switches to block-sort + log2(n/4096) merge passes below 2^20 items
-// (21 launches, ~150 us for 1 M keys on MI355X); Onesweep (histogram + one
-// launch per 8-bit digit) is the better fit from ~64 k items on.
-using depth_sort_config =
-    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+// The depth sort handles only N ~ 1e6 pairs, a size rocPRIM serves with
+// block-sort + merge passes (21 launches, ~170 us on MI355X).  Measured
+// alternatives: Onesweep forced from 64 k items with the default 16 k items per
+// workgroup (62 workgroups: ~200 us) or with 2 k items per workgroup (look-back
+// chain over 488 workgroups: ~350 us).  The default stays; a purpose-built
+// 4-pass sort for this size is future work.
+using depth_sort_config = rocprim::default_config;
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 

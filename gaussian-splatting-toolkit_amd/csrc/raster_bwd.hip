@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
   const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
 
-  float T[4], K[4], vr[4], vg[4], vb[4], br[4], bgr[4], bb[4];
+  float T[4], K[4], vr[4], vg[4], vb[4];
   int binf[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
@@ -185,7 +185,6 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const bool inside = col < img_w && row < img_h;
     T[p] = 1.f;
     K[p] = vr[p] = vg[p] = vb[p] = 0.f;
-    br[p] = bgr[p] = bb[p] = 0.f;
     binf[p] = -1;  // `inside && idx <= bin_final` folds into one compare
     if (inside) {
       const size_t pid = (size_t)row * img_w + col;
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   // last sorted index any pixel of sub-tile p still needs (wave-uniform)
   int topp[4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) topp[p] = wave_max(binf[p]);
+  for (int p = 0; p < 4; ++p) topp[p] = __builtin_amdgcn_readfirstlane(wave_max(binf[p]));
   const int top = min(range.y - 1, max(max(topp[0], topp[1]), max(topp[2], topp[3])));
   if (top < range.x) return;
 
@@ -257,17 +256,16 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             const bool valid = (C.sidx <= binf[p]) && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
             const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
             const float Tn = T[p] * ra;
-            const float fac_ = alpha * Tn;
-            float v_alpha = (B.r * Tn - br[p] * ra) * vr[p];
-            v_alpha += (B.g * Tn - bgr[p] * ra) * vg[p];
-            v_alpha += (C.blue * Tn - bb[p] * ra) * vb[p];
-            v_alpha += K[p] * ra;
+            // sum_c (rgb_c*T - buffer_c*ra) v_out_c + T_final*ra*(v_out_alpha - bg.v_out)
+            //   = T * (rgb . v_out) + ra * (K - buffer . v_out);
+            // K[p] carries  T_final*(v_out_alpha - bg.v_out) - buffer.v_out  (a scalar per
+            // pixel instead of the reference's 3-channel running buffer)
+            const float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
+            const float v_alpha = Tn * d + ra * K[p];
             const float w = valid ? vis * v_alpha : 0.f;
-            const float fac = valid ? fac_ : 0.f;
+            const float fac = valid ? alpha * Tn : 0.f;
             T[p] = valid ? Tn : T[p];
-            br[p] += B.r * fac;
-            bgr[p] += B.g * fac;
-            bb[p] += C.blue * fac;
+            K[p] -= fac * d;
             sr += fac * vr[p];
             sg += fac * vg[p];
             sb += fac * vb[p];

@@ -26,9 +26,16 @@ namespace {
 using namespace gsr;
 
 // ------------------------------------------------------------------ tile16
-// Per-pixel state: T is the live transmittance (0 once the pixel has finished
-// or lies outside the image, which makes every later splat a no-op), Tend keeps
-// the value to report.  Pixel p of a lane lives in sub-tile p (raster_common.h).
+// The kernel is VALU-issue bound (rocprof: VALU busy ~86 %, LDS and memory
+// idle).  Measured dead ends, kept out on purpose: writing the pixel math on
+// float2 pairs so that it compiles to v_pk_{mul,add,fma}_f32 cut the VALU
+// instruction count by ~30 % and made the kernel 9 % SLOWER (packed fp32 issues
+// at half rate on gfx950 and needs s_nop hazards) -- so the build also turns
+// the SLP vectorizer off for these files (Makefile).
+//
+// Per-pixel state is ONE float: T > 0 is the live transmittance, T < 0 means the
+// pixel is finished (or outside the image) and |T| is the value to report.  A
+// finished pixel gives next_T < 0, so it can neither draw nor finish again.
 __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
@@ -49,18 +56,17 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
 
   // pixel p = (qx + 8*(p&1), qy + 8*(p>>1))
-  float T[4], Tend[4], cr[4], cg[4], cb[4];
+  float T[4], cr[4], cg[4], cb[4];
   int last[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const bool inside = (qx + 8 * (p & 1)) < img_w && (qy + 8 * (p >> 1)) < img_h;
-    T[p] = inside ? 1.f : 0.f;
-    Tend[p] = 1.f;
+    T[p] = inside ? 1.f : -1.f;
     cr[p] = cg[p] = cb[p] = 0.f;
     last[p] = 0;
   }
 
-  // sub-tiles that still have a pixel with transmittance left (wave-uniform)
+  // sub-tiles that still have a live pixel (wave-uniform)
   auto live_subtiles = [&]() {
     int m = 0;
 #pragma unroll
@@ -97,18 +103,20 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
         if (!(m & (1 << p))) continue;  // wave-uniform: whole sub-tile out of reach / finished
         const float sigma = sig[p];
         const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
+        const float Tp = T[p];
+        const float next_T = Tp * (1.f - alpha);
+        // flat selects (v_cndmask); nested ternaries turn into exec-mask branches
         const bool hit = !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
-        const float next_T = T[p] * (1.f - alpha);
-        // T == 0 (finished / outside) gives next_T == 0: neither drawn nor "stopped again"
-        const bool draw = hit && (next_T > GSR_T_EPS);
-        const bool stop = hit && !draw && (T[p] > 0.f);
-        const float vis = draw ? alpha * T[p] : 0.f;
+        const bool go = next_T > GSR_T_EPS;
+        const bool draw = hit && go;
+        const float dead = __uint_as_float(__float_as_uint(Tp) | 0x80000000u);  // -|T|
+        const float upd = go ? next_T : dead;
+        const float vis = draw ? alpha * Tp : 0.f;
         cr[p] += B.r * vis;
         cg[p] += B.g * vis;
         cb[p] += C.blue * vis;
-        Tend[p] = draw ? next_T : Tend[p];
         last[p] = draw ? C.sidx : last[p];
-        T[p] = draw ? next_T : (stop ? 0.f : T[p]);
+        T[p] = hit ? upd : Tp;
       }
     }
     __syncthreads();
@@ -122,11 +130,12 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
     if (col < img_w && row < img_h) {
       const size_t pid = (size_t)row * img_w + col;
-      final_Ts[pid] = Tend[p];
+      const float Tp = fabsf(T[p]);
+      final_Ts[pid] = Tp;
       final_idx[pid] = last[p];
-      out_img[3 * pid] = cr[p] + Tend[p] * bg0;
-      out_img[3 * pid + 1] = cg[p] + Tend[p] * bg1;
-      out_img[3 * pid + 2] = cb[p] + Tend[p] * bg2;
+      out_img[3 * pid] = cr[p] + Tp * bg0;
+      out_img[3 * pid + 1] = cg[p] + Tp * bg1;
+      out_img[3 * pid + 2] = cb[p] + Tp * bg2;
     }
   }
 }
