@@ -14,19 +14,19 @@
 //   v_xy    += v_sigma*(a dx + b dy, b dx + c dy)
 // and the per-pixel contributions are summed per Gaussian.
 //
-// tile16 mapping (block_width 16, 3 channels): one wave64 per tile, a 2x2
-// pixel quad per lane, splats staged 64 at a time in LDS.  The reference
-// reduces every splat across a 32-lane warp (9 values x 5 shuffle steps) and
-// issues 9 atomics per warp per splat (72 per tile-splat).  Here a lane first
-// folds its 4 pixels into six moments of w = vis*v_alpha (sum w, w dx, w dy,
-// w dx^2, w dx dy, w dy^2) + the rgb sums, turns them into the 9 gradient
-// components, and then 8 splats x 9 components = 72 lane-partials are reduced
-// together with a halving butterfly: v_permlane32_swap / v_permlane16_swap
-// (new on gfx950) and DPP row ops, every step halving the number of live
-// values, ~2 instructions per output instead of 6 per value.  The butterfly
-// ends with exactly one fully reduced (splat, component) per lane, so one
-// wave-wide global_atomic_add_f32 retires 64 components: 9 atomics per
-// tile-splat instead of 72.
+// tile16 mapping (block_width 16, 3 channels): one wave64 per tile, 4 pixels per
+// lane (one in each 8x8 sub-tile), splats staged 64 at a time in LDS after an
+// exact reach test (raster_common.h).  The reference reduces every splat across
+// a 32-lane warp (9 values x 5 shuffle steps) and issues 9 atomics per warp per
+// splat (72 per tile-splat).  Here a lane first folds its pixels into six
+// moments of w = vis*v_alpha (sum w, w dx, w dy, w dx^2, w dx dy, w dy^2) + the
+// rgb sums, turns them into the 9 gradient components, and then G splats x 9
+// components lane-partials (G = 4 by default, 8 selectable) are reduced together
+// with a halving butterfly: v_permlane32_swap / v_permlane16_swap (new on
+// gfx950) and DPP row ops, every step halving the number of live values, ~20
+// instructions per splat instead of 54.  The butterfly ends with one fully
+// reduced (splat, component) per lane, so one wave-wide global_atomic_add_f32
+// retires 32 (G=4) or 64 (G=8) components: 9 atomics per tile-splat instead of 72.
 #include <stdlib.h>
 
 #include "raster_common.h"
