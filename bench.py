@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--scale-lo", type=float, default=0.0025)
     ap.add_argument("--scale-hi", type=float, default=0.025)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # "nccl" is RCCL on ROCm.  "gloo" exists so the N>1 code path can be exercised on a
+    # single-GPU box (ranks then share cuda:0); it is not a measurement configuration.
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,11 +153,15 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     from harness.parallel import allreduce_gradients
     from harness.pipeline import CameraTensors, render_view
@@ -225,7 +232,12 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(dominant)
+                td = json.load(open(tf))
+                wl = td.get("_workload", {})
+                # PMC passes were collected on the default workload only
+                if (wl.get("gaussians"), wl.get("width"), wl.get("height"), wl.get("sh_degree"),
+                        wl.get("scale_lo"), wl.get("scale_hi")) == (N, W, H, deg, args.scale_lo, args.scale_hi):
+                    traffic = td.get(dominant)
             except Exception:
                 traffic = None
         roofline = {
@@ -264,7 +276,7 @@ def main():
                 "intersections_per_gaussian": round(num_intersects / N, 2),
                 "gaussians": N, "visible": n_visible, "intersections": num_intersects,
                 "mean_gaussians_per_tile": round(num_intersects / tiles, 1),
-                "parallelism": f"dp{world} (per-view; one flat-gradient all-reduce/step)" if world > 1 else "single",
+                "parallelism": f"dp{world} (per-view; one flat-gradient all-reduce/step, {args.backend})" if world > 1 else "single",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -85,6 +85,9 @@ __device__ __forceinline__ int stage_chunk(
     c = conics[3 * g + 2];
     opac = opacities[g];
     mask = splat_reach_mask(xy.x, xy.y, a, b, c, opac, tx0, ty0);
+#ifdef GSR_NO_CULL
+    mask = 15;  // experiment: keep every list entry
+#endif
   }
   const unsigned long long kept = __ballot(mask != 0);
   if (mask != 0) {

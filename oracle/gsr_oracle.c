@@ -625,13 +625,15 @@ GSR_API void gsr_oracle_rasterize_forward(
         float a = conics[3 * g], b = conics[3 * g + 1], cc = conics[3 * g + 2];
         float sigma = 0.5f * (a * dx * dx + cc * dy * dy) + b * dx * dy;
         float alpha = fminf_(0.999f, opacities[g] * expf(-sigma));
+        float stol = 0.f; /* how far sigma may move under a different fp32 evaluation order */
         if (ambig) {
-          if (fabsf(sigma) <= ambig_eps) amb = 1;
-          if (fabsf(alpha - 1.f / 255.f) <= ambig_eps * (1.f / 255.f)) amb = 1;
+          stol = ambig_eps + 1e-6f * (0.5f * (fabsf(a) * dx * dx + fabsf(cc) * dy * dy) + fabsf(b * dx * dy));
+          if (fabsf(sigma) <= stol) amb = 1;
+          if (fabsf(alpha - 1.f / 255.f) <= stol * (1.f / 255.f)) amb = 1;
         }
         if (sigma < 0.f || alpha < 1.f / 255.f) continue;
         float next_T = T * (1.f - alpha);
-        if (ambig && fabsf(next_T - 1e-4f) <= 20.f * ambig_eps * 1e-4f) amb = 1;
+        if (ambig && fabsf(next_T - 1e-4f) <= (20.f * ambig_eps + stol) * 1e-4f) amb = 1;
         if (next_T <= 1e-4f) break;
         float vis = alpha * T;
         for (int c = 0; c < channels; ++c)
@@ -661,9 +663,18 @@ GSR_API void gsr_oracle_rasterize_backward(
     const float *conics, const float *colors, const float *opacities,
     const float *background, const float *final_Ts, const int *final_idx,
     const float *v_output, const float *v_output_alpha, float *v_xy,
-    float *v_conic, float *v_colors, float *v_opacity) {
+    float *v_conic, float *v_colors, float *v_opacity, float *abs_sums,
+    unsigned char *ambig, float ambig_eps) {
+  /* ambig (optional, [num_points]): 1 for Gaussians with a pixel whose skip
+   * decision (sigma<0, alpha<1/255) is within ambig_eps (relative) of flipping */
+  /* abs_sums (optional, [num_points, 6+channels], order xy(2) conic(3)
+   * opacity(1) colors(C)): sum of |per-pixel term| of every gradient component
+   * -- the scale fp32 accumulation error is relative to (tests use it to bound
+   * the error of sums with heavy cancellation). */
   const int tiles_x = (img_w + bw - 1) / bw;
   const int stride = 6 + channels; /* xy(2) conic(3) opac(1) colors(C) */
+  const int want_abs = abs_sums != NULL;
+  if (ambig) memset(ambig, 0, (size_t)num_points);
   int nthreads = 1;
 #ifdef _OPENMP
   nthreads = omp_get_max_threads();
@@ -671,6 +682,7 @@ GSR_API void gsr_oracle_rasterize_backward(
   /* bound the scratch: fall back to fewer accumulators for huge N */
   while (nthreads > 1 && (double)nthreads * num_points * stride * 8.0 > 6e9) nthreads /= 2;
   double *accs = (double *)calloc((size_t)nthreads * num_points * stride, sizeof(double));
+  double *absacc = want_abs ? (double *)calloc((size_t)nthreads * num_points * stride, sizeof(double)) : NULL;
 
 #pragma omp parallel num_threads(nthreads)
   {
@@ -679,6 +691,7 @@ GSR_API void gsr_oracle_rasterize_backward(
     tid = omp_get_thread_num();
 #endif
     double *A = accs + (size_t)tid * num_points * stride;
+    double *AA = want_abs ? absacc + (size_t)tid * num_points * stride : NULL;
     float *buf = (float *)malloc(sizeof(float) * (size_t)channels);
 #pragma omp for schedule(dynamic, 4)
     for (int i = 0; i < img_h; ++i) {
@@ -703,6 +716,10 @@ GSR_API void gsr_oracle_rasterize_backward(
           float opac = opacities[g];
           float vis = expf(-sigma);
           float alpha = fminf_(0.99f, opac * vis);
+          if (ambig) {
+            float stol = ambig_eps + 1e-6f * (0.5f * (fabsf(a) * dx * dx + fabsf(cc) * dy * dy) + fabsf(b * dx * dy));
+            if (fabsf(sigma) <= stol || fabsf(alpha - 1.f / 255.f) <= stol * (1.f / 255.f)) ambig[g] = 1;
+          }
           if (sigma < 0.f || alpha < 1.f / 255.f) continue;
           float ra = 1.f / (1.f - alpha);
           T *= ra;
@@ -725,6 +742,16 @@ GSR_API void gsr_oracle_rasterize_backward(
           Ag[0] += (double)(v_sigma * (a * dx + b * dy));
           Ag[1] += (double)(v_sigma * (b * dx + cc * dy));
           Ag[5] += (double)(vis * v_alpha);
+          if (want_abs) {
+            double *Bg = AA + (size_t)g * stride;
+            Bg[0] += fabs((double)(v_sigma * (a * dx + b * dy)));
+            Bg[1] += fabs((double)(v_sigma * (b * dx + cc * dy)));
+            Bg[2] += fabs((double)(0.5f * v_sigma * dx * dx));
+            Bg[3] += fabs((double)(v_sigma * dx * dy));
+            Bg[4] += fabs((double)(0.5f * v_sigma * dy * dy));
+            Bg[5] += fabs((double)(vis * v_alpha));
+            for (int c = 0; c < channels; ++c) Bg[6 + c] += fabs((double)(fac * vout[c]));
+          }
         }
       }
     }
@@ -747,8 +774,16 @@ GSR_API void gsr_oracle_rasterize_backward(
     v_opacity[g] = (float)s[5];
     for (int c = 0; c < channels && c < 58; ++c)
       v_colors[(size_t)channels * g + c] = (float)s[6 + c];
+    if (want_abs) {
+      for (int k = 0; k < ns; ++k) {
+        double t = 0.0;
+        for (int th = 0; th < nthreads; ++th) t += absacc[((size_t)th * num_points + g) * stride + k];
+        abs_sums[(size_t)g * stride + k] = (float)t;
+      }
+    }
   }
   free(accs);
+  free(absacc);
 }
 
 /* bindings.cu:19-56 : standalone conic + radius from cov2d */

@@ -228,9 +228,10 @@ def rasterize_forward(
 def rasterize_backward(
     img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
     conics, colors, opacities, background, final_Ts, final_idx, v_output,
-    v_output_alpha,
+    v_output_alpha, with_abs_sums: bool = False, ambig_eps: Optional[float] = None,
 ):
-    """-> (v_xy, v_conic, v_colors, v_opacity[N,1])"""
+    """-> (v_xy, v_conic, v_colors, v_opacity[N,1]) [+ the same four shapes holding
+    the sum of |per-pixel terms|, the scale fp32 accumulation error lives on]"""
     colors = _f(colors)
     n, ch = colors.shape
     gids, bins = _i(gaussian_ids_sorted), _i(tile_bins)
@@ -241,13 +242,21 @@ def rasterize_backward(
     v_conic = np.empty((n, 3), np.float32)
     v_colors = np.empty((n, ch), np.float32)
     v_opac = np.empty((n, 1), np.float32)
+    abs_sums = np.empty((n, 6 + ch), np.float32) if with_abs_sums else None
+    amb = np.zeros((n,), np.uint8) if ambig_eps is not None else None
     lib().gsr_oracle_rasterize_backward(
         C.c_int(img_height), C.c_int(img_width), C.c_int(block_width), C.c_int(ch),
         C.c_int(n), _p(gids), _p(bins), _p(xys), _p(conics), _p(colors), _p(opac),
         _p(bg), _p(Ts), _p(fidx), _p(vo), _p(voa), _p(v_xy), _p(v_conic),
-        _p(v_colors), _p(v_opac),
+        _p(v_colors), _p(v_opac), _p(abs_sums) if abs_sums is not None else None,
+        _p(amb) if amb is not None else None, C.c_float(ambig_eps if ambig_eps is not None else 0.0),
     )
-    return v_xy, v_conic, v_colors, v_opac
+    out = (v_xy, v_conic, v_colors, v_opac)
+    if with_abs_sums:
+        out = out + (abs_sums[:, 0:2], abs_sums[:, 2:5], abs_sums[:, 6:], abs_sums[:, 5:6])
+    if amb is not None:
+        out = out + (amb.astype(bool),)
+    return out
 
 
 # generic-channel entry points share the implementation (fp32 accumulators)
