@@ -140,6 +140,9 @@ def main():
     ap.add_argument("--scale-lo", type=float, default=0.0025)
     ap.add_argument("--scale-hi", type=float, default=0.025)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # co-gs / eval pattern (BASELINE config 5): a second rasterisation of the depths with
+    # zero background (depth_gs.py:99, vanilla_gs.py:839-855), differentiable, in the step
+    ap.add_argument("--render-depth", action="store_true")
     # "nccl" is RCCL on ROCm.  "gloo" exists so the N>1 code path can be exercised on a
     # single-GPU box (ranks then share cuda:0); it is not a measurement configuration.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -187,8 +190,12 @@ def main():
         for p in plist:
             p.grad = None
         out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
-                          params["sh_coeffs"], camt, bg, deg, clamp_rgb=False)
-        torch.autograd.backward([out["rgb"], out["alpha"]], [v_img, v_alpha[..., None]])
+                          params["sh_coeffs"], camt, bg, deg, clamp_rgb=False, render_depth=args.render_depth)
+        if args.render_depth:
+            torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]],
+                                    [v_img, v_alpha[..., None], v_alpha[..., None]])
+        else:
+            torch.autograd.backward([out["rgb"], out["alpha"]], [v_img, v_alpha[..., None]])
         if world > 1:
             allreduce_gradients(plist, average=True)
         return out
@@ -272,7 +279,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{N} random Gaussians (SURVEY 8d, seed 42, scales log-U[{args.scale_lo},{args.scale_hi}]), "
-                            f"SH degree {deg}, {W}x{H}, block 16, fwd+bwd through the rasterizer autograd API",
+                            f"SH degree {deg}, {W}x{H}, block 16, fwd+bwd through the rasterizer autograd API"
+                            + (" + differentiable depth pass" if args.render_depth else ""),
                 "intersections_per_gaussian": round(num_intersects / N, 2),
                 "gaussians": N, "visible": n_visible, "intersections": num_intersects,
                 "mean_gaussians_per_tile": round(num_intersects / tiles, 1),

@@ -1,0 +1,233 @@
+"""A minimal trainer with the toolkit's call pattern, for
+BASELINE configs 3/4: `gs-train gaussian-splatting` on a synthetic scene, one
+GPU or per-view data parallel.
+
+What is reproduced from the reference (so that the rasterizer sees exactly the
+calls the real models make):
+  * parameters and activations of `GaussianSplattingModel`
+    (gs_toolkit/models/vanilla_gs.py:128-174, 765-820): means, log-scales,
+    unnormalised quats, logit opacities, features_dc [N,3], features_rest
+    [N,15,3]; `exp`, normalise, `sigmoid`, SH degree warm-up
+    `min(step // sh_degree_interval, sh_degree)`, `clamp(SH + 0.5, min=0)`;
+  * the loss `(1 - lambda) L1 + lambda (1 - SSIM)` with lambda = 0.2
+    (vanilla_gs.py:900-947; SSIM restated in plain torch, 11x11 Gaussian window);
+  * one Adam optimiser per parameter group with the learning rates of
+    gs_toolkit/configs/method_configs.py:98-132;
+  * `xys.retain_grad()` and the densification statistics of `after_train`
+    (vanilla_gs.py:344-372) -- accumulated (and all-reduced) but, in this
+    harness, not acted upon: N stays fixed so iterations are comparable.
+The data side (cameras on a sphere, ground truth rendered by this rasterizer
+from a hidden "true" scene) replaces the toolkit's datamanager.
+"""
+import math
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import scene as S
+from .parallel import allreduce_densify_stats, allreduce_gradients, view_for_rank
+from .pipeline import CameraTensors, render_view
+
+LRS = {"means": 1.6e-4, "features_dc": 0.0025, "features_rest": 0.0025 / 20, "opacities": 0.05,
+       "scales": 0.005, "quats": 0.001}
+SH_C0 = 0.28209479177387814
+
+
+def orbit_cameras(n_views: int, width: int, height: int, radius: float = 6.0, fov_x_deg: float = 60.0):
+    """Cameras on a circle around the origin, all looking at it (rasterizer
+    convention: x right, y down, z forward)."""
+    cams = []
+    for i in range(n_views):
+        th = 2 * math.pi * i / n_views
+        eye = np.array([radius * math.sin(th), 0.6 * math.sin(2 * th), -radius * math.cos(th)])
+        fwd = -eye / np.linalg.norm(eye)
+        right = np.cross(np.array([0.0, -1.0, 0.0]), fwd)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        R = np.stack([right, down, fwd])  # world -> camera rows
+        cam = S.make_camera(width, height, fov_x_deg)
+        V = np.eye(4, dtype=np.float32)
+        V[:3, :3] = R.astype(np.float32)
+        V[:3, 3] = (-R @ eye).astype(np.float32)
+        fovx = math.radians(fov_x_deg)
+        fovy = 2.0 * math.atan(height / (2.0 * cam.fy))
+        P = S.projection_matrix(0.001, 1000.0, fovx, fovy) @ V
+        cams.append(S.Camera(width, height, cam.fx, cam.fy, cam.cx, cam.cy, V, P.astype(np.float32)))
+    return cams
+
+
+def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale_lo=0.01, scale_hi=0.06):
+    """Gaussians in a ball around the origin (raw, pre-activation parameters)."""
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal((n, 3))
+    p *= (extent * rng.uniform(0, 1, (n, 1)) ** (1 / 3)) / np.linalg.norm(p, axis=-1, keepdims=True)
+    K = S.num_sh_bases(sh_degree)
+    f32 = np.float32
+    return {
+        "means": p.astype(f32),
+        "scales": np.log(np.exp(rng.uniform(math.log(scale_lo), math.log(scale_hi), (n, 3)))).astype(f32),
+        "quats": rng.standard_normal((n, 4)).astype(f32),
+        "opacities": rng.uniform(-1.0, 2.0, (n, 1)).astype(f32),  # logits
+        "features_dc": (rng.uniform(0, 1, (n, 3)) - 0.5).astype(f32) / f32(SH_C0),
+        "features_rest": (rng.standard_normal((n, K - 1, 3)) * 0.05).astype(f32),
+    }
+
+
+class GaussianParams(torch.nn.Module):
+    def __init__(self, raw: Dict[str, np.ndarray], device):
+        super().__init__()
+        self.gauss = torch.nn.ParameterDict(
+            {k: torch.nn.Parameter(torch.from_numpy(v).to(device)) for k, v in raw.items()})
+
+    @property
+    def num_points(self):
+        return self.gauss["means"].shape[0]
+
+    def param_list(self) -> List[torch.nn.Parameter]:
+        return [self.gauss[k] for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities")]
+
+    def render(self, cam: CameraTensors, background, sh_degree_to_use: int, render_depth=False,
+               retain_xys_grad=False):
+        g = self.gauss
+        coeffs = torch.cat((g["features_dc"][:, None, :], g["features_rest"]), dim=1)
+        return render_view(
+            g["means"], torch.exp(g["scales"]), g["quats"] / g["quats"].norm(dim=-1, keepdim=True),
+            torch.sigmoid(g["opacities"]), coeffs, cam, background, sh_degree_to_use,
+            render_depth=render_depth, retain_xys_grad=retain_xys_grad)
+
+
+def _gauss_window(size=11, sigma=1.5, device="cpu"):
+    x = torch.arange(size, dtype=torch.float32, device=device) - size // 2
+    g = torch.exp(-(x * x) / (2 * sigma * sigma))
+    return g / g.sum()
+
+
+def ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
+    """Mean SSIM of two [H,W,3] images in [0,1] (11x11 Gaussian window, sigma 1.5)."""
+    a = img1.permute(2, 0, 1)[None]
+    b = img2.permute(2, 0, 1)[None]
+    w = _gauss_window(device=a.device)
+    C = a.shape[1]
+    kx = w.view(1, 1, 1, -1).repeat(C, 1, 1, 1)
+    ky = w.view(1, 1, -1, 1).repeat(C, 1, 1, 1)
+    blur = lambda t: F.conv2d(F.conv2d(t, kx, groups=C), ky, groups=C)
+    mu1, mu2 = blur(a), blur(b)
+    s11 = blur(a * a) - mu1 * mu1
+    s22 = blur(b * b) - mu2 * mu2
+    s12 = blur(a * b) - mu1 * mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))
+    return m.mean()
+
+
+def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float(-10.0 * torch.log10(((a - b) ** 2).mean().clamp_min(1e-12)))
+
+
+@dataclass
+class TrainConfig:
+    num_gaussians: int = 100_000
+    width: int = 640
+    height: int = 360
+    num_views: int = 24
+    iters: int = 300
+    sh_degree: int = 3
+    sh_degree_interval: int = 1000
+    ssim_lambda: float = 0.2
+    seed: int = 0
+    log_every: int = 0
+    eval_views: int = 4
+    fused_loss: bool = True   # gs_fused.l1_ssim_loss (2 HIP kernels) instead of the torch-op SSIM
+    fused_adam: bool = True   # torch's fused (multi-tensor, single-kernel) Adam
+
+
+def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
+    """Fit a perturbed copy of a hidden scene to its own renders.  Returns timing
+    and quality numbers; every rank ends with identical parameters."""
+    cams_np = orbit_cameras(cfg.num_views, cfg.width, cfg.height)
+    cams = [CameraTensors.from_numpy(c, device) for c in cams_np]
+    bg = torch.tensor(S.BACKGROUND, device=device)
+
+    truth = GaussianParams(blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree), device)
+    with torch.no_grad():
+        gt = [truth.render(c, bg, cfg.sh_degree)["rgb"] for c in cams]
+
+    # the model starts from the truth with perturbed geometry / washed-out colour
+    raw = blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree)
+    rng = np.random.default_rng(cfg.seed + 1)
+    raw["means"] += rng.standard_normal(raw["means"].shape).astype(np.float32) * 0.01
+    raw["features_dc"] *= 0.3
+    raw["features_rest"] *= 0.0
+    raw["opacities"] -= 0.5
+    model = GaussianParams(raw, device)
+    if cfg.fused_adam and device.type == "cuda":
+        # one optimiser, six parameter groups with the reference's learning rates
+        optims = {"all": torch.optim.Adam([{"params": [model.gauss[k]], "lr": lr} for k, lr in LRS.items()],
+                                          eps=1e-15, fused=True)}
+    else:
+        optims = {k: torch.optim.Adam([model.gauss[k]], lr=lr, eps=1e-15) for k, lr in LRS.items()}
+    plist = model.param_list()
+    if cfg.fused_loss and device.type == "cuda":
+        from gs_fused import l1_ssim_loss
+
+        loss_fn = lambda pred, target: l1_ssim_loss(pred, target, cfg.ssim_lambda)
+    else:
+        loss_fn = lambda pred, target: ((1 - cfg.ssim_lambda) * (pred - target).abs().mean()
+                                        + cfg.ssim_lambda * (1 - ssim(pred, target)))
+
+    n = model.num_points
+    xys_grad_norm = torch.zeros(n, device=device)
+    vis_counts = torch.zeros(n, device=device, dtype=torch.int32)
+    max_2dsize = torch.zeros(n, device=device)
+
+    def evaluate():
+        with torch.no_grad():
+            idx = np.linspace(0, cfg.num_views - 1, cfg.eval_views).astype(int)
+            return float(np.mean([psnr(model.render(cams[i], bg, cfg.sh_degree)["rgb"], gt[i]) for i in idx]))
+
+    psnr0 = evaluate()
+    losses = []
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for step in range(cfg.iters):
+        v = view_for_rank(step, rank, world, cfg.num_views)
+        for o in optims.values():
+            o.zero_grad(set_to_none=True)
+        deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
+        out = model.render(cams[v], bg, deg, retain_xys_grad=True)
+        rgb = out["rgb"]
+        loss = loss_fn(rgb, gt[v])
+        loss.backward()
+        # densification statistics (vanilla_gs.py:344-372)
+        with torch.no_grad():
+            visible = out["radii"] > 0
+            g = out["xys"].grad
+            if g is not None:
+                xys_grad_norm += torch.where(visible, g.norm(dim=-1), torch.zeros_like(xys_grad_norm))
+            vis_counts += visible.to(torch.int32)
+            max_2dsize = torch.maximum(max_2dsize, out["radii"].float() / max(cfg.width, cfg.height))
+        if world > 1:
+            allreduce_gradients(plist, average=True)
+        for o in optims.values():
+            o.step()
+        if cfg.log_every and step % cfg.log_every == 0:
+            losses.append(float(loss.detach()))
+    if world > 1:
+        allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize)
+        dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    psnr1 = evaluate()
+    checksum = float(sum(p.detach().double().sum() for p in plist))
+    return {"iters": cfg.iters, "seconds": elapsed, "iters_per_s": cfg.iters / elapsed, "psnr_start": psnr0,
+            "psnr_end": psnr1, "losses": losses, "param_checksum": checksum,
+            "views_per_s": world * cfg.iters / elapsed}

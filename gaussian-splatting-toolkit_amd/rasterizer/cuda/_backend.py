@@ -37,6 +37,8 @@ SYMBOLS = (
     "gsr_rasterize_forward_nd",
     "gsr_rasterize_backward_nd",
     "gsr_cov2d_bounds",
+    "gsr_l1_ssim_forward",
+    "gsr_l1_ssim_backward",
 )
 
 

@@ -204,6 +204,24 @@ int gsr_rasterize_backward_nd(unsigned img_height, unsigned img_width,
 int gsr_cov2d_bounds(int num_pts, const float *cov2d, float *conics,
                      float *radii, gsr_stream_t stream);
 
+/* ======================= "next" rows =======================
+ * f2 -- fused photometric loss head.  Replaces, for the caller
+ * GaussianSplattingModel.get_loss_dict (gs_toolkit/models/vanilla_gs.py:926-944),
+ * `torch.abs(gt - pred).mean()` + `1 - pytorch_msssim.SSIM(data_range=1,
+ * size_average=True, channel=3)(gt, pred)` and their autograd backward.
+ * pred, gt: [H,W,3] fp32.  maps: scratch [9, H-10, W-10] fp32 written by the
+ * forward and consumed by the backward.  sums: 2 doubles, zeroed by the call:
+ * sums[0] = sum |pred-gt|, sums[1] = sum of the SSIM map; the caller forms
+ * loss = (1-l)*sums[0]/(3HW) + l*(1 - sums[1]/(3(H-10)(W-10))).
+ * backward: v_pred[H,W,3] = upstream[0] * d loss / d pred (upstream on device). */
+int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width,
+                        const float *pred, const float *gt, float *maps,
+                        double *sums, gsr_stream_t stream);
+int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width,
+                         float ssim_lambda, const float *upstream,
+                         const float *pred, const float *gt, const float *maps,
+                         float *v_pred, gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -799,3 +799,83 @@ GSR_API void gsr_oracle_cov2d_bounds(int n, const float *cov2d, float *conics,
     radii[i] = radius;
   }
 }
+
+/* ------------------------------------------------- loss head (row f2) */
+
+/* (1-lambda)*mean|x-y| + lambda*(1 - SSIM(x,y)) and d/dx, for [H,W,3] images.
+ * Restates the call site gs_toolkit/models/vanilla_gs.py:926-944 and the
+ * published algorithm of pytorch_msssim 1.0.0 SSIM(data_range=1, channel=3,
+ * size_average=True): 11-tap Gaussian (sigma 1.5), valid padding, C1=0.01^2,
+ * C2=0.03^2.  Double precision throughout.  v_pred may be NULL. */
+GSR_API double gsr_oracle_l1_ssim(int H, int W, const float *pred, const float *gt,
+                                  float ssim_lambda, double *out_l1, double *out_ssim,
+                                  float *v_pred) {
+  double w[11], wsum = 0.0;
+  for (int k = 0; k < 11; ++k) { w[k] = exp(-((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); wsum += w[k]; }
+  for (int k = 0; k < 11; ++k) w[k] /= wsum;
+  const int Hv = H - 10, Wv = W - 10;
+  const double C1 = 0.01 * 0.01, C2 = 0.03 * 0.03;
+  double l1 = 0.0, ss = 0.0;
+  const size_t np = (size_t)H * W * 3;
+  for (size_t i = 0; i < np; ++i) l1 += fabs((double)pred[i] - (double)gt[i]);
+  l1 /= (double)np;
+  double *Dm = NULL, *D11 = NULL, *D12 = NULL;
+  if (v_pred) {
+    Dm = (double *)calloc((size_t)Hv * Wv * 3, sizeof(double));
+    D11 = (double *)calloc((size_t)Hv * Wv * 3, sizeof(double));
+    D12 = (double *)calloc((size_t)Hv * Wv * 3, sizeof(double));
+  }
+#pragma omp parallel for reduction(+ : ss) schedule(static)
+  for (int i = 0; i < Hv; ++i)
+    for (int j = 0; j < Wv; ++j)
+      for (int c = 0; c < 3; ++c) {
+        double mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+        for (int k = 0; k < 11; ++k)
+          for (int l = 0; l < 11; ++l) {
+            const size_t o = ((size_t)(i + k) * W + (j + l)) * 3 + c;
+            const double x = pred[o], y = gt[o], ww = w[k] * w[l];
+            mu1 += ww * x; mu2 += ww * y; e11 += ww * x * x; e22 += ww * y * y; e12 += ww * x * y;
+          }
+        const double s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        const double A1 = 2 * mu1 * mu2 + C1, A2 = 2 * s12 + C2;
+        const double B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+        const double S = A1 * A2 / (B1 * B2);
+        ss += S;
+        if (v_pred) {
+          const size_t m = ((size_t)i * Wv + j) * 3 + c;
+          const double dA1 = A2 / (B1 * B2), dA2 = A1 / (B1 * B2), dB1 = -S / B1, dB2 = -S / B2;
+          Dm[m] = dA1 * 2 * mu2 + dB1 * 2 * mu1 - dA2 * 2 * mu2 - dB2 * 2 * mu1;
+          D11[m] = dB2;
+          D12[m] = 2 * dA2;
+        }
+      }
+  ss /= (double)Hv * Wv * 3;
+  if (v_pred) {
+    const double kl1 = (1.0 - ssim_lambda) / (double)np;
+    const double kss = -(double)ssim_lambda / ((double)Hv * Wv * 3);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < H; ++i)
+      for (int j = 0; j < W; ++j)
+        for (int c = 0; c < 3; ++c) {
+          const size_t o = ((size_t)i * W + j) * 3 + c;
+          const double x = pred[o], y = gt[o];
+          double g = 0.0;
+          for (int k = 0; k < 11; ++k) {
+            const int mi = i - k;
+            if (mi < 0 || mi >= Hv) continue;
+            for (int l = 0; l < 11; ++l) {
+              const int mj = j - l;
+              if (mj < 0 || mj >= Wv) continue;
+              const size_t m = ((size_t)mi * Wv + mj) * 3 + c;
+              g += w[k] * w[l] * (Dm[m] + 2 * x * D11[m] + y * D12[m]);
+            }
+          }
+          const double d = x - y;
+          v_pred[o] = (float)(kl1 * (d > 0 ? 1.0 : (d < 0 ? -1.0 : 0.0)) + kss * g);
+        }
+    free(Dm); free(D11); free(D12);
+  }
+  if (out_l1) *out_l1 = l1;
+  if (out_ssim) *out_ssim = ss;
+  return (1.0 - ssim_lambda) * l1 + ssim_lambda * (1.0 - ss);
+}

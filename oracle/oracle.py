@@ -302,3 +302,17 @@ def render_forward(
     if ambig_eps is not None:
         res["ambig"] = r[3]
     return res
+
+
+def l1_ssim_loss(pred, gt, ssim_lambda=0.2, with_grad=True):
+    """(1-lambda)*L1 + lambda*(1-SSIM) of two [H,W,3] images and d loss / d pred
+    (vanilla_gs.py:926-944 + pytorch_msssim 1.0.0's SSIM).  -> (loss, l1, ssim, v_pred)"""
+    pred, gt = _f(pred), _f(gt)
+    H, W, _ = pred.shape
+    l1, ss = C.c_double(), C.c_double()
+    v = np.empty_like(pred) if with_grad else None
+    fn = lib().gsr_oracle_l1_ssim
+    fn.restype = C.c_double
+    loss = fn(C.c_int(H), C.c_int(W), _p(pred), _p(gt), C.c_float(ssim_lambda), C.byref(l1), C.byref(ss),
+              _p(v) if v is not None else None)
+    return float(loss), l1.value, ss.value, v

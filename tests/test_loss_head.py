@@ -1,0 +1,83 @@
+"""Loss head: oracle vs golden vectors (CPU); HIP kernels vs
+oracle and vs golden (GPU)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+CASES = ["a", "b", "c"]
+
+
+def load(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "loss.npz")))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_vs_golden(golden_dir, name):
+    g = load(golden_dir)
+    loss, l1, ss, v = O.l1_ssim_loss(g[f"{name}_pred"], g[f"{name}_gt"], float(g[f"{name}_lambda"]))
+    # goldens were computed in float64 from float64 inputs; the fixtures store float32 inputs
+    assert abs(l1 - float(g[f"{name}_l1"])) < 1e-6
+    assert abs(ss - float(g[f"{name}_ssim"])) < 1e-5
+    assert abs(loss - float(g[f"{name}_loss"])) < 1e-5
+    ref = g[f"{name}_grad"]
+    # an element with pred == gt in one precision but not the other flips the sign term
+    stable = np.abs(g[f"{name}_pred"].astype(np.float64) - g[f"{name}_gt"]) > 1e-6
+    assert np.abs(v - ref)[stable].max() < 1e-3 * np.abs(ref).max()
+    assert np.linalg.norm((v - ref)[stable]) / np.linalg.norm(ref[stable]) < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_vs_golden_and_oracle(golden_dir, name):
+    import torch
+
+    from gs_fused import l1_ssim_loss
+
+    g = load(golden_dir)
+    lam = float(g[f"{name}_lambda"])
+    pred = torch.from_numpy(g[f"{name}_pred"]).cuda().requires_grad_(True)
+    gt = torch.from_numpy(g[f"{name}_gt"]).cuda()
+    loss, l1, ss = l1_ssim_loss(pred, gt, lam, return_terms=True)
+    assert abs(float(loss) - float(g[f"{name}_loss"])) < 1e-5
+    assert abs(float(l1) - float(g[f"{name}_l1"])) < 1e-6 and abs(float(ss) - float(g[f"{name}_ssim"])) < 1e-5
+    (3.0 * loss).backward()
+    _, _, _, v = O.l1_ssim_loss(g[f"{name}_pred"], g[f"{name}_gt"], lam)
+    got = pred.grad.cpu().numpy() / 3.0
+    assert np.abs(got - v).max() < 1e-7 + 1e-4 * np.abs(v).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(1080, 1920), (237, 401), (12, 12)])
+def test_hip_vs_oracle_sizes(H, W):
+    import torch
+
+    from gs_fused import L1SSIMLoss
+
+    rng = np.random.default_rng(H + W)
+    gt = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+    pred = np.clip(gt + 0.1 * rng.standard_normal((H, W, 3)), 0, 1).astype(np.float32)
+    p = torch.from_numpy(pred).cuda().requires_grad_(True)
+    loss = L1SSIMLoss(0.2)(p, torch.from_numpy(gt).cuda())
+    loss.backward()
+    ref_loss, _, _, v = O.l1_ssim_loss(pred, gt, 0.2)
+    assert abs(float(loss) - ref_loss) < 2e-6
+    got = p.grad.cpu().numpy()
+    assert np.abs(got - v).max() < 1e-4 * np.abs(v).max()
+    assert np.linalg.norm(got - v) / np.linalg.norm(v) < 1e-5
+
+
+@pytest.mark.gpu
+def test_loss_errors():
+    import torch
+
+    from gs_fused import l1_ssim_loss
+
+    with pytest.raises(ValueError):
+        l1_ssim_loss(torch.zeros(8, 8, 3, device="cuda"), torch.zeros(8, 8, 3, device="cuda"))
+    with pytest.raises(ValueError):
+        l1_ssim_loss(torch.zeros(20, 20, 3, device="cuda"), torch.zeros(20, 21, 3, device="cuda"))
+    with pytest.raises(RuntimeError):
+        l1_ssim_loss(torch.zeros(20, 20, 3), torch.zeros(20, 20, 3))

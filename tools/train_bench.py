@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""BASELINE configs 3/4: iterations/s of a full training step (render, L1+SSIM,
+backward, [gradient all-reduce], 6 Adam groups) on a synthetic scene.
+
+    python tools/train_bench.py --gaussians 1000000 --width 1920 --height 1080 --iters 200
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...
+
+Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from harness.train import TrainConfig, train  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--views", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    idx = local % torch.cuda.device_count()
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    cfg = TrainConfig(num_gaussians=args.gaussians, width=args.width, height=args.height,
+                      num_views=args.views, iters=args.iters, sh_degree_interval=max(1, args.iters // 4))
+    res = train(cfg, dev, rank, world)
+    if world > 1:
+        cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        res["replicas_identical"] = bool(lo.item() == hi.item())
+    if rank == 0:
+        res.pop("losses", None)
+        res.update(metric="train iters/s", n_gpus=world, gaussians=args.gaussians,
+                   resolution=f"{args.width}x{args.height}")
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
