@@ -186,6 +186,8 @@ def main():
     camt = CameraTensors.from_numpy(cam, dev)
     bg, v_img, v_alpha = t(bg_np), t(v_img_np), t(v_alpha_np)
 
+    comm_events = []
+
     def step():
         for p in plist:
             p.grad = None
@@ -197,7 +199,14 @@ def main():
         else:
             torch.autograd.backward([out["rgb"], out["alpha"]], [v_img, v_alpha[..., None]])
         if world > 1:
-            allreduce_gradients(plist, average=True)
+            if timers.enabled:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                allreduce_gradients(plist, average=True)
+                e1.record()
+                comm_events.append((e0, e1))
+            else:
+                allreduce_gradients(plist, average=True)
         return out
 
     def barrier():
@@ -290,6 +299,10 @@ def main():
             "cpu_baseline": cpu,
             "kernels": per_kernel,
             "end_to_end_algorithmic_GBps": round(end_to_end, 1),
+            # N > 1: pack + all-reduce + unpack of the 59-float/Gaussian gradient (rank 0's view)
+            "allreduce_ms": (round(float(np.mean([a.elapsed_time(b) for a, b in comm_events])), 4)
+                             if comm_events else None),
+            "allreduce_bytes": sum(p.numel() for p in plist) * 4 if world > 1 else None,
         }
         print(json.dumps(line), flush=True)
 

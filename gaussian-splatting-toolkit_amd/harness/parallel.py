@@ -5,13 +5,14 @@ different camera; after the backward the parameter gradients are summed across
 ranks and (optionally) averaged.  The reference gets this from
 ``DistributedDataParallel`` (gs_toolkit/pipelines/base_pipeline.py:202-207),
 which breaks as soon as densification replaces the ``nn.Parameter`` objects, so
-the exchange is explicit here: all gradients are packed into ONE flat fp32
-buffer (59 floats = 236 B per Gaussian at SH degree 3) and reduced with a single
-collective -- on a ROCm build ``backend="nccl"`` is RCCL over xGMI, where one
-large message is what keeps all seven links of a GPU busy; many small bucketed
-ring all-reduces would be bound by a single link each.
+the exchange is explicit here: 59 floats = 236 B per Gaussian at SH degree 3,
+reduced either as one flat buffer or tensor by tensor in place (see
+`allreduce_gradients`).  On a ROCm build ``backend="nccl"`` is RCCL over xGMI;
+the messages are large (the SH block alone is 180 MB at 1 M Gaussians), which is
+what lets RCCL spread a collective over all seven links of a GPU -- DDP's default
+25 MB buckets would turn the same volume into ~10 smaller rings.
 """
-from typing import Iterable, List, Sequence
+from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -45,17 +46,37 @@ def unflatten_to_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]) -> No
         off += n
 
 
-def allreduce_gradients(params: Sequence[torch.Tensor], average: bool = True,
-                        group=None) -> torch.Tensor:
-    """Sum (or average) the gradients of `params` over all ranks with a single
-    all-reduce of the flat buffer; writes the result back into ``p.grad``."""
-    flat = flatten_grads(params)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+def allreduce_gradients(params: Sequence[torch.Tensor], average: bool = True, group=None,
+                        flat: Optional[bool] = None) -> Optional[torch.Tensor]:
+    """Sum (or average) the gradients of `params` over all ranks; the result
+    replaces ``p.grad``.
+
+    flat=True : pack everything into one fp32 buffer, ONE all-reduce, unpack (two
+                extra passes over the 236 B/Gaussian, but a single message);
+    flat=False: all-reduce each gradient tensor in place (no copies; six messages,
+                the 180 B/Gaussian `features_rest` one dominating).
+    Default: in place on RCCL (the copies cost more than five extra launches
+    there), flat on gloo/CPU."""
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if flat is None:
+        flat = not (distributed and dist.get_backend(group) == "nccl")
+    if not flat:
+        ws = dist.get_world_size(group) if distributed else 1
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if distributed:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group)
+                if average:
+                    p.grad.div_(ws)
+        return None
+    buf = flatten_grads(params)
+    if distributed:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         if average:
-            flat.div_(dist.get_world_size(group))
-    unflatten_to_grads(flat, params)
-    return flat
+            buf.div_(dist.get_world_size(group))
+    unflatten_to_grads(buf, params)
+    return buf
 
 
 def allreduce_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tensor,

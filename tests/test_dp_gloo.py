@@ -67,7 +67,16 @@ def _worker(rank, world, port, q):
     vc = torch.full((5,), rank + 1, dtype=torch.int32)
     mx = torch.tensor([float(rank), 3.0 - rank])
     allreduce_densify_stats(gn, vc, mx)
-    q.put((rank, view, [p.grad.clone() for p in params], flat.numel(), gn, vc, mx))
+    summed = [p.grad.clone() for p in params]
+    # the in-place, tensor-by-tensor variant (the default on RCCL) gives the same sums
+    for p, g in zip(params, grads):
+        p.grad = g.clone()
+    params[3].grad = None
+    assert allreduce_gradients(params, average=True, flat=False) is None
+    inplace_ok = all(torch.allclose(p.grad * world, s_, rtol=1e-6, atol=1e-7) for p, s_ in zip(params, summed))
+    for p, s_ in zip(params, summed):
+        p.grad = s_
+    q.put((rank, view, [p.grad.clone() for p in params], flat.numel(), gn, vc, mx, inplace_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,6 +106,7 @@ def test_two_rank_gradient_allreduce_equals_accumulation():
         assert torch.equal(rank_res[4], torch.full((5,), 3.0))
         assert torch.equal(rank_res[5], torch.full((5,), 3, dtype=torch.int32))
         assert torch.equal(rank_res[6], torch.tensor([1.0, 3.0]))
+        assert rank_res[7]
     # both ranks hold bit-identical reduced gradients (replicas stay in sync)
     for a, b in zip(results[0][2], results[1][2]):
         assert torch.equal(a, b)
