@@ -21,7 +21,16 @@
 
 #include "gsr_common.h"
 
+// sort_mid.hip
+size_t gsr_sort_mid_workspace_bytes(int n);
+int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, void *workspace,
+                 size_t workspace_bytes, hipStream_t s);
+
 namespace {
+
+// the purpose-built sort wins between these sizes; rocPRIM elsewhere
+constexpr int kMidSortMin = 1 << 16, kMidSortMax = 1 << 22;
+inline bool use_mid_sort(int n) { return n > kMidSortMin && n <= kMidSortMax; }
 
 struct TilesInOrder {
   const int *tiles;
@@ -121,8 +130,11 @@ size_t tile_sort_temp(int I) {
 
 GSR_EXPORT size_t gsr_depth_order_workspace_bytes(int num_points) {
   if (num_points <= 0) return 0;
-  const size_t t = std::max(depth_sort_temp(num_points), scan_temp(num_points));
-  return 2 * align_up(sizeof(unsigned) * (size_t)num_points) + align_up(t);
+  const size_t kb = align_up(sizeof(unsigned) * (size_t)num_points);
+  // [depth keys][ either: rocPRIM (sorted keys + temp)  or: sort_mid workspace ; scan temp shares it ]
+  const size_t rocprim_need = kb + align_up(std::max(depth_sort_temp(num_points), scan_temp(num_points)));
+  const size_t mid_need = align_up(std::max(gsr_sort_mid_workspace_bytes(num_points), scan_temp(num_points)));
+  return kb + (use_mid_sort(num_points) ? mid_need : rocprim_need);
 }
 
 GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
@@ -140,17 +152,24 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   char *ws = static_cast<char *>(workspace);
   const size_t kb = align_up(sizeof(unsigned) * (size_t)num_points);
   unsigned *keys_in = reinterpret_cast<unsigned *>(ws);
-  unsigned *keys_out = reinterpret_cast<unsigned *>(ws + kb);
-  void *temp = ws + 2 * kb;
-  size_t temp_bytes = workspace_bytes - 2 * kb;
+  char *rest = ws + kb;
+  size_t rest_bytes = workspace_bytes - kb;
   hipLaunchKernelGGL(depth_keys_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, num_points,
                      depths, radii, keys_in);
   GSR_CHECK_LAUNCH("depth_order(keys)");
-  GSR_CHECK_HIP(rocprim::radix_sort_pairs<depth_sort_config>(
-      temp, temp_bytes, (const unsigned *)keys_in, keys_out, rocprim::counting_iterator<int>(0), order,
-      (size_t)num_points, 0u, 31u, s));
+  if (use_mid_sort(num_points)) {
+    int rc = gsr_sort_mid(num_points, keys_in, order, 31, rest, rest_bytes, s);
+    if (rc != GSR_OK) return rc;
+  } else {
+    unsigned *keys_out = reinterpret_cast<unsigned *>(rest);
+    size_t temp_bytes = rest_bytes - kb;
+    GSR_CHECK_HIP(rocprim::radix_sort_pairs<depth_sort_config>(
+        rest + kb, temp_bytes, (const unsigned *)keys_in, keys_out, rocprim::counting_iterator<int>(0),
+        order, (size_t)num_points, 0u, 31u, s));
+  }
+  // the sort is finished with its workspace (stream order): reuse it for the scan
   auto in = rocprim::make_transform_iterator((const int *)order, TilesInOrder{num_tiles_hit});
-  GSR_CHECK_HIP(rocprim::inclusive_scan(temp, temp_bytes, in, cum_sorted, (size_t)num_points,
+  GSR_CHECK_HIP(rocprim::inclusive_scan(rest, rest_bytes, in, cum_sorted, (size_t)num_points,
                                         rocprim::plus<int>(), s));
   return GSR_OK;
 }

@@ -1,0 +1,182 @@
+// sort_mid.hip -- stable LSD radix sort of (u32 key, i32 index) pairs for
+// "mid-size" inputs (64 k .. 4 M items), gfx950.
+//
+// Why it exists: the depth ordering of the N ~ 1e6 Gaussians is the only sort of
+// that size in the pipeline, and rocPRIM serves it badly on MI355X whatever the
+// configuration (tools/exp/sortbench.hip: default / merge-path / Onesweep
+// variants all 143-190 us for 1 M pairs -- the work itself is 32 MB of traffic).
+// This is the textbook three-kernel pass, sized for the job:
+//   histogram  one workgroup per 2048-item chunk, 256-bin LDS histogram
+//   scan       one workgroup per digit: exclusive scan of its chunk counts + total
+//   scatter    same chunks; stable in-chunk ranking with wave-level digit
+//              matching (8 ballots) + per-wave counts in LDS
+// 4 passes x 3 launches for 31-bit keys.  The first pass reads the index as the
+// lane's position (no iota buffer).
+#include "gsr_common.h"
+
+namespace gsr_sort {
+
+constexpr int kThreads = 256;
+constexpr int kItems = 8;
+constexpr int kChunk = kThreads * kItems;  // 2048
+constexpr int kRadix = 256;
+
+__device__ __forceinline__ unsigned digit_of(unsigned key, int shift) { return (key >> shift) & 255u; }
+
+__global__ __launch_bounds__(kThreads) void hist_kernel(const int n, const unsigned *__restrict__ keys,
+                                                        const int shift, const int num_chunks,
+                                                        unsigned *__restrict__ hist) {
+  __shared__ unsigned h[kRadix];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  h[tid] = 0;
+  __syncthreads();
+  const int base = b * kChunk;
+#pragma unroll
+  for (int i = 0; i < kItems; ++i) {
+    const int idx = base + i * kThreads + tid;
+    if (idx < n) atomicAdd(&h[digit_of(keys[idx], shift)], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)tid * num_chunks + b] = h[tid];  // digit-major
+}
+
+// One workgroup per digit: exclusive scan of that digit's per-chunk counts (in place)
+// and the digit's total.  (A single-workgroup scan of all 256 x chunks counters took
+// 90 us -- one CU chasing 60 k dependent loads.)
+__global__ __launch_bounds__(kThreads) void digit_scan_kernel(const int num_chunks,
+                                                              unsigned *__restrict__ hist,
+                                                              unsigned *__restrict__ totals) {
+  __shared__ unsigned wave_sums[4];
+  __shared__ unsigned carry;
+  const int tid = threadIdx.x, d = blockIdx.x;
+  unsigned *row = hist + (size_t)d * num_chunks;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < num_chunks; base += kThreads) {
+    const int i = base + tid;
+    const unsigned c = i < num_chunks ? row[i] : 0u;
+    unsigned v = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(v, o);
+      if ((tid & 63) >= o) v += t;
+    }
+    if ((tid & 63) == 63) wave_sums[tid >> 6] = v;
+    __syncthreads();
+    unsigned before = carry;
+    for (int k = 0; k < (tid >> 6); ++k) before += wave_sums[k];
+    if (i < num_chunks) row[i] = before + v - c;
+    __syncthreads();
+    if (tid == 0) carry += wave_sums[0] + wave_sums[1] + wave_sums[2] + wave_sums[3];
+    __syncthreads();
+  }
+  if (tid == 0) totals[d] = carry;
+}
+
+// `vals_in == nullptr`: the value of item i is i
+__global__ __launch_bounds__(kThreads) void scatter_kernel(
+    const int n, const unsigned *__restrict__ keys_in, const int *__restrict__ vals_in, const int shift,
+    const int num_chunks, const unsigned *__restrict__ offsets, const unsigned *__restrict__ totals,
+    unsigned *__restrict__ keys_out, int *__restrict__ vals_out) {
+  __shared__ unsigned running[kRadix];      // next output slot per digit for this chunk
+  __shared__ unsigned wave_cnt[4][kRadix];  // per-wave digit counts of the current sub-tile
+  __shared__ unsigned wsum[4];
+  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63, w = tid >> 6;
+  // global base of digit `tid` = exclusive scan of the 256 digit totals
+  {
+    const unsigned t = totals[tid];
+    unsigned v = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = __shfl_up(v, o);
+      if (lane >= o) v += u;
+    }
+    if (lane == 63) wsum[w] = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wave_cnt[k][tid] = 0;
+    __syncthreads();
+    unsigned before = 0;
+    for (int k = 0; k < w; ++k) before += wsum[k];
+    running[tid] = before + v - t + offsets[(size_t)tid * num_chunks + b];
+  }
+  __syncthreads();
+  const int base = b * kChunk;
+  for (int i = 0; i < kItems; ++i) {
+    const int idx = base + i * kThreads + tid;
+    const bool live = idx < n;
+    const unsigned key = live ? keys_in[idx] : 0xffffffffu;
+    const unsigned d = live ? digit_of(key, shift) : 255u;
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const unsigned long long set = __ballot((d >> bit) & 1u);
+      peers &= ((d >> bit) & 1u) ? set : ~set;
+    }
+    const unsigned below = __popcll(peers & ((1ull << lane) - 1ull));
+    const bool leader = live && below == 0;  // one per (wave, digit)
+    const unsigned count = (unsigned)__popcll(peers);
+    if (leader) wave_cnt[w][d] = count;
+    __syncthreads();
+    if (live) {
+      unsigned pos = running[d] + below;
+      for (int k = 0; k < w; ++k) pos += wave_cnt[k][d];
+      keys_out[pos] = key;
+      vals_out[pos] = vals_in ? vals_in[idx] : idx;
+    }
+    __syncthreads();
+    if (leader) {
+      atomicAdd(&running[d], count);
+      wave_cnt[w][d] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace gsr_sort
+
+// ---- internal interface used by binning_fast.hip ---------------------------
+// workspace: 2 key buffers + 2 value buffers + histogram
+size_t gsr_sort_mid_workspace_bytes(int n) {
+  using namespace gsr_sort;
+  const size_t chunks = (size_t)gsr_cdiv((unsigned)n, kChunk);
+  return 2 * align_up(4 * (size_t)n) + align_up(4 * (size_t)n) + align_up(4 * kRadix * (chunks + 1));
+}
+
+// sorts by the low `key_bits` bits; keys_in is left untouched; result indices in vals_out
+int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, void *workspace,
+                 size_t workspace_bytes, hipStream_t s) {
+  using namespace gsr_sort;
+  if (n <= 0) return GSR_OK;
+  if (workspace_bytes < gsr_sort_mid_workspace_bytes(n)) {
+    gsr_set_error("sort_mid: workspace too small");
+    return GSR_ENOMEM;
+  }
+  const int chunks = (int)gsr_cdiv((unsigned)n, kChunk);
+  char *ws = static_cast<char *>(workspace);
+  const size_t nb = align_up(4 * (size_t)n);
+  unsigned *kbuf[2] = {reinterpret_cast<unsigned *>(ws), reinterpret_cast<unsigned *>(ws + nb)};
+  int *vtmp = reinterpret_cast<int *>(ws + 2 * nb);
+  unsigned *hist = reinterpret_cast<unsigned *>(ws + 3 * nb);
+  unsigned *totals = hist + (size_t)kRadix * chunks;
+  const int passes = (key_bits + 7) / 8;
+  // ping-pong so that the LAST pass writes the values into vals_out
+  const unsigned *kin = keys_in;
+  const int *vin = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    const bool last = p == passes - 1;
+    unsigned *kout = kbuf[p & 1];
+    int *vout = ((passes - 1 - p) & 1) ? vtmp : vals_out;
+    (void)last;
+    hipLaunchKernelGGL(hist_kernel, dim3(chunks), dim3(kThreads), 0, s, n, kin, 8 * p, chunks, hist);
+    hipLaunchKernelGGL(digit_scan_kernel, dim3(kRadix), dim3(kThreads), 0, s, chunks, hist, totals);
+    hipLaunchKernelGGL(scatter_kernel, dim3(chunks), dim3(kThreads), 0, s, n, kin, vin, 8 * p, chunks,
+                       (const unsigned *)hist, (const unsigned *)totals, kout, vout);
+    kin = kout;
+    vin = vout;
+  }
+  GSR_CHECK_LAUNCH("sort_mid");
+  return GSR_OK;
+}
