@@ -15,6 +15,7 @@
 // ties in depth keep ascending Gaussian id because step 1 is stable too.  The
 // I-sized arrays (I = #intersections, ~8-20 N) are touched by 44 B/intersection
 // instead of 164 B (12 B emission + six 24-B passes over 64-bit keys + 8 B).
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -25,6 +26,9 @@
 size_t gsr_sort_mid_workspace_bytes(int n);
 int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, void *workspace,
                  size_t workspace_bytes, hipStream_t s);
+int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsigned *keys_out,
+                       int *vals_out, int key_bits, void *workspace, size_t workspace_bytes,
+                       hipStream_t s);
 
 namespace {
 
@@ -176,7 +180,8 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
 
 GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects) {
   if (num_intersects <= 0) return 0;
-  return 3 * align_up(4 * (size_t)num_intersects) + align_up(tile_sort_temp(num_intersects));
+  return 3 * align_up(4 * (size_t)num_intersects) +
+         align_up(std::max(tile_sort_temp(num_intersects), gsr_sort_mid_workspace_bytes(num_intersects)));
 }
 
 GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
@@ -211,9 +216,19 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
                      num_points, order, cum_sorted, xys, radii, tiles_x, tiles_y, (int)block_width, tile_in,
                      ids_in);
   GSR_CHECK_LAUNCH("bin_sorted(emit)");
-  GSR_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned *)tile_in, tile_out,
-                                          (const int *)ids_in, gaussian_ids_sorted, (size_t)num_intersects,
-                                          0u, tile_bits(num_tiles), s));
+  static const bool mid_tile_sort = [] {
+    const char *e = getenv("GSR_TILE_SORT");
+    return e && e[0] == 'm';
+  }();
+  if (mid_tile_sort) {
+    int rc = gsr_sort_mid_pairs(num_intersects, tile_in, ids_in, tile_out, gaussian_ids_sorted,
+                                (int)tile_bits(num_tiles), temp, temp_bytes, s);
+    if (rc != GSR_OK) return rc;
+  } else {
+    GSR_CHECK_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned *)tile_in, tile_out,
+                                            (const int *)ids_in, gaussian_ids_sorted,
+                                            (size_t)num_intersects, 0u, tile_bits(num_tiles), s));
+  }
   hipLaunchKernelGGL(tile_bin_edges32_kernel, dim3(gsr_cdiv(num_intersects, 256)), dim3(256), 0, s,
                      num_intersects, (const unsigned *)tile_out, tile_bins);
   GSR_CHECK_LAUNCH("bin_sorted(edges)");

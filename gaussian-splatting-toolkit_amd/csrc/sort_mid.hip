@@ -145,9 +145,11 @@ size_t gsr_sort_mid_workspace_bytes(int n) {
   return 2 * align_up(4 * (size_t)n) + align_up(4 * (size_t)n) + align_up(4 * kRadix * (chunks + 1));
 }
 
-// sorts by the low `key_bits` bits; keys_in is left untouched; result indices in vals_out
-int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, void *workspace,
-                 size_t workspace_bytes, hipStream_t s) {
+// Sorts by the low `key_bits` bits, stably.  keys_in / vals_in are left untouched.
+// vals_in == nullptr: the value of item i is i.  keys_out may be nullptr.
+int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsigned *keys_out,
+                       int *vals_out, int key_bits, void *workspace, size_t workspace_bytes,
+                       hipStream_t s) {
   using namespace gsr_sort;
   if (n <= 0) return GSR_OK;
   if (workspace_bytes < gsr_sort_mid_workspace_bytes(n)) {
@@ -162,14 +164,13 @@ int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, vo
   unsigned *hist = reinterpret_cast<unsigned *>(ws + 3 * nb);
   unsigned *totals = hist + (size_t)kRadix * chunks;
   const int passes = (key_bits + 7) / 8;
-  // ping-pong so that the LAST pass writes the values into vals_out
+  // ping-pong so that the LAST pass writes into the caller's output buffers
   const unsigned *kin = keys_in;
-  const int *vin = nullptr;
+  const int *vin = vals_in;
   for (int p = 0; p < passes; ++p) {
     const bool last = p == passes - 1;
-    unsigned *kout = kbuf[p & 1];
+    unsigned *kout = (last && keys_out) ? keys_out : kbuf[p & 1];
     int *vout = ((passes - 1 - p) & 1) ? vtmp : vals_out;
-    (void)last;
     hipLaunchKernelGGL(hist_kernel, dim3(chunks), dim3(kThreads), 0, s, n, kin, 8 * p, chunks, hist);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(kRadix), dim3(kThreads), 0, s, chunks, hist, totals);
     hipLaunchKernelGGL(scatter_kernel, dim3(chunks), dim3(kThreads), 0, s, n, kin, vin, 8 * p, chunks,
@@ -179,4 +180,9 @@ int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, vo
   }
   GSR_CHECK_LAUNCH("sort_mid");
   return GSR_OK;
+}
+
+int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, void *workspace,
+                 size_t workspace_bytes, hipStream_t s) {
+  return gsr_sort_mid_pairs(n, keys_in, nullptr, nullptr, vals_out, key_bits, workspace, workspace_bytes, s);
 }

@@ -363,3 +363,37 @@ def test_cov2d_bounds():
     r_g, r_r = npy(got[1]), ref[1]
     assert got[1].shape == (n, 1)
     assert (r_g == r_r).mean() > 0.995 and np.abs(r_g - r_r).max() <= 1
+
+
+@pytest.mark.parametrize("n", [65_537, 100_000, 1_000_003, 4_194_304, 4_194_305])
+@pytest.mark.parametrize("dist", ["random", "equal", "two", "sorted", "reversed", "narrow"])
+def test_depth_order_sort_is_exact_and_stable(n, dist):
+    """gsr_depth_order (purpose-built radix sort between 64k and 4M items, rocPRIM
+    outside) == stable argsort by (depth, index); culled splats first; the scan of
+    the tile counts follows that order."""
+    import rasterizer.cuda as C
+
+    if n > 2_000_000 and dist not in ("random", "equal"):
+        pytest.skip("large sizes: two distributions are enough")
+    rng = np.random.default_rng(n % 1000 + len(dist))
+    if dist == "random":
+        d = rng.uniform(0.01, 1000.0, n)
+    elif dist == "equal":
+        d = np.full(n, 3.25)
+    elif dist == "two":
+        d = rng.choice([2.0, 7.5], n)
+    elif dist == "sorted":
+        d = np.linspace(0.5, 50.0, n)
+    elif dist == "reversed":
+        d = np.linspace(50.0, 0.5, n)
+    else:  # all keys share their three high bytes
+        d = (np.float32(4.0) + rng.integers(0, 200, n).astype(np.float32) * np.float32(4.7683716e-07))
+    d = d.astype(np.float32)
+    radii = np.ones(n, np.int32)
+    radii[rng.integers(0, n, n // 10)] = 0  # culled: key 0, emitted first
+    tiles = rng.integers(0, 5, n).astype(np.int32) * (radii > 0)
+    order, cum = C.depth_order(cu(d), cu(radii), cu(tiles))
+    key = np.where(radii > 0, d, 0).astype(np.float32)
+    ref = np.argsort(key.view(np.uint32), kind="stable")
+    assert np.array_equal(npy(order), ref.astype(np.int32))
+    assert np.array_equal(npy(cum), np.cumsum(tiles[ref]).astype(np.int32))
