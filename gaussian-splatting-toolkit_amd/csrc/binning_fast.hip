@@ -21,6 +21,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "gsr_common.h"
+#include "raster_common.h"
 
 // sort_mid.hip
 size_t gsr_sort_mid_workspace_bytes(int n);
@@ -51,26 +52,178 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(const int n, const floa
   keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0u;
 }
 
-__global__ __launch_bounds__(256) void emit_in_depth_order_kernel(
-    const int n, const int *__restrict__ order, const int *__restrict__ cum_sorted,
-    const float *__restrict__ xys, const int *__restrict__ radii, const int tiles_x,
-    const int tiles_y, const int bw, unsigned *__restrict__ tile_keys, int *__restrict__ gaussian_ids) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int g = order[i];
-  const int r = radii[g];
-  if (r <= 0) return;
-  int minx, miny, maxx, maxy;
-  gsr_tile_bbox(xys[2 * g], xys[2 * g + 1], (float)r, tiles_x, tiles_y, 0.f, bw, minx, miny, maxx, maxy);
-  int cur = (i == 0) ? 0 : cum_sorted[i - 1];
-  for (int ty = miny; ty < maxy; ++ty) {
-    const unsigned row = (unsigned)(ty * tiles_x);
-    for (int tx = minx; tx < maxx; ++tx) {
-      tile_keys[cur] = row + (unsigned)tx;
-      gaussian_ids[cur] = g;
-      ++cur;
+// ---- tile lists: which tiles of its bounding box does a splat go into? -----
+// Per Gaussian record (32 B) written by the count pass in index order and
+// gathered by the emission pass in depth order (one 32-B sector per Gaussian
+// instead of four scattered loads).
+struct alignas(16) SplatRec {
+  float x, y, a, b, c;
+  float smax;     // see raster_common.h make_reach(): +inf = keep every box tile, < 0 = none
+  unsigned box0;  // minx | miny << 16
+  unsigned box1;  // box width | box height << 16   (0 | 0 when culled)
+};
+static_assert(sizeof(SplatRec) == 32, "SplatRec layout");
+
+// derived per Gaussian, kept in LDS for the row loop
+struct RowParams {
+  float D;      // a c - b^2
+  float umax;   // half x-extent of {sigma <= smax}
+  float vmax;   // half y-extent
+  float vstar;  // y offset of the rightmost point is -vstar, of the leftmost +vstar
+};
+
+__device__ __forceinline__ RowParams make_row_params(const SplatRec &r) {
+  RowParams p{1.f, 0.f, 0.f, 0.f};
+  if (r.smax >= 0.f && r.smax != INFINITY) {
+    p.D = r.a * r.c - r.b * r.b;  // > 0 (make_reach sets smax = inf otherwise)
+    const float t = 2.f * r.smax / p.D;
+    p.umax = sqrtf(t * r.c);
+    p.vmax = sqrtf(t * r.a);
+    p.vstar = r.b * p.umax / r.c;
+  }
+  return p;
+}
+
+// Tiles [t0, t1) of tile row `ty` (inside the box) in which the splat can reach
+// alpha >= 1/255, i.e. whose pixel-centre rectangle [16tx, 16tx+15] x [16ty, 16ty+15]
+// meets the ellipse {sigma <= smax}.  The ellipse cut by the row's band is convex,
+// so its x-projection is one interval [xl, xr]; xr is attained at the band's point
+// closest (in y) to the ellipse's rightmost point, xl likewise.  Conservative:
+// `smax` carries a 1 % margin in alpha (make_reach) and the interval is widened
+// by 1e-3 of the ellipse's extent + 0.05 px against rounding in the square roots.
+// The compositing kernels re-test per sub-tile / pixel, so keeping a dead pair is
+// harmless; dropping a live one is what the margins exclude
+// (tests/test_gpu_kernels.py::test_exact_lists_drop_only_dead_pairs).
+__device__ __forceinline__ void row_range(const SplatRec &r, const RowParams &p, int ty, int &t0, int &t1) {
+  const int minx = (int)(r.box0 & 0xffffu), bwid = (int)(r.box1 & 0xffffu);
+  t0 = minx;
+  t1 = minx + bwid;
+  if (r.smax == INFINITY) return;
+  if (r.smax < 0.f) {
+    t1 = t0;
+    return;
+  }
+  const float v0 = 16.f * (float)ty - r.y, v1 = v0 + 15.f;
+  const float mv = 1e-3f * p.vmax + 0.05f, mu = 1e-3f * p.umax + 0.05f;
+  if (v0 > p.vmax + mv || v1 < -p.vmax - mv) {
+    t1 = t0;
+    return;
+  }
+  const float two_as = 2.f * r.a * r.smax;
+  const float vr = fminf(fmaxf(-p.vstar, v0), v1), vl = fminf(fmaxf(p.vstar, v0), v1);
+  const float inv_a = 1.f / r.a;
+  const float xr = (-r.b * vr + sqrtf(fmaxf(two_as - p.D * vr * vr, 0.f))) * inv_a + mu;
+  const float xl = (-r.b * vl - sqrtf(fmaxf(two_as - p.D * vl * vl, 0.f))) * inv_a - mu;
+  // 16 tx <= x + xr   and   16 tx + 15 >= x + xl
+  const float f0 = fminf(fmaxf(ceilf((r.x + xl - 15.f) * 0.0625f), (float)t0), (float)t1);
+  const float f1 = fminf(fmaxf(floorf((r.x + xr) * 0.0625f) + 1.f, (float)t0), (float)t1);
+  t0 = (int)f0;
+  t1 = (int)f1 > t0 ? (int)f1 : t0;
+}
+
+// One wave handles 64 Gaussians and walks their (Gaussian, tile row) items
+// LOAD-BALANCED: rows are numbered consecutively (prefix sum of the box heights)
+// and lane l takes rows l, l+64, ... -- a lane per Gaussian looping over its own
+// box leaves most of the wave idle behind the largest splat.
+//
+//   mode 0 (count): Gaussians in index order; writes counts[g] and recs[g]
+//   mode 1 (emit):  Gaussians in depth order (`order`); the tiles of a row are
+//           written at cum[first Gaussian of the wave - 1] + rank, which keeps the
+//           stream ordered by (depth position, tile row-major)
+//
+// With `recs == nullptr` (mode 1 only) every box tile is emitted: the reference's
+// lists.  Both modes evaluate row_range() with the same instructions on the same
+// record, so counts and emission agree exactly.
+__global__ __launch_bounds__(256) void tile_rows_kernel(
+    const int mode, const int n, const int *__restrict__ order, const int *__restrict__ cum,
+    const float *__restrict__ xys, const int *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ opacities, const int tiles_x, const int tiles_y, const int bw,
+    SplatRec *__restrict__ recs, unsigned *__restrict__ tile_keys, int *__restrict__ gaussian_ids,
+    int *__restrict__ counts) {
+  __shared__ int s_pref[4][64];
+  __shared__ int s_cnt[4][64];
+  __shared__ int s_gid[4][64];
+  __shared__ SplatRec s_rec[4][64];
+  __shared__ RowParams s_par[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i0 = (blockIdx.x * 4 + w) * 64, i = i0 + lane;
+  const int g = i < n ? (mode ? order[i] : i) : 0;
+  SplatRec rec{0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0u, 0u};
+  if (i < n) {
+    if (mode && recs) {
+      rec = recs[g];
+    } else {
+      const int r = radii[g];
+      if (r > 0) {
+        int minx, miny, maxx, maxy;
+        const float x = xys[2 * g], y = xys[2 * g + 1];
+        gsr_tile_bbox(x, y, (float)r, tiles_x, tiles_y, 0.f, bw, minx, miny, maxx, maxy);
+        rec.x = x;
+        rec.y = y;
+        rec.smax = INFINITY;
+        if (conics) {
+          const gsr::Reach rc = gsr::make_reach(x, y, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g]);
+          rec.a = rc.a;
+          rec.b = rc.b;
+          rec.c = rc.c;
+          rec.smax = rc.smax;
+        }
+        if (maxx > minx && maxy > miny && !(rec.smax < 0.f)) {
+          rec.box0 = (unsigned)minx | ((unsigned)miny << 16);
+          rec.box1 = (unsigned)(maxx - minx) | ((unsigned)(maxy - miny) << 16);
+        }
+      }
+      if (!mode) recs[g] = rec;
     }
   }
+  const int rows = (int)(rec.box1 >> 16);
+  int incl = rows;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  const int total = __shfl(incl, 63);
+  s_pref[w][lane] = incl;
+  s_cnt[w][lane] = 0;
+  s_gid[w][lane] = g;
+  s_rec[w][lane] = rec;
+  s_par[w][lane] = make_row_params(rec);
+  __syncthreads();
+  int out = 0;
+  if (mode) out = (i0 > 0 && i0 < n) ? cum[i0 - 1] : 0;
+  for (int q0 = 0; q0 < total; q0 += 64) {
+    const int q = q0 + lane;
+    int k = 0;  // number of Gaussians whose rows all precede q
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1)
+      if (s_pref[w][k + step - 1] <= q) k += step;
+    k = k < 63 ? k : 63;
+    const SplatRec r = s_rec[w][k];
+    const int ty = (int)(r.box0 >> 16) + q - (k ? s_pref[w][k - 1] : 0);
+    int t0 = 0, t1 = 0;
+    if (q < total) row_range(r, s_par[w][k], ty, t0, t1);
+    const int cnt = t1 - t0;
+    if (mode) {
+      int sc = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(sc, o);
+        if (lane >= o) sc += t;
+      }
+      int pos = out + sc - cnt;
+      const unsigned key0 = (unsigned)(ty * tiles_x);
+      const int gid = s_gid[w][k];
+      for (int tx = t0; tx < t1; ++tx, ++pos) {
+        tile_keys[pos] = key0 + (unsigned)tx;
+        gaussian_ids[pos] = gid;
+      }
+      out += __shfl(sc, 63);
+    } else if (cnt > 0) {
+      atomicAdd(&s_cnt[w][k], cnt);
+    }
+  }
+  if (!mode && i < n) counts[i] = s_cnt[w][lane];
 }
 
 __global__ __launch_bounds__(256) void tile_bins_clear_kernel(const int num_tiles, int2 *__restrict__ tile_bins) {
@@ -178,6 +331,24 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   return GSR_OK;
 }
 
+GSR_EXPORT size_t gsr_reach_record_bytes(void) { return sizeof(SplatRec); }
+
+GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *radii, const float *conics,
+                               const float *opacities, int tiles_x, int tiles_y, int32_t *counts,
+                               void *reach_records, gsr_stream_t stream) {
+  GSR_REQUIRE(num_points >= 0, "count_reach: num_points < 0");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(xys && radii && conics && opacities && counts && reach_records, "count_reach: null pointer");
+  GSR_REQUIRE(tiles_x > 0 && tiles_y > 0 && tiles_x <= 65535 && tiles_y <= 65535, "count_reach: bad tile grid");
+  GSR_REQUIRE((reinterpret_cast<uintptr_t>(reach_records) & 15) == 0, "count_reach: reach_records must be 16-byte aligned");
+  hipLaunchKernelGGL(tile_rows_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream, 0,
+                     num_points, (const int *)nullptr, (const int *)nullptr, xys, radii, conics, opacities,
+                     tiles_x, tiles_y, 16, static_cast<SplatRec *>(reach_records), (unsigned *)nullptr,
+                     (int *)nullptr, counts);
+  GSR_CHECK_LAUNCH("count_reach");
+  return GSR_OK;
+}
+
 GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects) {
   if (num_intersects <= 0) return 0;
   return 3 * align_up(4 * (size_t)num_intersects) +
@@ -186,13 +357,15 @@ GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects) {
 
 GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                               const int32_t *cum_sorted, const float *xys, const int32_t *radii,
-                              int tiles_x, int tiles_y, unsigned block_width,
+                              const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
                               int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
                               size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0 && num_intersects >= 0, "bin_sorted: negative size");
   GSR_REQUIRE(block_width >= 2 && block_width <= 16, "bin_sorted: block_width must be in [2,16]");
   GSR_REQUIRE(tiles_x > 0 && tiles_y > 0, "bin_sorted: empty tile grid");
   GSR_REQUIRE(tile_bins, "bin_sorted: null pointer");
+  GSR_REQUIRE(reach_records == nullptr || block_width == 16, "bin_sorted: reach records are for block_width 16");
+  GSR_REQUIRE(tiles_x <= 65535 && tiles_y <= 65535, "bin_sorted: tile grid too large");
   hipStream_t s = (hipStream_t)stream;
   const int num_tiles = tiles_x * tiles_y;
   hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
@@ -212,9 +385,11 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
   int *ids_in = reinterpret_cast<int *>(ws + 2 * ib);
   void *temp = ws + 3 * ib;
   size_t temp_bytes = workspace_bytes - 3 * ib;
-  hipLaunchKernelGGL(emit_in_depth_order_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s,
-                     num_points, order, cum_sorted, xys, radii, tiles_x, tiles_y, (int)block_width, tile_in,
-                     ids_in);
+  hipLaunchKernelGGL(tile_rows_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, 1, num_points,
+                     order, cum_sorted, xys, radii, (const float *)nullptr, (const float *)nullptr, tiles_x,
+                     tiles_y, (int)block_width,
+                     const_cast<SplatRec *>(static_cast<const SplatRec *>(reach_records)), tile_in, ids_in,
+                     (int *)nullptr);
   GSR_CHECK_LAUNCH("bin_sorted(emit)");
   static const bool mid_tile_sort = [] {
     const char *e = getenv("GSR_TILE_SORT");

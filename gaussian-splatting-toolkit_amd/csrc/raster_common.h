@@ -22,46 +22,60 @@ struct __align__(16) SplatC { float blue; int sidx; int mask; int pad; };
 
 // Can ANY pixel centre of the (w+1) x (w+1) pixel square whose first pixel is
 // (rx0, ry0) get alpha = opac*exp(-sigma) >= 1/255 from this splat?  The tile
-// lists are built from the 3-sigma *square* bounding box (forward.cu:73): about
-// half of a tile's entries never pass the alpha test at any of its pixels, and
-// of the rest ~1/3 of the (splat, sub-tile) pairs don't either.  Dropping them
-// cannot change a result: the compositing rule skips them pixel by pixel
-// (alpha < 1/255 -> continue).  The test is conservative: sigma is minimised
-// over the continuous rectangle (<= its minimum over the pixel centres) and
-// `smax` carries a 1 % margin in alpha, far above fp32 rounding.
-__device__ __forceinline__ bool reaches_rect(float x, float y, float a, float b, float c,
-                                             float nb_c, float nb_a, float smax, float rx0,
-                                             float ry0, float w) {
-  const float u0 = rx0 - x, u1 = u0 + w, v0 = ry0 - y, v1 = v0 + w;
+// lists of the reference are built from the 3-sigma *square* bounding box
+// (forward.cu:73): about half of a tile's entries never pass the alpha test at
+// any of its pixels, and of the rest ~1/3 of the (splat, sub-tile) pairs don't
+// either.  Dropping them cannot change a result: the compositing rule skips them
+// pixel by pixel (alpha < 1/255 -> continue).  The test is conservative: sigma is
+// minimised over the continuous rectangle (<= its minimum over the pixel
+// centres) and `smax` carries a 1 % margin in alpha, far above fp32 rounding.
+struct Reach {
+  float x, y, a, b, c;
+  float nb_c, nb_a;  // -b/c, -b/a
+  float smax;        // sigma bound: +inf = always keep, < 0 = can never reach
+};
+
+__device__ __forceinline__ Reach make_reach(float x, float y, float a, float b, float c, float opac) {
+  Reach r{x, y, a, b, c, 0.f, 0.f, 0.f};
+  // alpha >= 1/255  <=>  sigma <= log(255*opac)
+  r.smax = __logf(255.f * opac) + 0.01f;
+  if (!(r.smax >= 0.f)) r.smax = (opac == opac) ? -1.f : INFINITY;  // too faint anywhere (NaN: keep)
+  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) {
+    r.smax = INFINITY;  // not positive definite: no culling
+  } else {
+    r.nb_c = -b / c;
+    r.nb_a = -b / a;
+  }
+  return r;
+}
+
+__device__ __forceinline__ bool reaches_rect(const Reach &r, float rx0, float ry0, float w) {
+  if (r.smax == INFINITY) return true;
+  if (r.smax < 0.f) return false;
+  const float u0 = rx0 - r.x, u1 = u0 + w, v0 = ry0 - r.y, v1 = v0 + w;
   if (u0 <= 0.f && u1 >= 0.f && v0 <= 0.f && v1 >= 0.f) return true;  // centre inside
   // convex quadratic, unconstrained minimum (0,0) outside the rectangle ->
   // the minimum over the rectangle lies on one of its four edges
   auto edge_u = [&](float ue) {
-    const float v = fminf(fmaxf(nb_c * ue, v0), v1);
-    return 0.5f * (a * ue * ue + c * v * v) + b * ue * v;
+    const float v = fminf(fmaxf(r.nb_c * ue, v0), v1);
+    return 0.5f * (r.a * ue * ue + r.c * v * v) + r.b * ue * v;
   };
   auto edge_v = [&](float ve) {
-    const float u = fminf(fmaxf(nb_a * ve, u0), u1);
-    return 0.5f * (a * u * u + c * ve * ve) + b * u * ve;
+    const float u = fminf(fmaxf(r.nb_a * ve, u0), u1);
+    return 0.5f * (r.a * u * u + r.c * ve * ve) + r.b * u * ve;
   };
   const float smin = fminf(fminf(edge_u(u0), edge_u(u1)), fminf(edge_v(v0), edge_v(v1)));
-  return smin <= smax;
+  return smin <= r.smax;
 }
 
 // 4-bit reach mask over the sub-tiles of the tile at (tx0, ty0); 0 = drop.
 __device__ __forceinline__ int splat_reach_mask(float x, float y, float a, float b, float c,
                                                 float opac, float tx0, float ty0) {
-  // alpha >= 1/255  <=>  sigma <= log(255*opac)
-  const float smax = __logf(255.f * opac) + 0.01f;
-  if (!(smax >= 0.f)) return (opac == opac) ? 0 : 15;  // too faint anywhere (NaN: keep)
-  if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return 15;  // not positive definite: no culling
-  const float nb_c = -b / c, nb_a = -b / a;
+  const Reach r = make_reach(x, y, a, b, c, opac);
   int m = 0;
 #pragma unroll
   for (int p = 0; p < 4; ++p)
-    m |= reaches_rect(x, y, a, b, c, nb_c, nb_a, smax, tx0 + 8.f * (p & 1), ty0 + 8.f * (p >> 1), 7.f)
-             ? (1 << p)
-             : 0;
+    m |= reaches_rect(r, tx0 + 8.f * (p & 1), ty0 + 8.f * (p >> 1), 7.f) ? (1 << p) : 0;
   return m;
 }
 

@@ -14,7 +14,7 @@ reference's ``torch::zeros`` pre-fill is not needed) and kernels are enqueued
 on the *current* HIP stream of that device.  There is no CPU path.
 """
 import ctypes as C
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -252,14 +252,42 @@ def depth_order(depths: Tensor, radii: Tensor, num_tiles_hit: Tensor) -> Tuple[T
     return order, cum
 
 
+def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
+                tile_bounds: Tuple[int, int, int]) -> Tuple[Tensor, Tensor]:
+    """``gsr_count_reach``: per Gaussian, the number of 16x16 tiles of its bounding
+    box in which it can reach alpha >= 1/255 -> (counts i32[N] <= num_tiles_hit,
+    opaque per-Gaussian records for :func:`bin_sorted`)."""
+    _check(xys, "xys", _f32)
+    _check(radii, "radii", _i32)
+    _check(conics, "conics", _f32)
+    _check(opacities, "opacities", _f32)
+    n = radii.numel()
+    if xys.numel() != 2 * n or conics.numel() != 3 * n or opacities.numel() != n:
+        raise RuntimeError("count_reach: xys [N,2], conics [N,3], opacities [N,1] expected")
+    dev = xys.device
+    with torch.cuda.device(dev):
+        counts = torch.empty((n,), dtype=_i32, device=dev)
+        recs = torch.empty((n, int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
+        _call("gsr_count_reach", C.c_int(n), _ptr(xys), _ptr(radii), _ptr(conics), _ptr(opacities),
+              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(counts), _ptr(recs), _stream(dev))
+    return counts, recs
+
+
 def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Tensor, xys: Tensor,
-               radii: Tensor, tile_bounds: Tuple[int, int, int], block_width: int) -> Tuple[Tensor, Tensor]:
+               radii: Tensor, tile_bounds: Tuple[int, int, int], block_width: int,
+               reach_records: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Second half (``gsr_bin_sorted``): -> (gaussian_ids_sorted i32[I],
-    tile_bins i32[T,2]), identical to what ``bin_and_sort_gaussians`` returns."""
+    tile_bins i32[T,2]), identical to what ``bin_and_sort_gaussians`` returns.
+    With the records (and counts) of :func:`count_reach`: the same lists without
+    the pairs that cannot reach alpha >= 1/255 anywhere in their tile."""
     _check(order, "order", _i32)
     _check(cum_sorted, "cum_sorted", _i32)
     _check(xys, "xys", _f32)
     _check(radii, "radii", _i32)
+    if reach_records is not None:
+        _check(reach_records, "reach_records", torch.uint8)
+        if reach_records.numel() != int(num_points) * int(_lib().gsr_reach_record_bytes()):
+            raise RuntimeError("bin_sorted: reach_records has the wrong size")
     I = int(num_intersects)
     nt = int(tile_bounds[0]) * int(tile_bounds[1])
     dev = xys.device
@@ -269,8 +297,9 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
         nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I)))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         _call("gsr_bin_sorted", C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted),
-              _ptr(xys), _ptr(radii), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
-              C.c_uint(block_width), _ptr(ids), _ptr(tile_bins), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+              _ptr(xys), _ptr(radii), _ptr(reach_records) if reach_records is not None else None,
+              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(block_width), _ptr(ids),
+              _ptr(tile_bins), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
     return ids, tile_bins
 
 

@@ -28,6 +28,8 @@ SYMBOLS = (
     "gsr_sort_workspace_bytes",
     "gsr_sort_intersects",
     "gsr_tile_bin_edges",
+    "gsr_reach_record_bytes",
+    "gsr_count_reach",
     "gsr_depth_order_workspace_bytes",
     "gsr_depth_order",
     "gsr_bin_sorted_workspace_bytes",
@@ -63,6 +65,7 @@ def _load():
     lib.gsr_version.restype = C.c_int
     lib.gsr_cumsum_workspace_bytes.restype = C.c_size_t
     lib.gsr_sort_workspace_bytes.restype = C.c_size_t
+    lib.gsr_reach_record_bytes.restype = C.c_size_t
     lib.gsr_depth_order_workspace_bytes.restype = C.c_size_t
     lib.gsr_bin_sorted_workspace_bytes.restype = C.c_size_t
     return lib

@@ -9,7 +9,8 @@ One addition that is invisible to the caller: the models call
 depth; gs_toolkit/models/vanilla_gs.py:822,840).  The second call reuses the
 sorted intersection list and tile ranges of the first instead of running the
 scan + key emission + radix sort again.  The cache holds one entry, keyed on
-the storage address, shape and version counter of the four geometry tensors.
+the storage address, shape and version counter of the four geometry tensors
+(plus conics and opacity, which the 16x16 lists also depend on).
 It keeps detached aliases of them alive, so their storage cannot be recycled
 for another tensor while the entry exists (an address match therefore means
 the same memory), and an in-place update bumps the version and misses.
@@ -22,13 +23,30 @@ from torch.autograd import Function
 
 import rasterizer.cuda as _C
 
-_bin_cache = {"key": None, "value": None, "keepalive": None}
+_bin_cache = {"key": None, "value": None, "keepalive": None, "reach": None}
 
 
 def _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width):
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (xys, depths, radii, num_tiles_hit)) + (
         img_height, img_width, block_width, xys.device,
     )
+
+
+def _same_reach_inputs(conics, opacity) -> bool:
+    """Are `conics` / `opacity` the tensors the cached lists were built from?  The
+    same storage at the same version, or -- the models pass a fresh
+    `torch.sigmoid(opacities)` to each of their two calls per view
+    (vanilla_gs.py:829,847) -- equal values."""
+    c0, o0, cv, ov = _bin_cache["reach"]
+    for t, t0, v0 in ((conics, c0, cv), (opacity, o0, ov)):
+        if t.shape != t0.shape:
+            return False
+        if t.data_ptr() == t0.data_ptr():
+            if t._version != v0:
+                return False
+        elif not torch.equal(t, t0):
+            return False
+    return True
 
 
 def rasterize_gaussians(
@@ -95,22 +113,33 @@ class _RasterizeGaussians(Function):
         img_size = (img_width, img_height, 1)
 
         key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
-        if _bin_cache["key"] == key:
+        # With 16x16 tiles the lists leave out the (Gaussian, tile) pairs that cannot
+        # reach alpha >= 1/255 anywhere in the tile (about half of the reference's
+        # bounding-box pairs; the compositing rule skips them pixel by pixel, so
+        # images and gradients are unchanged).  Those lists also depend on
+        # conics and opacity.
+        exact = block_width == 16
+        if _bin_cache["key"] == key and (not exact or _same_reach_inputs(conics, opacity)):
             num_intersects, gaussian_ids_sorted, tile_bins = _bin_cache["value"]
         else:
             # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
-            # compute_cumulative_intersects + bin_and_sort_gaussians, bit for bit
-            # (tests/test_gpu_kernels.py::test_fused_binning_equals_reference_pipeline)
-            order, cum_sorted = _C.depth_order(depths, radii, num_tiles_hit)
+            # compute_cumulative_intersects + bin_and_sort_gaussians (bit for bit
+            # when not `exact`: tests/test_gpu_kernels.py::
+            # test_fused_binning_equals_reference_pipeline)
+            tiles, records = num_tiles_hit, None
+            if exact:
+                tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds)
+            order, cum_sorted = _C.depth_order(depths, radii, tiles)
             num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
             gaussian_ids_sorted = tile_bins = None
             if num_intersects >= 1:
                 gaussian_ids_sorted, tile_bins = _C.bin_sorted(
-                    num_points, num_intersects, order, cum_sorted, xys, radii, tile_bounds, block_width
+                    num_points, num_intersects, order, cum_sorted, xys, radii, tile_bounds, block_width, records
                 )
             _bin_cache["key"] = key
             _bin_cache["value"] = (num_intersects, gaussian_ids_sorted, tile_bins)
             _bin_cache["keepalive"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
+            _bin_cache["reach"] = (conics.detach(), opacity.detach(), conics._version, opacity._version)
 
         if num_intersects < 1:
             # nothing on screen: background everywhere (rasterize.py:119-127)

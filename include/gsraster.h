@@ -131,7 +131,24 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  *   gsr_depth_order : order[n] = Gaussian indices by (depth, index), culled
  *                     first; cum_sorted[n] = inclusive scan of num_tiles_hit in
  *                     that order (cum_sorted[n-1] = number of intersections).
- *   gsr_bin_sorted  : gaussian_ids_sorted[I], tile_bins[T,2]. */
+ *   gsr_bin_sorted  : gaussian_ids_sorted[I], tile_bins[T,2].
+ *
+ * Exact lists (optional, block_width 16 only).  The reference lists every tile
+ * of a splat's 3-sigma SQUARE (forward.cu:73-82); about half of those (splat,
+ * tile) pairs cannot reach alpha >= 1/255 at any pixel of the tile, and the
+ * compositing rule skips them pixel by pixel (forward.cu:349).  gsr_count_reach
+ * counts, per Gaussian, the tiles that can, and fills one opaque record of
+ * gsr_reach_record_bytes() bytes per Gaussian (16-byte aligned buffer).  Passing
+ * the counts to gsr_depth_order (in place of num_tiles_hit) and the records to
+ * gsr_bin_sorted builds the lists without the dead pairs: images and gradients
+ * are unchanged, `gaussian_ids_sorted` is a subsequence of the reference's.
+ * With reach_records == NULL gsr_bin_sorted reproduces the reference's lists
+ * bit for bit. */
+size_t gsr_reach_record_bytes(void);
+int gsr_count_reach(int num_points, const float *xys, const int32_t *radii,
+                    const float *conics, const float *opacities, int tiles_x,
+                    int tiles_y, int32_t *counts, void *reach_records,
+                    gsr_stream_t stream);
 size_t gsr_depth_order_workspace_bytes(int num_points);
 int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
                     const int32_t *num_tiles_hit, int32_t *order,
@@ -140,10 +157,10 @@ int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
 size_t gsr_bin_sorted_workspace_bytes(int num_intersects);
 int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                    const int32_t *cum_sorted, const float *xys,
-                   const int32_t *radii, int tiles_x, int tiles_y,
-                   unsigned block_width, int32_t *gaussian_ids_sorted,
-                   int32_t *tile_bins, void *workspace, size_t workspace_bytes,
-                   gsr_stream_t stream);
+                   const int32_t *radii, const void *reach_records, int tiles_x,
+                   int tiles_y, unsigned block_width,
+                   int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                   void *workspace, size_t workspace_bytes, gsr_stream_t stream);
 
 /* ---- compositing ----------------------------------------------------------
  * replaces rasterize_forward_tensor (bindings.cu:269-328), kernel

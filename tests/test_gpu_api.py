@@ -348,3 +348,55 @@ def test_inria_named_facade_matches_the_three_ops():
     with pytest.raises(NotImplementedError):
         GaussianRasterizer(settings)(pb["means3d"], means2D, pb["opacities"], shs=pb["sh_coeffs"],
                                      cov3D_precomp=torch.zeros(2500, 6, device=DEV))
+
+
+def test_binning_cache_tracks_opacity_and_conics():
+    """The 16x16 lists depend on opacity / conics: an equal-valued fresh tensor
+    (the models' second `torch.sigmoid(opacities)`) reuses them, a changed one
+    rebuilds them."""
+    import rasterizer.cuda as C
+    from rasterizer import project_gaussians, rasterize_gaussians
+    from rasterizer import rasterize as R
+
+    cam = S.make_camera(160, 96)
+    sc = S.make_scene(2000, cam, sh_degree=0, seed=5, scale_lo=0.01, scale_hi=0.1)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
+        cu(sc["means3d"]), cu(sc["scales"]), 1.0, cu(sc["quats"]), ct.viewmat[:3], ct.projmat, cam.fx, cam.fy,
+        cam.cx, cam.cy, cam.height, cam.width, 16)
+    colors = torch.rand(2000, 3, device=DEV)
+    opac = cu(sc["opacities"])
+    R._bin_cache["key"] = None
+    calls = {"n": 0}
+    orig = C.bin_sorted
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    C.bin_sorted = counting
+    try:
+        a = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac, cam.height, cam.width, 16)
+        b = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac.clone(), cam.height, cam.width, 16)
+        assert calls["n"] == 1 and torch.equal(a, b)
+        faint = opac * 0.01
+        c = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, faint, cam.height, cam.width, 16)
+        assert calls["n"] == 2
+        opac.mul_(0.01)  # in place: same storage, new version
+        rasterize_gaussians(xys, depths, radii, conics, tiles, colors, faint, cam.height, cam.width, 16)
+        assert calls["n"] == 2
+        d = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac, cam.height, cam.width, 16)
+        assert torch.equal(c, d)
+    finally:
+        C.bin_sorted = orig
+    # against the oracle with the reference's full lists
+    n = 2000
+    xn, dn, rn, cn, tn = (t.cpu().numpy() for t in (xys, depths, radii, conics, tiles))
+    I, cum = O.compute_cumulative_intersects(tn)
+    tb = ((cam.width + 15) // 16, (cam.height + 15) // 16, 1)
+    _, _, _, vs, bins = O.bin_and_sort_gaussians(n, I, xn, dn, rn, cum, tb, 16)
+    img, _, _, amb = O.rasterize_forward(tb, (16, 16, 1), (cam.width, cam.height, 1), vs, bins, xn, cn,
+                                         colors.cpu().numpy(), faint.cpu().numpy(), np.ones(3, np.float32),
+                                         ambig_eps=1e-5)
+    ok = ~amb.astype(bool)
+    assert np.abs(c.cpu().numpy() - img)[ok].max() < 1e-4

@@ -397,3 +397,99 @@ def test_depth_order_sort_is_exact_and_stable(n, dist):
     ref = np.argsort(key.view(np.uint32), kind="stable")
     assert np.array_equal(npy(order), ref.astype(np.int32))
     assert np.array_equal(npy(cum), np.cumsum(tiles[ref]).astype(np.int32))
+
+
+@pytest.mark.parametrize("n,W,H,ck,opac_hi", [(3000, 160, 96, {}, 1.0), (20_000, 317, 203, {"yaw": 0.3}, 1.0),
+                                             (5000, 256, 256, {}, 0.02), (200_000, 640, 360, {}, 1.0)])
+def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
+    """count_reach + bin_sorted(conics, opacities): per tile, the list is a
+    subsequence of the reference's; every dropped (Gaussian, tile) pair has
+    alpha < 1/255 at every pixel of the tile; the image composited from the short
+    lists is bit-identical, gradients equal up to atomic summation order."""
+    import rasterizer.cuda as C
+
+    bw = 16
+    cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2)
+    rng = np.random.default_rng(n)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    opac = (sc["opacities"] * opac_hi).astype(np.float32)
+    if opac_hi < 1.0:
+        opac[::7] = 0.0  # never visible
+    colors = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    g = dict(xys=cu(xys), depths=cu(depths), radii=cu(radii), conics=cu(conics), tiles=cu(tiles), opac=cu(opac),
+             colors=cu(colors))
+    # reference lists
+    order, cum = C.depth_order(g["depths"], g["radii"], g["tiles"])
+    I = int(cum[-1].item())
+    ids_ref, bins_ref = C.bin_sorted(n, I, order, cum, g["xys"], g["radii"], tb, bw)
+    # exact lists
+    cnt, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
+    assert (cnt <= g["tiles"]).all() and (cnt >= 0).all()
+    assert (cnt[g["radii"] <= 0] == 0).all()
+    order2, cum2 = C.depth_order(g["depths"], g["radii"], cnt)
+    assert torch.equal(order, order2)
+    I2 = int(cum2[-1].item())
+    assert 0 < I2 < I
+    ids_ex, bins_ex = C.bin_sorted(n, I2, order2, cum2, g["xys"], g["radii"], tb, bw, recs)
+    ids_ref_n, bins_ref_n, ids_ex_n, bins_ex_n = npy(ids_ref), npy(bins_ref), npy(ids_ex), npy(bins_ex)
+    assert np.array_equal(np.bincount(ids_ex_n, minlength=n), npy(cnt))
+    px = np.arange(bw, dtype=np.float32)
+    checked = 0
+    for t in range(tb[0] * tb[1]):
+        a = ids_ref_n[bins_ref_n[t, 0]:bins_ref_n[t, 1]]
+        b = ids_ex_n[bins_ex_n[t, 0]:bins_ex_n[t, 1]]
+        keep = np.isin(a, b)
+        assert np.array_equal(a[keep], b), f"tile {t}: not a subsequence"
+        if t % 7 and n > 50_000:
+            continue  # the per-pixel check below on a sample of the tiles
+        dropped = a[~keep]
+        if dropped.size == 0:
+            continue
+        X = (t % tb[0]) * bw + px[None, None, :]
+        Y = (t // tb[0]) * bw + px[None, :, None]
+        dx = xys[dropped, 0][:, None, None] - X
+        dy = xys[dropped, 1][:, None, None] - Y
+        cn = conics[dropped].astype(np.float64)
+        sigma = 0.5 * (cn[:, 0, None, None] * dx * dx + cn[:, 2, None, None] * dy * dy) + cn[:, 1, None, None] * dx * dy
+        alpha = np.minimum(0.999, opac[dropped, 0][:, None, None] * np.exp(-sigma))
+        assert (alpha[sigma >= 0] < 1.0 / 255.0).all(), f"tile {t}: a live pair was dropped"
+        checked += dropped.size
+    assert checked > 0
+    # compositing from either list
+    block, img_size = (bw, bw, 1), (W, H, 1)
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    img_r, T_r, idx_r = C.rasterize_forward(tb, block, img_size, ids_ref, bins_ref, g["xys"], g["conics"],
+                                            g["colors"], g["opac"], bg)
+    img_e, T_e, idx_e = C.rasterize_forward(tb, block, img_size, ids_ex, bins_ex, g["xys"], g["conics"],
+                                            g["colors"], g["opac"], bg)
+    assert torch.equal(img_r, img_e) and torch.equal(T_r, T_e)
+    v_img = cu(rng.standard_normal((H, W, 3)).astype(np.float32))
+    v_alpha = cu(rng.standard_normal((H, W)).astype(np.float32))
+    gr = C.rasterize_backward(H, W, bw, ids_ref, bins_ref, g["xys"], g["conics"], g["colors"], g["opac"], bg,
+                              T_r, idx_r, v_img, v_alpha)
+    ge = C.rasterize_backward(H, W, bw, ids_ex, bins_ex, g["xys"], g["conics"], g["colors"], g["opac"], bg,
+                              T_e, idx_e, v_img, v_alpha)
+    for a, b, nm in zip(gr, ge, ("v_xy", "v_conic", "v_colors", "v_opacity")):
+        a, b = npy(a), npy(b)
+        assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max() + 1e-12, nm
+
+
+def test_count_reach_errors():
+    import rasterizer.cuda as C
+
+    z = torch.zeros
+    with pytest.raises(RuntimeError):
+        C.count_reach(z(4, 2, device=DEV), z(4, dtype=torch.int32, device=DEV), z(4, 3, device=DEV),
+                      z(3, 1, device=DEV), (4, 4, 1))
+    with pytest.raises(RuntimeError):  # the reach test is defined on 16x16 tiles only
+        C.bin_sorted(4, 4, z(4, dtype=torch.int32, device=DEV), z(4, dtype=torch.int32, device=DEV),
+                     z(4, 2, device=DEV), z(4, dtype=torch.int32, device=DEV), (4, 4, 1), 8,
+                     z(4, 32, dtype=torch.uint8, device=DEV))
+    with pytest.raises(RuntimeError):  # wrong record buffer size
+        C.bin_sorted(4, 4, z(4, dtype=torch.int32, device=DEV), z(4, dtype=torch.int32, device=DEV),
+                     z(4, 2, device=DEV), z(4, dtype=torch.int32, device=DEV), (4, 4, 1), 16,
+                     z(3, 32, dtype=torch.uint8, device=DEV))
+    out, _ = C.count_reach(z(0, 2, device=DEV), z(0, dtype=torch.int32, device=DEV), z(0, 3, device=DEV),
+                        z(0, 1, device=DEV), (4, 4, 1))
+    assert out.numel() == 0
