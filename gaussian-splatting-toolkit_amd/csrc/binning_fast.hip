@@ -31,6 +31,12 @@ int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsig
                        int *vals_out, int key_bits, void *workspace, size_t workspace_bytes,
                        hipStream_t s);
 
+// tile_scatter.hip
+bool gsr_tile_scatter_supported(int num_tiles);
+size_t gsr_tile_scatter_workspace_bytes(int I, int num_tiles);
+int gsr_tile_scatter(int I, const unsigned *keys, const int *gids, int num_tiles, int *ids_sorted,
+                     int *tile_bins, int *total_out, void *workspace, size_t workspace_bytes, hipStream_t s);
+
 namespace {
 
 // the purpose-built sort wins between these sizes; rocPRIM elsewhere
@@ -349,10 +355,28 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
   return GSR_OK;
 }
 
+// How the depth-ordered stream is partitioned by tile:
+//   's' (default when the tile grid fits): single-pass counting sort, tile_scatter.hip
+//   'r': rocPRIM radix sort on the tile bits + edge detection
+//   'm': sort_mid.hip + edge detection
+// GSR_TILE_SORT=r|m|s overrides (A/B measurements).
+char tile_sort_mode(int num_tiles) {
+  static const char forced = [] {
+    const char *e = getenv("GSR_TILE_SORT");
+    return e ? e[0] : '\0';
+  }();
+  if (forced == 'r' || forced == 'm') return forced;
+  return gsr_tile_scatter_supported(num_tiles) ? 's' : 'r';
+}
+
+// upper bound over the tile grids the scatter path supports
+size_t tile_scatter_temp(int I) { return gsr_tile_scatter_workspace_bytes(I, 16384); }
+
 GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects) {
   if (num_intersects <= 0) return 0;
   return 3 * align_up(4 * (size_t)num_intersects) +
-         align_up(std::max(tile_sort_temp(num_intersects), gsr_sort_mid_workspace_bytes(num_intersects)));
+         align_up(std::max({tile_sort_temp(num_intersects), gsr_sort_mid_workspace_bytes(num_intersects),
+                            tile_scatter_temp(num_intersects)}));
 }
 
 GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
@@ -368,9 +392,13 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
   GSR_REQUIRE(tiles_x <= 65535 && tiles_y <= 65535, "bin_sorted: tile grid too large");
   hipStream_t s = (hipStream_t)stream;
   const int num_tiles = tiles_x * tiles_y;
-  hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
-                     reinterpret_cast<int2 *>(tile_bins));
-  GSR_CHECK_LAUNCH("bin_sorted(clear)");
+  const char mode = tile_sort_mode(num_tiles);
+  const bool nothing = num_points == 0 || num_intersects == 0;
+  if (nothing || mode != 's') {  // the scatter path writes every entry of tile_bins itself
+    hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
+                       reinterpret_cast<int2 *>(tile_bins));
+    GSR_CHECK_LAUNCH("bin_sorted(clear)");
+  }
   if (num_points == 0 || num_intersects == 0) return GSR_OK;
   GSR_REQUIRE(order && cum_sorted && xys && radii && gaussian_ids_sorted && workspace, "bin_sorted: null pointer");
   const size_t need = gsr_bin_sorted_workspace_bytes(num_intersects);
@@ -391,11 +419,10 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
                      const_cast<SplatRec *>(static_cast<const SplatRec *>(reach_records)), tile_in, ids_in,
                      (int *)nullptr);
   GSR_CHECK_LAUNCH("bin_sorted(emit)");
-  static const bool mid_tile_sort = [] {
-    const char *e = getenv("GSR_TILE_SORT");
-    return e && e[0] == 'm';
-  }();
-  if (mid_tile_sort) {
+  if (mode == 's')
+    return gsr_tile_scatter(num_intersects, tile_in, ids_in, num_tiles, gaussian_ids_sorted, tile_bins, nullptr,
+                            temp, temp_bytes, s);
+  if (mode == 'm') {
     int rc = gsr_sort_mid_pairs(num_intersects, tile_in, ids_in, tile_out, gaussian_ids_sorted,
                                 (int)tile_bits(num_tiles), temp, temp_bytes, s);
     if (rc != GSR_OK) return rc;

@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     const float hy = P[4] * px + P[5] * py + P[6] * pz + P[7];
     const float hw = P[12] * px + P[13] * py + P[14] * pz + P[15];
     const float rw = 1.f / (hw + 1e-6f);
-    const float vnx = 0.5f * (float)img_w * v_xy[2 * i];
-    const float vny = 0.5f * (float)img_h * v_xy[2 * i + 1];
+    const float vnx = v_xy ? 0.5f * (float)img_w * v_xy[2 * i] : 0.f;
+    const float vny = v_xy ? 0.5f * (float)img_h * v_xy[2 * i + 1] : 0.f;
     const float vt0 = vnx * rw, vt1 = vny * rw;
     const float vt3 = -(vnx * hx + vny * hy) * rw * rw;
     gm[0] = P[0] * vt0 + P[4] * vt1 + P[12] * vt3;
@@ -195,14 +195,15 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     gm[2] = P[2] * vt0 + P[6] * vt1 + P[14] * vt3;
 
     // depth = V[2,:] . p
-    const float vz = v_depth[i];
+    const float vz = v_depth ? v_depth[i] : 0.f;
     gm[0] += V[8] * vz;
     gm[1] += V[9] * vz;
     gm[2] += V[10] * vz;
 
     // conic = inv(cov2d)  ->  v_cov2d = -X G X  (helpers.cuh:62-74)
     const float X00 = conics[3 * i], X01 = conics[3 * i + 1], X11 = conics[3 * i + 2];
-    const float G00 = v_conic[3 * i], G01 = 0.5f * v_conic[3 * i + 1], G11 = v_conic[3 * i + 2];
+    const float G00 = v_conic ? v_conic[3 * i] : 0.f, G01 = v_conic ? 0.5f * v_conic[3 * i + 1] : 0.f,
+                G11 = v_conic ? v_conic[3 * i + 2] : 0.f;
     const float A00 = X00 * G00 + X01 * G01, A01 = X00 * G01 + X01 * G11;
     const float A10 = X01 * G00 + X11 * G01, A11 = X01 * G01 + X11 * G11;
     g2[0] = -(A00 * X00 + A01 * X01);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
       const float comp = compensation[i];
       const float inv_det = X00 * X11 - X01 * X01;
       const float om2 = 1.f - comp * comp;
-      const float vsq = v_compensation[i] * 0.5f / (comp + 1e-6f);
+      const float vsq = (v_compensation ? v_compensation[i] : 0.f) * 0.5f / (comp + 1e-6f);
       g2[0] += vsq * (om2 * X00 - 0.3f * inv_det);
       g2[1] += 2.f * vsq * (om2 * X01);
       g2[2] += vsq * (om2 * X11 - 0.3f * inv_det);
@@ -348,7 +349,7 @@ GSR_EXPORT int gsr_project_backward(
   GSR_REQUIRE(num_points >= 0, "project_backward: num_points < 0");
   if (num_points == 0) return GSR_OK;
   GSR_REQUIRE(means3d && scales && quats && viewmat && projmat && cov3d && radii && conics &&
-                  compensation && v_xy && v_depth && v_conic && v_compensation && v_cov2d &&
+                  compensation && v_cov2d &&
                   v_cov3d && v_mean3d && v_scale && v_quat,
               "project_backward: null pointer");
   hipLaunchKernelGGL(project_bwd_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0,

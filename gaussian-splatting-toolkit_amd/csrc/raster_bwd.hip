@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
       vg[p] = v_output[3 * pid + 1];
       vb[p] = v_output[3 * pid + 2];
       // T_final*ra*v_out_alpha - T_final*ra*(bg . v_out) = ra * K
-      K[p] = Tf * (v_output_alpha[pid] - (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p]));
+      K[p] = Tf * ((v_output_alpha ? v_output_alpha[pid] : 0.f) - (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p]));
       binf[p] = final_idx[pid];
     }
   }
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void raster_bwd_generic_kernel(
   if (inside) {
     const size_t pid = (size_t)row * img_w + col;
     T_final = final_Ts[pid];
-    vout_alpha = v_output_alpha[pid];
+    vout_alpha = v_output_alpha ? v_output_alpha[pid] : 0.f;
     bin_final = final_idx[pid];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
@@ -479,7 +479,7 @@ GSR_EXPORT int gsr_rasterize_backward_nd(
   GSR_REQUIRE(num_points >= 0, "rasterize_backward: num_points < 0");
   if (num_points == 0) return GSR_OK;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
-                  background && final_Ts && final_idx && v_output && v_output_alpha && v_xy &&
+                  background && final_Ts && final_idx && v_output && v_xy &&
                   v_conic && v_colors && v_opacity,
               "rasterize_backward: null pointer");
   int rc = zero_grads(num_points, channels, v_xy, v_conic, v_colors, v_opacity, (hipStream_t)stream);
@@ -505,7 +505,7 @@ GSR_EXPORT int gsr_rasterize_backward(
   GSR_REQUIRE(num_points >= 0, "rasterize_backward: num_points < 0");
   if (num_points == 0) return GSR_OK;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
-                  background && final_Ts && final_idx && v_output && v_output_alpha && v_xy &&
+                  background && final_Ts && final_idx && v_output && v_xy &&
                   v_conic && v_colors && v_opacity,
               "rasterize_backward: null pointer");
   hipStream_t s = (hipStream_t)stream;

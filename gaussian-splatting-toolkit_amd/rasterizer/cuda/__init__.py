@@ -104,12 +104,13 @@ def project_gaussians_backward(
                   (compensation, "compensation")):
         _check(t, nm, _f32)
     _check(radii, "radii", _i32)
-    # cotangents may arrive non-contiguous / expanded from autograd
+    # cotangents may arrive non-contiguous / expanded from autograd; None = zero
     v_xy, v_depth, v_conic, v_compensation = (
-        _check(t.contiguous(), nm, _f32)
+        None if t is None else _check(t.contiguous(), nm, _f32)
         for t, nm in ((v_xy, "v_xy"), (v_depth, "v_depth"), (v_conic, "v_conic"),
                       (v_compensation, "v_compensation"))
     )
+    _opt = lambda t: None if t is None else _ptr(t)
     with torch.cuda.device(dev):
         v_cov2d = torch.empty((n, 3), dtype=_f32, device=dev)
         v_cov3d = torch.empty((n, 6), dtype=_f32, device=dev)
@@ -120,7 +121,7 @@ def project_gaussians_backward(
             "gsr_project_backward", C.c_int(n), _ptr(means3d), _ptr(scales), _cf(glob_scale),
             _ptr(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
             C.c_uint(img_height), C.c_uint(img_width), _ptr(cov3d), _ptr(radii), _ptr(conics),
-            _ptr(compensation), _ptr(v_xy), _ptr(v_depth), _ptr(v_conic), _ptr(v_compensation),
+            _ptr(compensation), _opt(v_xy), _opt(v_depth), _opt(v_conic), _opt(v_compensation),
             _ptr(v_cov2d), _ptr(v_cov3d), _ptr(v_mean3d), _ptr(v_scale), _ptr(v_quat),
             _stream(dev),
         )
@@ -366,7 +367,8 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
     _check(final_Ts, "final_Ts", _f32)
     _check(final_idx, "final_idx", _i32)
     v_output = _check(v_output.contiguous(), "v_output", _f32)
-    v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
+    if v_output_alpha is not None:  # None = zero cotangent for the alpha output
+        v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
     n, channels = xys.size(0), colors.size(1)
     dev = xys.device
     with torch.cuda.device(dev):
@@ -380,7 +382,7 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
         head = (C.c_uint(img_height), C.c_uint(img_width), C.c_uint(block_width))
         tail = (C.c_int(n), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics),
                 _ptr(colors), _ptr(opacities), _ptr(background), _ptr(final_Ts), _ptr(final_idx),
-                _ptr(v_output), _ptr(v_output_alpha), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
+                _ptr(v_output), _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
                 _ptr(v_opacity), _stream(dev))
         if nd:
             _call("gsr_rasterize_backward_nd", *head, C.c_uint(channels), *tail)

@@ -68,6 +68,10 @@ class _ProjectGaussians(Function):
         )
 
         ctx.scalars = (num_points, glob_scale, fx, fy, cx, cy, img_height, img_width)
+        # unused outputs (depths, compensation, cov3d in the RGB pass) arrive as None
+        # in backward instead of N-sized zero tensors; the kernel reads None as zero
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii, num_tiles_hit)
         ctx.save_for_backward(means3d, scales, quats, viewmat, projmat, cov3d, radii, conics,
                               compensation)
         return xys, depths, radii, conics, compensation, num_tiles_hit, cov3d

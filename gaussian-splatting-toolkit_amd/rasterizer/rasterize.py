@@ -155,6 +155,7 @@ class _RasterizeGaussians(Function):
                 opacity, background,
             )
 
+        ctx.set_materialize_grads(False)
         ctx.img_width = img_width
         ctx.img_height = img_height
         ctx.num_intersects = num_intersects
@@ -171,8 +172,10 @@ class _RasterizeGaussians(Function):
         (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
          final_idx) = ctx.saved_tensors
 
-        if v_out_alpha is None:
-            v_out_alpha = torch.zeros_like(v_out_img[..., 0])
+        # v_out_alpha stays None when the alpha output was not requested / not used:
+        # the kernels read a missing cotangent as zero (no H x W zero tensor)
+        if v_out_img is None:  # only the alpha output was used
+            v_out_img = torch.zeros(ctx.img_height, ctx.img_width, colors.shape[-1], device=xys.device)
 
         if ctx.num_intersects < 1:
             v_xy = torch.zeros_like(xys)

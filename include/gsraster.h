@@ -65,7 +65,8 @@ int gsr_project_forward(int num_points, const float *means3d,
 
 /* replaces project_gaussians_backward_tensor (bindings.cu:164-216), kernel
  * backward.cu:305-347.  outputs: v_cov2d[n,3] v_cov3d[n,6] v_mean3d[n,3]
- * v_scale[n,3] v_quat[n,4] */
+ * v_scale[n,3] v_quat[n,4].  Each of the cotangents v_xy, v_depth, v_conic,
+ * v_compensation may be NULL (= all zeros). */
 int gsr_project_backward(int num_points, const float *means3d,
                          const float *scales, float glob_scale,
                          const float *quats, const float *viewmat,
@@ -177,7 +178,8 @@ int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_width,
 
 /* replaces rasterize_backward_tensor (bindings.cu:476-528), kernel
  * backward.cu:133-303.  v_xy[n,2] v_conic[n,3] v_colors[n,3] v_opacity[n]
- * are zero-filled by the call, then accumulated with fp32 atomics. */
+ * are zero-filled by the call, then accumulated with fp32 atomics.
+ * v_output_alpha may be NULL (= all zeros), here and in the _nd variant. */
 int gsr_rasterize_backward(unsigned img_height, unsigned img_width,
                            unsigned block_width, int num_points,
                            const int32_t *gaussian_ids_sorted,
