@@ -43,6 +43,7 @@ KERNELS = (
     # rasterizer.cuda attribute, key in the algorithmic-bytes table
     ("project_gaussians_forward", "project_fwd"),
     ("compute_sh_forward", "sh_fwd"),
+    ("count_reach", "count_reach"),
     ("depth_order", "depth_order"),
     ("bin_sorted", "bin_sorted"),
     ("rasterize_forward", "raster_fwd"),

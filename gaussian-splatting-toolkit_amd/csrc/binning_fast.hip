@@ -34,8 +34,9 @@ int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsig
 // tile_scatter.hip
 bool gsr_tile_scatter_supported(int num_tiles);
 size_t gsr_tile_scatter_workspace_bytes(int I, int num_tiles);
-int gsr_tile_scatter(int I, const unsigned *keys, const int *gids, int num_tiles, int *ids_sorted,
-                     int *tile_bins, int *total_out, void *workspace, size_t workspace_bytes, hipStream_t s);
+int gsr_tile_scatter(int I, const int *I_dev, const unsigned *keys, const int *gids, int num_tiles,
+                     int *ids_sorted, int *tile_bins, int *total_out, void *workspace, size_t workspace_bytes,
+                     hipStream_t s);
 
 namespace {
 
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(
     const float *__restrict__ xys, const int *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, const int tiles_x, const int tiles_y, const int bw,
     SplatRec *__restrict__ recs, unsigned *__restrict__ tile_keys, int *__restrict__ gaussian_ids,
-    int *__restrict__ counts) {
+    int *__restrict__ counts, const int capacity) {
   __shared__ int s_pref[4][64];
   __shared__ int s_cnt[4][64];
   __shared__ int s_gid[4][64];
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(
       int pos = out + sc - cnt;
       const unsigned key0 = (unsigned)(ty * tiles_x);
       const int gid = s_gid[w][k];
-      for (int tx = t0; tx < t1; ++tx, ++pos) {
+      for (int tx = t0; tx < t1 && pos < capacity; ++tx, ++pos) {
         tile_keys[pos] = key0 + (unsigned)tx;
         gaussian_ids[pos] = gid;
       }
@@ -350,7 +351,7 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
   hipLaunchKernelGGL(tile_rows_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream, 0,
                      num_points, (const int *)nullptr, (const int *)nullptr, xys, radii, conics, opacities,
                      tiles_x, tiles_y, 16, static_cast<SplatRec *>(reach_records), (unsigned *)nullptr,
-                     (int *)nullptr, counts);
+                     (int *)nullptr, counts, 0);
   GSR_CHECK_LAUNCH("count_reach");
   return GSR_OK;
 }
@@ -379,11 +380,14 @@ GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects) {
                             tile_scatter_temp(num_intersects)}));
 }
 
-GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
-                              const int32_t *cum_sorted, const float *xys, const int32_t *radii,
-                              const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
-                              int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
-                              size_t workspace_bytes, gsr_stream_t stream) {
+namespace {
+// device_sized: the stream length is cum_sorted[num_points - 1] on the device and
+// `num_intersects` is the capacity the caller sized its buffers for
+int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const int32_t *order,
+                    const int32_t *cum_sorted, const float *xys, const int32_t *radii,
+                    const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
+                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
+                    size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0 && num_intersects >= 0, "bin_sorted: negative size");
   GSR_REQUIRE(block_width >= 2 && block_width <= 16, "bin_sorted: block_width must be in [2,16]");
   GSR_REQUIRE(tiles_x > 0 && tiles_y > 0, "bin_sorted: empty tile grid");
@@ -393,6 +397,7 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
   hipStream_t s = (hipStream_t)stream;
   const int num_tiles = tiles_x * tiles_y;
   const char mode = tile_sort_mode(num_tiles);
+  GSR_REQUIRE(!device_sized || mode == 's', "bin_sorted_dev: needs the single-pass tile scatter (<= 16384 tiles)");
   const bool nothing = num_points == 0 || num_intersects == 0;
   if (nothing || mode != 's') {  // the scatter path writes every entry of tile_bins itself
     hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
@@ -417,11 +422,11 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
                      order, cum_sorted, xys, radii, (const float *)nullptr, (const float *)nullptr, tiles_x,
                      tiles_y, (int)block_width,
                      const_cast<SplatRec *>(static_cast<const SplatRec *>(reach_records)), tile_in, ids_in,
-                     (int *)nullptr);
+                     (int *)nullptr, num_intersects);
   GSR_CHECK_LAUNCH("bin_sorted(emit)");
   if (mode == 's')
-    return gsr_tile_scatter(num_intersects, tile_in, ids_in, num_tiles, gaussian_ids_sorted, tile_bins, nullptr,
-                            temp, temp_bytes, s);
+    return gsr_tile_scatter(num_intersects, device_sized ? cum_sorted + (num_points - 1) : nullptr, tile_in,
+                            ids_in, num_tiles, gaussian_ids_sorted, tile_bins, nullptr, temp, temp_bytes, s);
   if (mode == 'm') {
     int rc = gsr_sort_mid_pairs(num_intersects, tile_in, ids_in, tile_out, gaussian_ids_sorted,
                                 (int)tile_bits(num_tiles), temp, temp_bytes, s);
@@ -436,3 +441,24 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
   GSR_CHECK_LAUNCH("bin_sorted(edges)");
   return GSR_OK;
 }
+}  // namespace
+
+GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
+                              const int32_t *cum_sorted, const float *xys, const int32_t *radii,
+                              const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
+                              int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
+                              size_t workspace_bytes, gsr_stream_t stream) {
+  return bin_sorted_impl(false, num_points, num_intersects, order, cum_sorted, xys, radii, reach_records, tiles_x,
+                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, workspace, workspace_bytes, stream);
+}
+
+GSR_EXPORT int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
+                                  const int32_t *cum_sorted, const float *xys, const int32_t *radii,
+                                  const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
+                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
+                                  size_t workspace_bytes, gsr_stream_t stream) {
+  GSR_REQUIRE(capacity > 0 && num_points > 0, "bin_sorted_dev: capacity and num_points must be positive");
+  return bin_sorted_impl(true, num_points, capacity, order, cum_sorted, xys, radii, reach_records, tiles_x,
+                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, workspace, workspace_bytes, stream);
+}
+

@@ -58,10 +58,20 @@ inline Plan make_plan(int I) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void hist_kernel(const int I, const int chunk, const int T,
+// `I_dev` (nullable): the stream length lives on the device; `I` is then the
+// capacity the buffers were sized for and the stream is cut there.
+__device__ __forceinline__ int stream_length(const int I, const int *I_dev) {
+  if (!I_dev) return I;
+  const int v = *I_dev;
+  return v < I ? v : I;
+}
+
+__global__ __launch_bounds__(256) void hist_kernel(const int I_cap, const int *__restrict__ I_dev,
+                                                   const int chunk, const int T,
                                                    const unsigned *__restrict__ keys,
                                                    unsigned *__restrict__ table) {
   extern __shared__ unsigned h[];
+  const int I = stream_length(I_cap, I_dev);
   const int tid = threadIdx.x, c = blockIdx.x;
   for (int t = tid; t < T; t += 256) h[t] = 0;
   __syncthreads();
@@ -164,7 +174,8 @@ __global__ __launch_bounds__(1024) void bases_kernel(const int T, unsigned *__re
 constexpr int kUnroll = 8;
 
 // T is a multiple of 4 here (padded row stride): the rows are staged with 16-byte loads.
-__global__ __launch_bounds__(256) void scatter_kernel(const int I, const int chunk, const int T,
+__global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const int *__restrict__ I_dev,
+                                                      const int chunk, const int T,
                                                      const int chunks_per_group,
                                                      const unsigned *__restrict__ keys,
                                                      const int *__restrict__ gids,
@@ -178,6 +189,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I, const int chu
   // the slots one tile's list receives from consecutive chunks are adjacent, so
   // each XCD fills its own ~1/8 of every list and its 4-byte writes merge into
   // full lines in that XCD's L2 instead of leaving 8 partially written copies.
+  const int I = stream_length(I_cap, I_dev);
   const int per_xcd = (int)gridDim.x >> 3;
   const int c = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (c >= chunks) return;
@@ -213,7 +225,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I, const int chu
   // loaded before the current one is placed.  The loop body is straight-line
   // (unconditional loads and stores) so that the wait for the prefetched batch is
   // `vmcnt(kUnroll)` -- it must not wait for the scattered stores issued after it.
-  const int nfull = (end - (int)beg) / (kUnroll * 64);
+  const int nfull = end > (int)beg ? (end - (int)beg) / (kUnroll * 64) : 0;
   unsigned nkey[kUnroll];
   int ngid[kUnroll];
   if (nfull > 0 && threadIdx.x < 64) {
@@ -279,9 +291,11 @@ size_t gsr_tile_scatter_workspace_bytes(int I, int num_tiles) {
 
 // keys[I] (tile ids < num_tiles) / gids[I] in stream order -> ids_sorted[I] stably
 // ordered by tile, tile_bins[num_tiles][2].  total_out (device int, may be null)
-// receives I.
-int gsr_tile_scatter(int I, const unsigned *keys, const int *gids, int num_tiles, int *ids_sorted,
-                     int *tile_bins, int *total_out, void *workspace, size_t workspace_bytes, hipStream_t s) {
+// receives I.  With I_dev (device int) the stream length is min(*I_dev, I): the
+// caller sized the buffers for I without knowing the length on the host.
+int gsr_tile_scatter(int I, const int *I_dev, const unsigned *keys, const int *gids, int num_tiles,
+                     int *ids_sorted, int *tile_bins, int *total_out, void *workspace, size_t workspace_bytes,
+                     hipStream_t s) {
   using namespace gsr_ts;
   if (!gsr_tile_scatter_supported(num_tiles)) {
     gsr_set_error("tile_scatter: %d tiles > %d", num_tiles, kMaxTiles);
@@ -300,14 +314,14 @@ int gsr_tile_scatter(int I, const unsigned *keys, const int *gids, int num_tiles
   unsigned *totals = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(gsum) +
                                                   align_up(4 * (size_t)p.groups * num_tiles));
   const size_t lds = 4 * (size_t)num_tiles;
-  hipLaunchKernelGGL(hist_kernel, dim3(p.chunks), dim3(256), lds, s, I, p.chunk, num_tiles, keys, table);
+  hipLaunchKernelGGL(hist_kernel, dim3(p.chunks), dim3(256), lds, s, I, I_dev, p.chunk, num_tiles, keys, table);
   hipLaunchKernelGGL(colscan_kernel, dim3(gsr_cdiv(num_tiles, 256), p.groups), dim3(256), 0, s, num_tiles,
                      p.chunks, p.chunks_per_group, table, gsum);
   hipLaunchKernelGGL(group_scan_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles, p.groups,
                      gsum, totals);
   hipLaunchKernelGGL(bases_kernel, dim3(1), dim3(1024), 0, s, real_tiles, totals, tile_bins, total_out);
-  hipLaunchKernelGGL(scatter_kernel, dim3(8 * gsr_cdiv(p.chunks, 8)), dim3(256), lds, s, I, p.chunk, num_tiles,
-                     p.chunks_per_group, keys, gids, (const unsigned *)table, (const unsigned *)gsum,
+  hipLaunchKernelGGL(scatter_kernel, dim3(8 * gsr_cdiv(p.chunks, 8)), dim3(256), lds, s, I, I_dev, p.chunk,
+                     num_tiles, p.chunks_per_group, keys, gids, (const unsigned *)table, (const unsigned *)gsum,
                      (const unsigned *)totals, p.chunks, ids_sorted);
   GSR_CHECK_LAUNCH("tile_scatter");
   return GSR_OK;

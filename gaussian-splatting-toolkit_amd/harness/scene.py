@@ -134,5 +134,8 @@ def algorithmic_bytes(n: int, num_intersects: int, pixels: int, tiles: int, sh_b
     # ... and grouped the way the fused pipeline launches it (same formula)
     per["depth_order"] = per["scan"]
     per["bin_sorted"] = per["map"] + per["sort"] + per["bin_edges"]
-    per["total"] = sum(v for k, v in per.items() if k not in ("depth_order", "bin_sorted"))
+    # not in SURVEY's formula (the reference has no such pass): reads xys, radii, conics,
+    # opacity (28 B), writes a count and a 32-byte record per Gaussian
+    per["count_reach"] = 64 * N
+    per["total"] = sum(v for k, v in per.items() if k not in ("depth_order", "bin_sorted", "count_reach"))
     return per

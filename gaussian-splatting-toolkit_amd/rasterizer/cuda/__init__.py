@@ -274,13 +274,20 @@ def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
     return counts, recs
 
 
+MAX_SCATTER_TILES = 16384  # tile grids the device-sized path supports (tile_scatter.hip)
+
+
 def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Tensor, xys: Tensor,
                radii: Tensor, tile_bounds: Tuple[int, int, int], block_width: int,
-               reach_records: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+               reach_records: Optional[Tensor] = None, device_sized: bool = False) -> Tuple[Tensor, Tensor]:
     """Second half (``gsr_bin_sorted``): -> (gaussian_ids_sorted i32[I],
     tile_bins i32[T,2]), identical to what ``bin_and_sort_gaussians`` returns.
     With the records (and counts) of :func:`count_reach`: the same lists without
-    the pairs that cannot reach alpha >= 1/255 anywhere in their tile."""
+    the pairs that cannot reach alpha >= 1/255 anywhere in their tile.
+    ``device_sized``: ``num_intersects`` is only a capacity; the length is read on
+    the device from ``cum_sorted[-1]`` and the lists are cut at the capacity
+    (``gsr_bin_sorted_dev``) -- the caller checks ``cum_sorted[-1] <= capacity``
+    later, off the critical path."""
     _check(order, "order", _i32)
     _check(cum_sorted, "cum_sorted", _i32)
     _check(xys, "xys", _f32)
@@ -297,7 +304,8 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
         tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
         nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I)))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
-        _call("gsr_bin_sorted", C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted),
+        _call("gsr_bin_sorted_dev" if device_sized else "gsr_bin_sorted", C.c_int(int(num_points)), C.c_int(I),
+              _ptr(order), _ptr(cum_sorted),
               _ptr(xys), _ptr(radii), _ptr(reach_records) if reach_records is not None else None,
               C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(block_width), _ptr(ids),
               _ptr(tile_bins), _ptr(ws), C.c_size_t(nbytes), _stream(dev))

@@ -34,6 +34,7 @@ SYMBOLS = (
     "gsr_depth_order",
     "gsr_bin_sorted_workspace_bytes",
     "gsr_bin_sorted",
+    "gsr_bin_sorted_dev",
     "gsr_rasterize_forward",
     "gsr_rasterize_backward",
     "gsr_rasterize_forward_nd",

@@ -15,6 +15,7 @@ It keeps detached aliases of them alive, so their storage cannot be recycled
 for another tensor while the entry exists (an address match therefore means
 the same memory), and an in-place update bumps the version and misses.
 """
+import os
 from typing import Optional
 
 import torch
@@ -30,6 +31,56 @@ def _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, bloc
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (xys, depths, radii, num_tiles_hit)) + (
         img_height, img_width, block_width, xys.device,
     )
+
+
+# ---- sizing the lists without a host round trip ------------------------------
+# The reference reads the number of intersections back before it can allocate
+# (`cum_tiles_hit[-1].item()`, utils.py:124): the GPU idles for the round trip
+# (~50 us at 1080p, 4 % of a forward+backward).  From the second view on, the
+# lists are sized from the last count (+25 %), the kernels read the real count on
+# the device, and the host compares the two after compositing is already queued.
+# A guess that was too small costs one rebuild; the result never depends on it.
+_count_hint = {}
+_pinned_count = {}
+
+
+def _speculation_enabled() -> bool:
+    return os.environ.get("GSR_NO_SPECULATION", "0") in ("", "0") and \
+        os.environ.get("GSR_TILE_SORT", "s")[:1] not in ("r", "m")
+
+
+def _note_count(device, num_points, tile_bounds, num_intersects):
+    _count_hint[(device, tile_bounds)] = (num_points, num_intersects)
+
+
+def _speculative_capacity(device, num_points, tile_bounds):
+    hint = _count_hint.get((device, tile_bounds))
+    if hint is None or tile_bounds[0] * tile_bounds[1] > _C.MAX_SCATTER_TILES or not _speculation_enabled():
+        return None
+    n_last, count_last = hint
+    if n_last < 1 or count_last < 1:
+        return None
+    guess = count_last * (num_points / n_last)
+    cap = int(1.25 * guess) + 65536
+    return cap if cap < 2**31 - 1 else None
+
+
+class _PendingCount:
+    """`cum_sorted[-1]` on its way to the host (pinned buffer + event)."""
+
+    def __init__(self, cum_sorted):
+        dev = cum_sorted.device
+        buf = _pinned_count.get(dev)
+        if buf is None:
+            buf = _pinned_count[dev] = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.buf = buf
+        buf.copy_(cum_sorted[-1:], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(dev))
+
+    def resolve(self) -> int:
+        self.event.synchronize()
+        return int(self.buf[0])
 
 
 def _same_reach_inputs(conics, opacity) -> bool:
@@ -119,7 +170,9 @@ class _RasterizeGaussians(Function):
         # images and gradients are unchanged).  Those lists also depend on
         # conics and opacity.
         exact = block_width == 16
-        if _bin_cache["key"] == key and (not exact or _same_reach_inputs(conics, opacity)):
+        pending = None
+        cached = _bin_cache["key"] == key and (not exact or _same_reach_inputs(conics, opacity))
+        if cached:
             num_intersects, gaussian_ids_sorted, tile_bins = _bin_cache["value"]
         else:
             # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
@@ -130,12 +183,43 @@ class _RasterizeGaussians(Function):
             if exact:
                 tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds)
             order, cum_sorted = _C.depth_order(depths, radii, tiles)
-            num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
+            capacity = _speculative_capacity(xys.device, num_points, tile_bounds)
             gaussian_ids_sorted = tile_bins = None
-            if num_intersects >= 1:
+            if capacity is not None:
+                # size the lists from the previous view instead of waiting for the
+                # count to reach the host (utils.py:124); checked after compositing
+                # has been enqueued
+                pending = _PendingCount(cum_sorted)
+                num_intersects = None
+                gaussian_ids_sorted, tile_bins = _C.bin_sorted(
+                    num_points, capacity, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
+                    device_sized=True,
+                )
+            else:
+                num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
+                _note_count(xys.device, num_points, tile_bounds, num_intersects)
+                if num_intersects >= 1:
+                    gaussian_ids_sorted, tile_bins = _C.bin_sorted(
+                        num_points, num_intersects, order, cum_sorted, xys, radii, tile_bounds, block_width, records
+                    )
+
+        rasterize_fn = _C.rasterize_forward if colors.shape[-1] == 3 else _C.nd_rasterize_forward
+        if pending is not None:
+            out_img, final_Ts, final_idx = rasterize_fn(
+                tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                opacity, background,
+            )
+            num_intersects = pending.resolve()
+            _note_count(xys.device, num_points, tile_bounds, num_intersects)
+            if num_intersects > capacity:  # the guess was too small: build the lists again, composite again
                 gaussian_ids_sorted, tile_bins = _C.bin_sorted(
                     num_points, num_intersects, order, cum_sorted, xys, radii, tile_bounds, block_width, records
                 )
+                out_img, final_Ts, final_idx = rasterize_fn(
+                    tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                    opacity, background,
+                )
+        if not cached:
             _bin_cache["key"] = key
             _bin_cache["value"] = (num_intersects, gaussian_ids_sorted, tile_bins)
             _bin_cache["keepalive"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
@@ -148,8 +232,7 @@ class _RasterizeGaussians(Function):
             tile_bins = torch.zeros(0, 2, device=xys.device)
             final_Ts = torch.zeros(img_height, img_width, device=xys.device)
             final_idx = torch.zeros(img_height, img_width, device=xys.device)
-        else:
-            rasterize_fn = _C.rasterize_forward if colors.shape[-1] == 3 else _C.nd_rasterize_forward
+        elif pending is None:
             out_img, final_Ts, final_idx = rasterize_fn(
                 tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
                 opacity, background,

@@ -163,6 +163,23 @@ int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                    int32_t *gaussian_ids_sorted, int32_t *tile_bins,
                    void *workspace, size_t workspace_bytes, gsr_stream_t stream);
 
+/* gsr_bin_sorted without the host knowing the number of intersections: the
+ * length of the lists is read on the device (cum_sorted[num_points-1], as
+ * written by gsr_depth_order) and `capacity` is what gaussian_ids_sorted and the
+ * workspace (gsr_bin_sorted_workspace_bytes(capacity)) were sized for.  If the
+ * length exceeds the capacity the lists are cut there (memory-safe, results
+ * incomplete): the caller compares the two once the value has reached the host
+ * and repeats the call with a larger capacity.  This removes the host round
+ * trip of rasterizer/utils.py:124 (`cum_tiles_hit[-1].item()`) from the critical
+ * path.  Tile grids above 16384 tiles: GSR_EINVAL, use gsr_bin_sorted. */
+int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
+                       const int32_t *cum_sorted, const float *xys,
+                       const int32_t *radii, const void *reach_records,
+                       int tiles_x, int tiles_y, unsigned block_width,
+                       int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                       void *workspace, size_t workspace_bytes,
+                       gsr_stream_t stream);
+
 /* ---- compositing ----------------------------------------------------------
  * replaces rasterize_forward_tensor (bindings.cu:269-328), kernel
  * forward.cu:278-395 (3 channels, fp32).  out_img[H,W,3] final_Ts[H,W]

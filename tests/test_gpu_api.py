@@ -400,3 +400,60 @@ def test_binning_cache_tracks_opacity_and_conics():
                                          ambig_eps=1e-5)
     ok = ~amb.astype(bool)
     assert np.abs(c.cpu().numpy() - img)[ok].max() < 1e-4
+
+
+def test_speculative_list_sizing_never_changes_results():
+    """From the second view on the lists are sized from the previous count and the
+    real count is checked after compositing was enqueued (rasterize.py): a right
+    guess, a guess that is far too small (lists cut, then rebuilt) and the
+    synchronous path give identical images and gradients."""
+    import rasterizer.cuda as C
+    from rasterizer import project_gaussians, rasterize_gaussians
+    from rasterizer import rasterize as R
+
+    cam = S.make_camera(640, 360)
+    n = 30_000
+    sc = S.make_scene(n, cam, sh_degree=0, seed=9, scale_lo=0.01, scale_hi=0.1)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
+        cu(sc["means3d"]), cu(sc["scales"]), 1.0, cu(sc["quats"]), ct.viewmat[:3], ct.projmat, cam.fx, cam.fy,
+        cam.cx, cam.cy, cam.height, cam.width, 16)
+    colors = torch.rand(n, 3, device=DEV)
+    v = torch.randn(cam.height, cam.width, 3, device=DEV)
+    modes = []
+    orig = C.bin_sorted
+
+    def spy(*a, **k):
+        modes.append(bool(k.get("device_sized", False)))
+        return orig(*a, **k)
+
+    def run():
+        R._bin_cache["key"] = None
+        c = colors.clone().requires_grad_(True)
+        o = cu(sc["opacities"]).requires_grad_(True)
+        img = rasterize_gaussians(xys, depths, radii, conics, tiles, c, o, cam.height, cam.width, 16)
+        (img * v).sum().backward()
+        return img.detach(), c.grad, o.grad
+
+    C.bin_sorted = spy
+    try:
+        R._count_hint.clear()
+        ref = run()                      # no hint: synchronous
+        assert modes == [False]
+        key = (xys.device, ((cam.width + 15) // 16, (cam.height + 15) // 16, 1))
+        count = R._count_hint[key][1]
+        assert count > 150_000
+        modes.clear()
+        good = run()                     # sized from the previous view
+        assert modes == [True]
+        R._count_hint[key] = (n, 8)      # capacity 65546 < count: cut, then rebuilt
+        modes.clear()
+        small = run()
+        assert modes == [True, False]
+        assert R._count_hint[key] == (n, count)
+    finally:
+        C.bin_sorted = orig
+    for got in (good, small):
+        assert torch.equal(got[0], ref[0])
+        for a, b in zip(got[1:], ref[1:]):
+            assert (a - b).abs().max() <= 1e-5 * b.abs().max()
