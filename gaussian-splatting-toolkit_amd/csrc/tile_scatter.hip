@@ -133,42 +133,67 @@ __global__ __launch_bounds__(256) void group_scan_kernel(const int T, const int 
   totals[t] = run;
 }
 
-// one workgroup of 1024, 16 consecutive tiles per thread: totals[t] <- first slot
-// of tile t; tile_bins[t] = [first, last) or (0, 0) for an empty tile (what the
-// reference's zero-initialised tile_bins holds, bindings.cu:258); *total_out = I.
+// One workgroup of 1024 threads; thread i owns tiles i, i + 1024, ... (coalesced):
+// totals[t] <- first slot of tile t; tile_bins[t] = [first, last) or (0, 0) for an
+// empty tile (what the reference's zero-initialised tile_bins holds,
+// bindings.cu:258); *total_out = I.
 __global__ __launch_bounds__(1024) void bases_kernel(const int T, unsigned *__restrict__ totals,
                                                      int *__restrict__ tile_bins, int *__restrict__ total_out) {
-  constexpr int kPer = kMaxTiles / 1024;
-  __shared__ unsigned wsum[16];
+  constexpr int kPer = kMaxTiles / 1024;  // 16 batches of 1024 tiles
+  __shared__ unsigned wsum[kPer * 16];    // [batch][wave] sums, then their exclusive prefix
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  unsigned v[kPer], sum = 0;
+  unsigned v[kPer], incl[kPer];
 #pragma unroll
   for (int j = 0; j < kPer; ++j) {
-    const int t = tid * kPer + j;
+    const int t = j * 1024 + tid;
     v[j] = t < T ? totals[t] : 0u;
-    sum += v[j];
+    incl[j] = v[j];
   }
-  unsigned incl = sum;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const unsigned u = __shfl_up(incl, o);
-    if (lane >= o) incl += u;
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      const unsigned u = __shfl_up(incl[j], o);
+      if (lane >= o) incl[j] += u;
+    }
   }
-  if (lane == 63) wsum[w] = incl;
+  if (lane == 63) {
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) wsum[j * 16 + w] = incl[j];
+  }
   __syncthreads();
-  unsigned base = incl - sum;
-  for (int k = 0; k < w; ++k) base += wsum[k];
+  if (w == 0) {  // exclusive scan of the 256 (batch, wave) sums: 4 per lane
+    unsigned a[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = wsum[lane * 4 + k];
+      s += a[k];
+    }
+    unsigned p = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = __shfl_up(p, o);
+      if (lane >= o) p += u;
+    }
+    if (lane == 63 && total_out) *total_out = (int)p;
+    p -= s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      wsum[lane * 4 + k] = p;
+      p += a[k];
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < kPer; ++j) {
-    const int t = tid * kPer + j;
+    const int t = j * 1024 + tid;
     if (t < T) {
+      const unsigned base = wsum[j * 16 + w] + incl[j] - v[j];
       totals[t] = base;
       tile_bins[2 * t] = v[j] ? (int)base : 0;
       tile_bins[2 * t + 1] = v[j] ? (int)(base + v[j]) : 0;
     }
-    base += v[j];
   }
-  if (tid == 1023 && total_out) *total_out = (int)base;
 }
 
 constexpr int kUnroll = 8;
@@ -190,9 +215,13 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const int
   // each XCD fills its own ~1/8 of every list and its 4-byte writes merge into
   // full lines in that XCD's L2 instead of leaving 8 partially written copies.
   const int I = stream_length(I_cap, I_dev);
-  const int per_xcd = (int)gridDim.x >> 3;
-  const int c = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-  if (c >= chunks) return;
+  // (over the chunks the stream really fills: with a device-side length the grid is
+  // sized for the capacity and the tail chunks are empty)
+  const int used = (int)(((long long)I + chunk - 1) / chunk);
+  const int per_xcd = (used + 7) >> 3;
+  const int slot = (int)blockIdx.x >> 3;
+  const int c = ((int)blockIdx.x & 7) * per_xcd + slot;
+  if (slot >= per_xcd || c >= used) return;
   const unsigned *row = table + (size_t)c * T;
   const unsigned *grow = gsum + (size_t)(c / chunks_per_group) * T;
   const long long beg = (long long)c * chunk;
