@@ -35,7 +35,7 @@ int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsig
 bool gsr_tile_scatter_supported(int num_tiles);
 size_t gsr_tile_scatter_workspace_bytes(int I, int num_tiles);
 int gsr_tile_scatter(int I, const int *I_dev, const unsigned *keys, const int *gids, int num_tiles,
-                     int *ids_sorted, int *tile_bins, int *total_out, void *workspace, size_t workspace_bytes,
+                     int *ids_sorted, int *tile_bins, int *count_out, void *workspace, size_t workspace_bytes,
                      hipStream_t s);
 
 namespace {
@@ -386,7 +386,7 @@ namespace {
 int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const int32_t *order,
                     const int32_t *cum_sorted, const float *xys, const int32_t *radii,
                     const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
-                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
+                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *count_out, void *workspace,
                     size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0 && num_intersects >= 0, "bin_sorted: negative size");
   GSR_REQUIRE(block_width >= 2 && block_width <= 16, "bin_sorted: block_width must be in [2,16]");
@@ -426,7 +426,7 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   GSR_CHECK_LAUNCH("bin_sorted(emit)");
   if (mode == 's')
     return gsr_tile_scatter(num_intersects, device_sized ? cum_sorted + (num_points - 1) : nullptr, tile_in,
-                            ids_in, num_tiles, gaussian_ids_sorted, tile_bins, nullptr, temp, temp_bytes, s);
+                            ids_in, num_tiles, gaussian_ids_sorted, tile_bins, count_out, temp, temp_bytes, s);
   if (mode == 'm') {
     int rc = gsr_sort_mid_pairs(num_intersects, tile_in, ids_in, tile_out, gaussian_ids_sorted,
                                 (int)tile_bits(num_tiles), temp, temp_bytes, s);
@@ -449,16 +449,18 @@ GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t 
                               int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
                               size_t workspace_bytes, gsr_stream_t stream) {
   return bin_sorted_impl(false, num_points, num_intersects, order, cum_sorted, xys, radii, reach_records, tiles_x,
-                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, workspace, workspace_bytes, stream);
+                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, nullptr, workspace, workspace_bytes,
+                         stream);
 }
 
 GSR_EXPORT int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
                                   const int32_t *cum_sorted, const float *xys, const int32_t *radii,
                                   const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
-                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
-                                  size_t workspace_bytes, gsr_stream_t stream) {
+                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *count_out,
+                                  void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(capacity > 0 && num_points > 0, "bin_sorted_dev: capacity and num_points must be positive");
   return bin_sorted_impl(true, num_points, capacity, order, cum_sorted, xys, radii, reach_records, tiles_x,
-                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, workspace, workspace_bytes, stream);
+                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, count_out, workspace, workspace_bytes,
+                         stream);
 }
 

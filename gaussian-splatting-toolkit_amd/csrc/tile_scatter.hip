@@ -69,9 +69,11 @@ __device__ __forceinline__ int stream_length(const int I, const int *I_dev) {
 __global__ __launch_bounds__(256) void hist_kernel(const int I_cap, const int *__restrict__ I_dev,
                                                    const int chunk, const int T,
                                                    const unsigned *__restrict__ keys,
-                                                   unsigned *__restrict__ table) {
+                                                   unsigned *__restrict__ table, int *__restrict__ count_out) {
   extern __shared__ unsigned h[];
   const int I = stream_length(I_cap, I_dev);
+  // the uncut length, for the caller's capacity check (count_out may be mapped host memory)
+  if (count_out && blockIdx.x == 0 && threadIdx.x == 0) *count_out = I_dev ? *I_dev : I;
   const int tid = threadIdx.x, c = blockIdx.x;
   for (int t = tid; t < T; t += 256) h[t] = 0;
   __syncthreads();
@@ -319,11 +321,11 @@ size_t gsr_tile_scatter_workspace_bytes(int I, int num_tiles) {
 }
 
 // keys[I] (tile ids < num_tiles) / gids[I] in stream order -> ids_sorted[I] stably
-// ordered by tile, tile_bins[num_tiles][2].  total_out (device int, may be null)
-// receives I.  With I_dev (device int) the stream length is min(*I_dev, I): the
-// caller sized the buffers for I without knowing the length on the host.
+// ordered by tile, tile_bins[num_tiles][2].  With I_dev (device int) the stream length is min(*I_dev, I): the
+// caller sized the buffers for I without knowing the length on the host; count_out
+// (device-accessible int, may be null) then receives *I_dev, uncut.
 int gsr_tile_scatter(int I, const int *I_dev, const unsigned *keys, const int *gids, int num_tiles,
-                     int *ids_sorted, int *tile_bins, int *total_out, void *workspace, size_t workspace_bytes,
+                     int *ids_sorted, int *tile_bins, int *count_out, void *workspace, size_t workspace_bytes,
                      hipStream_t s) {
   using namespace gsr_ts;
   if (!gsr_tile_scatter_supported(num_tiles)) {
@@ -343,12 +345,13 @@ int gsr_tile_scatter(int I, const int *I_dev, const unsigned *keys, const int *g
   unsigned *totals = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(gsum) +
                                                   align_up(4 * (size_t)p.groups * num_tiles));
   const size_t lds = 4 * (size_t)num_tiles;
-  hipLaunchKernelGGL(hist_kernel, dim3(p.chunks), dim3(256), lds, s, I, I_dev, p.chunk, num_tiles, keys, table);
+  hipLaunchKernelGGL(hist_kernel, dim3(p.chunks), dim3(256), lds, s, I, I_dev, p.chunk, num_tiles, keys, table,
+                     count_out);
   hipLaunchKernelGGL(colscan_kernel, dim3(gsr_cdiv(num_tiles, 256), p.groups), dim3(256), 0, s, num_tiles,
                      p.chunks, p.chunks_per_group, table, gsum);
   hipLaunchKernelGGL(group_scan_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles, p.groups,
                      gsum, totals);
-  hipLaunchKernelGGL(bases_kernel, dim3(1), dim3(1024), 0, s, real_tiles, totals, tile_bins, total_out);
+  hipLaunchKernelGGL(bases_kernel, dim3(1), dim3(1024), 0, s, real_tiles, totals, tile_bins, (int *)nullptr);
   hipLaunchKernelGGL(scatter_kernel, dim3(8 * gsr_cdiv(p.chunks, 8)), dim3(256), lds, s, I, I_dev, p.chunk,
                      num_tiles, p.chunks_per_group, keys, gids, (const unsigned *)table, (const unsigned *)gsum,
                      (const unsigned *)totals, p.chunks, ids_sorted);

@@ -279,7 +279,8 @@ MAX_SCATTER_TILES = 16384  # tile grids the device-sized path supports (tile_sca
 
 def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Tensor, xys: Tensor,
                radii: Tensor, tile_bounds: Tuple[int, int, int], block_width: int,
-               reach_records: Optional[Tensor] = None, device_sized: bool = False) -> Tuple[Tensor, Tensor]:
+               reach_records: Optional[Tensor] = None, device_sized: bool = False,
+               count_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Second half (``gsr_bin_sorted``): -> (gaussian_ids_sorted i32[I],
     tile_bins i32[T,2]), identical to what ``bin_and_sort_gaussians`` returns.
     With the records (and counts) of :func:`count_reach`: the same lists without
@@ -287,7 +288,8 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     ``device_sized``: ``num_intersects`` is only a capacity; the length is read on
     the device from ``cum_sorted[-1]`` and the lists are cut at the capacity
     (``gsr_bin_sorted_dev``) -- the caller checks ``cum_sorted[-1] <= capacity``
-    later, off the critical path."""
+    later, off the critical path; ``count_out`` (int32[1], pinned host memory or
+    device) receives that count."""
     _check(order, "order", _i32)
     _check(cum_sorted, "cum_sorted", _i32)
     _check(xys, "xys", _f32)
@@ -304,11 +306,14 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
         tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
         nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I)))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
-        _call("gsr_bin_sorted_dev" if device_sized else "gsr_bin_sorted", C.c_int(int(num_points)), C.c_int(I),
-              _ptr(order), _ptr(cum_sorted),
-              _ptr(xys), _ptr(radii), _ptr(reach_records) if reach_records is not None else None,
-              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(block_width), _ptr(ids),
-              _ptr(tile_bins), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+        head = (C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted), _ptr(xys), _ptr(radii),
+                _ptr(reach_records) if reach_records is not None else None, C.c_int(tile_bounds[0]),
+                C.c_int(tile_bounds[1]), C.c_uint(block_width), _ptr(ids), _ptr(tile_bins))
+        tail = (_ptr(ws), C.c_size_t(nbytes), _stream(dev))
+        if device_sized:
+            _call("gsr_bin_sorted_dev", *head, _ptr(count_out) if count_out is not None else None, *tail)
+        else:
+            _call("gsr_bin_sorted", *head, *tail)
     return ids, tile_bins
 
 

@@ -66,17 +66,22 @@ def _speculative_capacity(device, num_points, tile_bounds):
 
 
 class _PendingCount:
-    """`cum_sorted[-1]` on its way to the host (pinned buffer + event)."""
+    """The real number of list entries on its way to the host: a kernel of
+    `gsr_bin_sorted_dev` writes it straight into pinned (device-mapped) host memory
+    -- no copy operation in the stream -- and `resolve` waits for the event recorded
+    behind that call."""
 
-    def __init__(self, cum_sorted):
-        dev = cum_sorted.device
-        buf = _pinned_count.get(dev)
+    def __init__(self, device):
+        buf = _pinned_count.get(device)
         if buf is None:
-            buf = _pinned_count[dev] = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            buf = _pinned_count[device] = torch.empty(1, dtype=torch.int32, pin_memory=True)
         self.buf = buf
-        buf.copy_(cum_sorted[-1:], non_blocking=True)
+        self.device = device
+        self.event = None
+
+    def mark(self):
         self.event = torch.cuda.Event()
-        self.event.record(torch.cuda.current_stream(dev))
+        self.event.record(torch.cuda.current_stream(self.device))
 
     def resolve(self) -> int:
         self.event.synchronize()
@@ -189,12 +194,13 @@ class _RasterizeGaussians(Function):
                 # size the lists from the previous view instead of waiting for the
                 # count to reach the host (utils.py:124); checked after compositing
                 # has been enqueued
-                pending = _PendingCount(cum_sorted)
+                pending = _PendingCount(xys.device)
                 num_intersects = None
                 gaussian_ids_sorted, tile_bins = _C.bin_sorted(
                     num_points, capacity, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
-                    device_sized=True,
+                    device_sized=True, count_out=pending.buf,
                 )
+                pending.mark()
             else:
                 num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
                 _note_count(xys.device, num_points, tile_bounds, num_intersects)

@@ -171,14 +171,17 @@ int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
  * incomplete): the caller compares the two once the value has reached the host
  * and repeats the call with a larger capacity.  This removes the host round
  * trip of rasterizer/utils.py:124 (`cum_tiles_hit[-1].item()`) from the critical
- * path.  Tile grids above 16384 tiles: GSR_EINVAL, use gsr_bin_sorted. */
+ * path.  count_out (nullable) receives the uncut length; it only has to be
+ * device-accessible, e.g. pinned host memory mapped into the device's address
+ * space, which spares the copy as well.  Tile grids above 16384 tiles:
+ * GSR_EINVAL, use gsr_bin_sorted. */
 int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
                        const int32_t *cum_sorted, const float *xys,
                        const int32_t *radii, const void *reach_records,
                        int tiles_x, int tiles_y, unsigned block_width,
                        int32_t *gaussian_ids_sorted, int32_t *tile_bins,
-                       void *workspace, size_t workspace_bytes,
-                       gsr_stream_t stream);
+                       int32_t *count_out, void *workspace,
+                       size_t workspace_bytes, gsr_stream_t stream);
 
 /* ---- compositing ----------------------------------------------------------
  * replaces rasterize_forward_tensor (bindings.cu:269-328), kernel
