@@ -85,6 +85,8 @@ struct Butterfly<8> {
   }
   static __device__ __forceinline__ bool owns_main(int) { return true; }
   static __device__ __forceinline__ bool owns_extra(int lane) { return (lane & 7) == 0; }
+  // component 0's holder receives component 1 of the same splat and vice versa
+  static __device__ __forceinline__ float swap01(float v) { return dpp<DPP_QUAD_XOR2>(v); }
   static __device__ __forceinline__ void run(float (&P)[72], int lane, float &main_v, float &extra_v) {
     float Q[36];
 #pragma unroll
@@ -119,6 +121,7 @@ struct Butterfly<4> {
   }
   static __device__ __forceinline__ bool owns_main(int lane) { return (lane & 2) == 0; }
   static __device__ __forceinline__ bool owns_extra(int lane) { return (lane & 15) == 0; }
+  static __device__ __forceinline__ float swap01(float v) { return dpp<DPP_QUAD_XOR1>(v); }
   static __device__ __forceinline__ void run(float (&P)[36], int lane, float &main_v, float &extra_v) {
     float Q[18];
 #pragma unroll
@@ -211,6 +214,10 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   const int dst_stride = comp < 2 ? 2 : 3;
   const int dst_off = comp < 2 ? comp : (comp < 5 ? comp - 2 : comp - 5);
   const bool owns_main = BF::owns_main(lane), owns_extra = BF::owns_extra(lane);
+  // lane-constant selectors of the moment -> gradient map for this lane's component
+  const float sel_ha = comp == 0 ? 1.f : 0.f, sel_hc = comp == 1 ? 1.f : 0.f, sel_b = comp < 2 ? 1.f : 0.f;
+  const float sel_no = (comp == 2 || comp == 4) ? 0.5f : (comp == 3 ? 1.f : 0.f);
+  const float sel_one = comp >= 5 ? 1.f : 0.f;
 
   for (int hi = top; hi >= range.x; hi -= kChunk) {
     // back to front: lane l fetches sorted index hi - l; kept splats stay in that order
@@ -227,15 +234,10 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
         const int t = t0 + j;
         float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f;
         float sr = 0.f, sg = 0.f, sb = 0.f;
-        float ha = 0.f, hc = 0.f, cb_ = 0.f, opac = 0.f;
         if (t < count) {  // wave-uniform
           const SplatA A = sA[t];
           const SplatB B = sB[t];
           const SplatC C = sC[t];
-          ha = A.ha;
-          hc = B.hc;
-          cb_ = A.b;
-          opac = B.opac;
           const float dx0 = A.x - fx0, dx1 = A.x - fx1;
           const float dy0 = A.y - fy0, dy1 = A.y - fy1;
           const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
@@ -279,13 +281,14 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             lane_any = lane_any || valid;
           }
         }
-        // v_sigma = -opac * w  ->  gradient components of this splat
-        const float a = 2.f * ha, c = 2.f * hc, nvs = -opac;
-        P[9 * j + 0] = nvs * (a * mx + cb_ * my);
-        P[9 * j + 1] = nvs * (cb_ * mx + c * my);
-        P[9 * j + 2] = nvs * 0.5f * mxx;
-        P[9 * j + 3] = nvs * mxy;
-        P[9 * j + 4] = nvs * 0.5f * myy;
+        // raw moments; they are turned into gradient components AFTER the wave-wide
+        // reduction (linear map: once per group by the owning lanes instead of once
+        // per splat by all 64)
+        P[9 * j + 0] = mx;
+        P[9 * j + 1] = my;
+        P[9 * j + 2] = mxx;
+        P[9 * j + 3] = mxy;
+        P[9 * j + 4] = myy;
         P[9 * j + 5] = sr;
         P[9 * j + 6] = sg;
         P[9 * j + 7] = sb;
@@ -295,11 +298,20 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
 
       float main_v, extra_v;
       BF::run(P, lane, main_v, extra_v);
+      // v_sigma = -opac * w:  v_xy = -opac (a Sx + b Sy, b Sx + c Sy),
+      // v_conic = -opac (Sxx/2, Sxy, Syy/2),  v_rgb = the colour sums,  v_opacity = S0
+      const float other = BF::swap01(main_v);
       const int t = t0 + BF::splat_of_lane(lane);
       if (t < count) {
+        const SplatA A = sA[t];
+        const SplatB B = sB[t];
+        const float no = -B.opac;
+        const float k1 = no * (2.f * (sel_ha * A.ha + sel_hc * B.hc) + sel_no) + sel_one;
+        const float k2 = no * sel_b * A.b;
+        const float grad = main_v * k1 + other * k2;
         const int g = sId[t];
-        if (owns_main && main_v != 0.f)
-          unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, main_v);
+        if (owns_main && grad != 0.f)
+          unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, grad);
         if (owns_extra && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
       }
     }
