@@ -94,18 +94,40 @@ __device__ __forceinline__ void sh_basis(unsigned deg, float dx, float dy, float
 //  like the reference's x / norm; with deg == 0 the masks multiply NaN by 0 ->
 //  guard: the degree-0 term never touches the direction)
 
-// ---- K == 16, 16-byte aligned coefficients: one lane per Gaussian ----------
-// Each lane streams its own 192 contiguous bytes with 12 dwordx4 accesses
-// (measured 4.5 TB/s forward, 2.2 TB/s backward (write-bound) on 3 M Gaussians).
+// ---- K == 16, 16-byte aligned coefficients ----------------------------------
+// One lane per Gaussian for the arithmetic, but the coefficients move as the
+// wave's 64 x 192 contiguous bytes in 12 fully coalesced 1-KB dwordx4 rows and are
+// transposed through LDS (per-Gaussian rows padded to 13 float4: 2-way bank
+// conflicts at most).  A lane streaming its own 192 bytes with 12 dwordx4 accesses
+// touches every 64-byte sector from four different instructions and, for the
+// backward's stores, writes four partial sectors: tools/exp/shbench.hip on 3 M
+// Gaussians (576 MB): forward 4.36 -> 5.18 TB/s, backward 2.2 -> 5.4 TB/s.
+constexpr int kShRow = 13;  // float4 per Gaussian row in LDS (12 + 1 padding)
+
 __global__ __launch_bounds__(256) void sh16_fwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
     const float4 *__restrict__ coeffs, float *__restrict__ colors) {
-  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  const float4 *c = coeffs + (size_t)g * 12;
+  __shared__ float4 lds[4][64 * kShRow];
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned g0 = (blockIdx.x * 4 + w) * 64;  // first Gaussian of this wave
+  const unsigned navail = g0 < n ? (n - g0 < 64 ? n - g0 : 64) * 12 : 0;
+  const float4 *src = coeffs + (size_t)g0 * 12;
   float4 q[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) q[i] = c[i];
+  for (int i = 0; i < 12; ++i) {
+    const unsigned j = i * 64 + lane;
+    q[i] = j < navail ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const unsigned j = i * 64 + lane;
+    lds[w][(j / 12) * kShRow + j % 12] = q[i];
+  }
+  __syncthreads();
+  const unsigned g = g0 + lane;
+  if (g >= n) return;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) q[i] = lds[w][lane * kShRow + i];
   float B[16];
   sh_basis<16>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
   if (deg_use == 0) {
@@ -132,25 +154,37 @@ __global__ __launch_bounds__(256) void sh16_fwd_kernel(
 __global__ __launch_bounds__(256) void sh16_bwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
     const float *__restrict__ v_colors, float4 *__restrict__ v_coeffs) {
-  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  float B[16];
-  sh_basis<16>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
-  if (deg_use == 0) {
+  __shared__ float4 lds[4][64 * kShRow];
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned g0 = (blockIdx.x * 4 + w) * 64;
+  const unsigned g = g0 + lane;
+  if (g < n) {
+    float B[16];
+    sh_basis<16>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+    if (deg_use == 0) {
 #pragma unroll
-    for (int k = 1; k < 16; ++k) B[k] = 0.f;
+      for (int k = 1; k < 16; ++k) B[k] = 0.f;
+    }
+    const float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
+    float f[48];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      f[3 * k] = B[k] * vr;
+      f[3 * k + 1] = B[k] * vg;
+      f[3 * k + 2] = B[k] * vb;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      lds[w][lane * kShRow + i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
   }
-  const float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
-  float f[48];
+  __syncthreads();
+  const unsigned navail = g0 < n ? (n - g0 < 64 ? n - g0 : 64) * 12 : 0;
+  float4 *dst = v_coeffs + (size_t)g0 * 12;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    f[3 * k] = B[k] * vr;
-    f[3 * k + 1] = B[k] * vg;
-    f[3 * k + 2] = B[k] * vb;
+  for (int i = 0; i < 12; ++i) {
+    const unsigned j = i * 64 + lane;
+    if (j < navail) dst[j] = lds[w][(j / 12) * kShRow + j % 12];
   }
-  float4 *o = v_coeffs + (size_t)g * 12;
-#pragma unroll
-  for (int i = 0; i < 12; ++i) o[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
 }
 
 // ---- any degree / any alignment: one lane per Gaussian, dword accesses -----

@@ -104,6 +104,59 @@ __global__ __launch_bounds__(256) void b2(unsigned n, const float* __restrict__ 
   float* o = vco + (size_t)g*48+3*k;
   o[0]=bk*vcol[3*g]; o[1]=bk*vcol[3*g+1]; o[2]=bk*vcol[3*g+2];
 }
+// F3: one lane per gaussian for the math, but the wave moves its 64 x 192 B as 12
+// fully coalesced 1-KB dwordx4 rows and transposes through LDS (rows padded to 13 float4)
+__global__ __launch_bounds__(256) void f3(unsigned n, const float* __restrict__ dirs, const float4* __restrict__ coeffs, float* __restrict__ colors){
+  __shared__ float4 lds[4][64*13];
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned g0 = (blockIdx.x*4 + w)*64;        // first gaussian of this wave
+  if (g0 >= n) return;
+  const float4* src = coeffs + (size_t)g0*12;
+  const unsigned navail = (n - g0 < 64 ? n - g0 : 64)*12;
+  float4 q[12];
+#pragma unroll
+  for(int i=0;i<12;i++){ unsigned j=i*64+lane; q[i] = j<navail ? src[j] : make_float4(0,0,0,0); }
+#pragma unroll
+  for(int i=0;i<12;i++){ unsigned j=i*64+lane; lds[w][(j/12)*13 + j%12] = q[i]; }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  const unsigned g = g0+lane;
+#pragma unroll
+  for(int i=0;i<12;i++) q[i] = lds[w][lane*13+i];
+  if (g>=n) return;
+  float B[16]; basis16(dirs[3*g],dirs[3*g+1],dirs[3*g+2],B);
+  const float* f = reinterpret_cast<const float*>(q);
+  float r=0,gg=0,b=0;
+#pragma unroll
+  for(int k=0;k<16;k++){ r+=B[k]*f[3*k]; gg+=B[k]*f[3*k+1]; b+=B[k]*f[3*k+2]; }
+  colors[3*g]=r;colors[3*g+1]=gg;colors[3*g+2]=b;
+}
+// B3: backward with the same transposition before the stores
+__global__ __launch_bounds__(256) void b3(unsigned n, const float* __restrict__ dirs, const float* __restrict__ vcol, float4* __restrict__ vco){
+  __shared__ float4 lds[4][64*13];
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned g0 = (blockIdx.x*4 + w)*64;
+  if (g0 >= n) return;
+  const unsigned g = g0+lane;
+  float f[48];
+  if (g<n){
+    float B[16]; basis16(dirs[3*g],dirs[3*g+1],dirs[3*g+2],B);
+    const float vr=vcol[3*g],vg=vcol[3*g+1],vb=vcol[3*g+2];
+#pragma unroll
+    for(int k=0;k<16;k++){ f[3*k]=B[k]*vr; f[3*k+1]=B[k]*vg; f[3*k+2]=B[k]*vb; }
+  } else {
+#pragma unroll
+    for(int k=0;k<48;k++) f[k]=0.f;
+  }
+#pragma unroll
+  for(int i=0;i<12;i++) lds[w][lane*13+i] = make_float4(f[4*i],f[4*i+1],f[4*i+2],f[4*i+3]);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  float4* dst = vco + (size_t)g0*12;
+  const unsigned navail = (n - g0 < 64 ? n - g0 : 64)*12;
+#pragma unroll
+  for(int i=0;i<12;i++){ unsigned j=i*64+lane; if (j<navail) dst[j] = lds[w][(j/12)*13 + j%12]; }
+}
 int main(){
   unsigned n=1000000; size_t nb=(size_t)n*48*4;
   float *coeffs,*dirs,*colors; CK(hipMalloc(&coeffs,nb)); CK(hipMalloc(&dirs,n*12)); CK(hipMalloc(&colors,(size_t)3000000*48*4));
@@ -124,6 +177,14 @@ int main(){
     run("[3M] b1 lane/gaussian float4 stores", [&]{ hipLaunchKernelGGL(b1, dim3((n3+255)/256), dim3(256),0,0,n3,d3,c3,(float4*)co3); });
     run("[3M] PROD gsr_sh_forward deg3", [&]{ gsr_sh_forward(n3,3,3,d3,co3,colors,0); });
     run("[3M] PROD gsr_sh_backward deg3", [&]{ gsr_sh_backward(n3,3,3,d3,c3,co3,0); });
+    run("[3M] f3 coalesced rows + LDS transpose", [&]{ hipLaunchKernelGGL(f3, dim3((n3+255)/256), dim3(256),0,0,n3,d3,(const float4*)co3,colors); });
+    run("[3M] b3 LDS transpose + coalesced rows", [&]{ hipLaunchKernelGGL(b3, dim3((n3+255)/256), dim3(256),0,0,n3,d3,c3,(float4*)co3); });
+    { unsigned n1=1000000; nb=(size_t)n1*48*4;
+      run("[1M] f1", [&]{ hipLaunchKernelGGL(f1, dim3((n1+255)/256), dim3(256),0,0,n1,d3,(const float4*)co3,colors); });
+      run("[1M] f3", [&]{ hipLaunchKernelGGL(f3, dim3((n1+255)/256), dim3(256),0,0,n1,d3,(const float4*)co3,colors); });
+      run("[1M] b1", [&]{ hipLaunchKernelGGL(b1, dim3((n1+255)/256), dim3(256),0,0,n1,d3,c3,(float4*)co3); });
+      run("[1M] b3", [&]{ hipLaunchKernelGGL(b3, dim3((n1+255)/256), dim3(256),0,0,n1,d3,c3,(float4*)co3); });
+      nb=nb3; }
     run("[3M] b2 16 lanes stores", [&]{ hipLaunchKernelGGL(b2, dim3((n3*16+255)/256), dim3(256),0,0,n3,d3,c3,co3); });
   }
   CK(hipDeviceSynchronize());
