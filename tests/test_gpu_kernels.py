@@ -161,7 +161,7 @@ def test_binning_bit_exact(n, W, H, bw, ck):
 
 
 @pytest.mark.parametrize("n,W,H,bw,ck", CASES + [(200_000, 640, 360, 16, {}), (50_000, 2560, 1440, 16, {}),
-                                             (30_000, 3840, 2160, 16, {}), (20_000, 48, 32, 16, {}),
+                                             (30_000, 3840, 2160, 16, {}), (20_000, 5120, 2880, 16, {}), (20_000, 48, 32, 16, {}),
                                              (300_000, 64, 64, 4, {})])
 def test_fused_binning_equals_reference_pipeline(n, W, H, bw, ck):
     """depth_order + bin_sorted (what rasterize_gaussians runs) produce the same
