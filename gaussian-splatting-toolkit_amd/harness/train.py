@@ -143,7 +143,8 @@ class TrainConfig:
     log_every: int = 0
     eval_views: int = 4
     fused_loss: bool = True   # gs_fused.l1_ssim_loss (2 HIP kernels) instead of the torch-op SSIM
-    fused_adam: bool = True   # torch's fused (multi-tensor, single-kernel) Adam
+    fused_adam: bool = True   # gs_fused.FusedAdam: all six parameter groups in one HIP launch
+    torch_fused_adam: bool = False  # (A/B) torch's own fused multi-tensor Adam instead
 
 
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
@@ -167,8 +168,13 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     model = GaussianParams(raw, device)
     if cfg.fused_adam and device.type == "cuda":
         # one optimiser, six parameter groups with the reference's learning rates
-        optims = {"all": torch.optim.Adam([{"params": [model.gauss[k]], "lr": lr} for k, lr in LRS.items()],
-                                          eps=1e-15, fused=True)}
+        groups = [{"params": [model.gauss[k]], "lr": lr} for k, lr in LRS.items()]
+        if cfg.torch_fused_adam:
+            optims = {"all": torch.optim.Adam(groups, eps=1e-15, fused=True)}
+        else:
+            from gs_fused import FusedAdam
+
+            optims = {"all": FusedAdam(groups, eps=1e-15)}
     else:
         optims = {k: torch.optim.Adam([model.gauss[k]], lr=lr, eps=1e-15) for k, lr in LRS.items()}
     plist = model.param_list()

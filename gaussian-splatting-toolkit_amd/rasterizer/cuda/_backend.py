@@ -42,6 +42,7 @@ SYMBOLS = (
     "gsr_cov2d_bounds",
     "gsr_l1_ssim_forward",
     "gsr_l1_ssim_backward",
+    "gsr_adam_step",
 )
 
 

@@ -261,6 +261,30 @@ int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width,
                          const float *pred, const float *gt, const float *maps,
                          float *v_pred, gsr_stream_t stream);
 
+/* ---- optimiser step ------------------------------------
+ * Adam over up to GSR_ADAM_MAX_TENSORS tensors in one launch; replaces the
+ * per-group torch.optim.Adam objects the toolkit builds
+ * (gs_toolkit/engine/optimizers.py:59-196, learning rates and eps = 1e-15 of
+ * configs/method_configs.py:47-80).  Rule of torch.optim.Adam with
+ * amsgrad = False, weight_decay = 0:  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+ * p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).
+ * `tensors` is a HOST array; its pointers are device pointers (fp32, n elements
+ * each, updated in place: param, exp_avg, exp_avg_sq).  `step` counts from 1.
+ * The betas are doubles because torch forms 1 - beta in double before rounding
+ * to fp32 (1.f - 0.999f is 1.3e-5 off). */
+#define GSR_ADAM_MAX_TENSORS 8
+typedef struct {
+  float *param;
+  const float *grad;
+  float *exp_avg;
+  float *exp_avg_sq;
+  long long n;
+  float lr;
+} gsr_adam_tensor;
+int gsr_adam_step(int num_tensors, const gsr_adam_tensor *tensors,
+                  double beta1, double beta2, double eps, long long step,
+                  gsr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

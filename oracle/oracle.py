@@ -316,3 +316,21 @@ def l1_ssim_loss(pred, gt, ssim_lambda=0.2, with_grad=True):
     loss = fn(C.c_int(H), C.c_int(W), _p(pred), _p(gt), C.c_float(ssim_lambda), C.byref(l1), C.byref(ss),
               _p(v) if v is not None else None)
     return float(loss), l1.value, ss.value, v
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One step of torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False)
+    as `_single_tensor_adam` (torch/optim/adam.py) computes it for fp32 tensors:
+    fp32 elementwise arithmetic, bias corrections as Python floats.  `step` counts
+    from 1.  -> (param, exp_avg, exp_avg_sq), new arrays.  This is what the
+    toolkit's per-group optimisers do (gs_toolkit/engine/optimizers.py:59-196)."""
+    f = np.float32
+    p, g = np.asarray(param, f), np.asarray(grad, f)
+    m = (np.asarray(exp_avg, f) * f(beta1) + g * f(1.0 - beta1)).astype(f)
+    v = (np.asarray(exp_avg_sq, f) * f(beta2) + (g * g) * f(1.0 - beta2)).astype(f)
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    step_size = lr / bc1
+    denom = (np.sqrt(v) / f(np.sqrt(bc2)) + f(eps)).astype(f)
+    p = (p - f(step_size) * (m / denom)).astype(f)
+    return p, m, v

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--torch-fused-adam", action="store_true", help="A/B: torch's fused Adam instead of gs_fused.FusedAdam")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -44,7 +45,8 @@ def main():
         else:
             dist.init_process_group("gloo")
     cfg = TrainConfig(num_gaussians=args.gaussians, width=args.width, height=args.height,
-                      num_views=args.views, iters=args.iters, sh_degree_interval=max(1, args.iters // 4))
+                      num_views=args.views, iters=args.iters, sh_degree_interval=max(1, args.iters // 4),
+                      torch_fused_adam=args.torch_fused_adam)
     res = train(cfg, dev, rank, world)
     if world > 1:
         cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
