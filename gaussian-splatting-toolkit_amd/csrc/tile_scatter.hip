@@ -229,6 +229,8 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const int
   const long long beg = (long long)c * chunk;
   const int end = (int)(beg + chunk < (long long)I ? beg + chunk : (long long)I);
   const unsigned long long lt = (1ull << lane) - 1ull;
+  int key_bits = 1;  // bits that distinguish tile ids
+  while ((1 << key_bits) < T) ++key_bits;
   // One 64-lane step: slot = ds_add_rtn, conflicts re-ranked by lane (see the header).
   auto place = [&](const unsigned key, const int gid, const bool live) {
     unsigned old = 0, cur = 1;
@@ -242,6 +244,19 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const int
     // of such a group except the one whose add was applied last)
     const bool conf = cur != old + 1u;
     unsigned long long cm = __ballot(conf);
+    if (__popcll(cm) >= 8) {
+      // many lanes collided (spatially coherent scenes: consecutive Gaussians cover
+      // the same tiles): one pass of wave-wide key matching, whose cost does not
+      // depend on the number of distinct tiles involved
+      unsigned long long peers = __ballot(live);
+      for (int bit = 0; bit < key_bits; ++bit) {
+        const bool b = (key >> bit) & 1u;
+        const unsigned long long set = __ballot(b);
+        peers &= b ? set : ~set;
+      }
+      if (live) pos = cur - (unsigned)__popcll(peers) + (unsigned)__popcll(peers & lt);
+      cm = 0;
+    }
     while (cm) {
       const int leader = __ffsll((long long)cm) - 1;
       const unsigned k = (unsigned)__shfl((int)key, leader);
