@@ -239,6 +239,187 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// ---- split coefficients: features_dc [N,3] + features_rest [N,K-1,3] ---------
+// The models keep the DC band and the higher bands as separate parameters and
+// torch.cat them for every render (vanilla_gs.py:809): at K = 16 that is a 192-MB
+// copy per forward and two strided copies back per backward, more than the SH
+// kernels themselves.  These kernels read / write the two tensors in place.  Same
+// scheme as the K = 16 kernels above: the wave's 64 x (K-1) x 3 contiguous floats of
+// `rest` move as coalesced dwordx4 and are transposed through LDS (row stride padded
+// to an odd number of floats: conflict-free dword reads).
+template <int K>
+struct SplitCfg {
+  static constexpr int R = 3 * (K - 1);  // floats of `rest` per Gaussian
+  static constexpr int STRIDE = R | 1;
+};
+
+template <int K, bool VEC>
+__device__ __forceinline__ void split_rows_to_lds(const float *__restrict__ src, const unsigned cnt,
+                                                  const unsigned lane, float *lds) {
+  constexpr int R = SplitCfg<K>::R, STRIDE = SplitCfg<K>::STRIDE;
+  if (VEC && cnt == 64) {
+    const float4 *s4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll
+    for (int i = 0; i < (16 * R + 63) / 64; ++i) {
+      const unsigned j = i * 64 + lane;
+      if (j < 16u * R) {
+        const float4 q = s4[j];
+        const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned e = 4 * j + c;
+          lds[(e / R) * STRIDE + e % R] = v[c];
+        }
+      }
+    }
+  } else {
+    for (unsigned e = lane; e < cnt * R; e += 64) lds[(e / R) * STRIDE + e % R] = src[e];
+  }
+}
+
+template <int K, bool VEC>
+__device__ __forceinline__ void split_rows_from_lds(float *__restrict__ dst, const unsigned cnt,
+                                                    const unsigned lane, const float *lds) {
+  constexpr int R = SplitCfg<K>::R, STRIDE = SplitCfg<K>::STRIDE;
+  if (VEC && cnt == 64) {
+    float4 *d4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+    for (int i = 0; i < (16 * R + 63) / 64; ++i) {
+      const unsigned j = i * 64 + lane;
+      if (j < 16u * R) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const unsigned e = 4 * j + c;
+          v[c] = lds[(e / R) * STRIDE + e % R];
+        }
+        d4[j] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  } else {
+    for (unsigned e = lane; e < cnt * R; e += 64) dst[e] = lds[(e / R) * STRIDE + e % R];
+  }
+}
+
+template <int K, bool VEC>
+__global__ __launch_bounds__(256) void sh_split_fwd_kernel(
+    const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
+    const float *__restrict__ dc, const float *__restrict__ rest, float *__restrict__ colors) {
+  constexpr int R = SplitCfg<K>::R, STRIDE = SplitCfg<K>::STRIDE;
+  __shared__ float lds[4][64 * STRIDE];
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned g0 = (blockIdx.x * 4 + w) * 64;
+  const unsigned cnt = g0 < n ? (n - g0 < 64 ? n - g0 : 64) : 0;
+  split_rows_to_lds<K, VEC>(rest + (size_t)g0 * R, cnt, lane, lds[w]);
+  __syncthreads();
+  const unsigned g = g0 + lane;
+  if (g >= n) return;
+  float B[K];
+  sh_basis<K>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+  if (deg_use == 0) {
+#pragma unroll
+    for (int k = 1; k < K; ++k) B[k] = 0.f;
+  }
+  float r = B[0] * dc[3 * g], gr = B[0] * dc[3 * g + 1], b = B[0] * dc[3 * g + 2];
+  const float *row = lds[w] + lane * STRIDE;
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    r += B[k] * row[3 * (k - 1)];
+    gr += B[k] * row[3 * (k - 1) + 1];
+    b += B[k] * row[3 * (k - 1) + 2];
+  }
+  colors[3 * g] = r;
+  colors[3 * g + 1] = gr;
+  colors[3 * g + 2] = b;
+}
+
+template <int K, bool VEC>
+__global__ __launch_bounds__(256) void sh_split_bwd_kernel(
+    const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
+    const float *__restrict__ v_colors, float *__restrict__ v_dc, float *__restrict__ v_rest) {
+  constexpr int R = SplitCfg<K>::R, STRIDE = SplitCfg<K>::STRIDE;
+  __shared__ float lds[4][64 * STRIDE];
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned g0 = (blockIdx.x * 4 + w) * 64;
+  const unsigned cnt = g0 < n ? (n - g0 < 64 ? n - g0 : 64) : 0;
+  const unsigned g = g0 + lane;
+  if (g < n) {
+    float B[K];
+    sh_basis<K>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+    if (deg_use == 0) {
+#pragma unroll
+      for (int k = 1; k < K; ++k) B[k] = 0.f;
+    }
+    const float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
+    v_dc[3 * g] = B[0] * vr;
+    v_dc[3 * g + 1] = B[0] * vg;
+    v_dc[3 * g + 2] = B[0] * vb;
+    float *row = lds[w] + lane * STRIDE;
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+      row[3 * (k - 1)] = B[k] * vr;
+      row[3 * (k - 1) + 1] = B[k] * vg;
+      row[3 * (k - 1) + 2] = B[k] * vb;
+    }
+  }
+  __syncthreads();
+  split_rows_from_lds<K, VEC>(v_rest + (size_t)g0 * R, cnt, lane, lds[w]);
+}
+
+GSR_EXPORT int gsr_sh_forward_split(unsigned num_points, unsigned degree, unsigned degrees_to_use,
+                                    const float *viewdirs, const float *dc, const float *rest,
+                                    float *colors, gsr_stream_t stream) {
+  GSR_REQUIRE(degree >= 1 && degree <= 3, "sh_forward_split: degree must be in [1,3]");
+  GSR_REQUIRE(degrees_to_use <= degree, "sh_forward_split: degrees_to_use > degree");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(viewdirs && dc && rest && colors, "sh_forward_split: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 blk(256), grd(gsr_cdiv(num_points, 256));
+  const bool vec = aligned16(rest);
+#define GSR_SPLIT_FWD(KK)                                                                                  \
+  if (vec)                                                                                                 \
+    hipLaunchKernelGGL((sh_split_fwd_kernel<KK, true>), grd, blk, 0, s, num_points, degrees_to_use,        \
+                       viewdirs, dc, rest, colors);                                                        \
+  else                                                                                                     \
+    hipLaunchKernelGGL((sh_split_fwd_kernel<KK, false>), grd, blk, 0, s, num_points, degrees_to_use,       \
+                       viewdirs, dc, rest, colors)
+  switch (degree) {
+    case 1: GSR_SPLIT_FWD(4); break;
+    case 2: GSR_SPLIT_FWD(9); break;
+    default: GSR_SPLIT_FWD(16); break;
+  }
+#undef GSR_SPLIT_FWD
+  GSR_CHECK_LAUNCH("sh_forward_split");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_sh_backward_split(unsigned num_points, unsigned degree, unsigned degrees_to_use,
+                                     const float *viewdirs, const float *v_colors, float *v_dc,
+                                     float *v_rest, gsr_stream_t stream) {
+  GSR_REQUIRE(degree >= 1 && degree <= 3, "sh_backward_split: degree must be in [1,3]");
+  GSR_REQUIRE(degrees_to_use <= degree, "sh_backward_split: degrees_to_use > degree");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(viewdirs && v_colors && v_dc && v_rest, "sh_backward_split: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 blk(256), grd(gsr_cdiv(num_points, 256));
+  const bool vec = aligned16(v_rest);
+#define GSR_SPLIT_BWD(KK)                                                                                  \
+  if (vec)                                                                                                 \
+    hipLaunchKernelGGL((sh_split_bwd_kernel<KK, true>), grd, blk, 0, s, num_points, degrees_to_use,        \
+                       viewdirs, v_colors, v_dc, v_rest);                                                  \
+  else                                                                                                     \
+    hipLaunchKernelGGL((sh_split_bwd_kernel<KK, false>), grd, blk, 0, s, num_points, degrees_to_use,       \
+                       viewdirs, v_colors, v_dc, v_rest)
+  switch (degree) {
+    case 1: GSR_SPLIT_BWD(4); break;
+    case 2: GSR_SPLIT_BWD(9); break;
+    default: GSR_SPLIT_BWD(16); break;
+  }
+#undef GSR_SPLIT_BWD
+  GSR_CHECK_LAUNCH("sh_backward_split");
+  return GSR_OK;
+}
+
 GSR_EXPORT int gsr_sh_forward(unsigned num_points, unsigned degree, unsigned degrees_to_use,
                               const float *viewdirs, const float *coeffs, float *colors,
                               gsr_stream_t stream) {

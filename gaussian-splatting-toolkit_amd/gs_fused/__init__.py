@@ -1,5 +1,7 @@
 """Fused caller-side ops next to the rasterizer (SURVEY.md 8f "next" rows): the
-photometric loss head (f2) and the one-launch Adam step (f1).  Same native library and C ABI (`include/gsraster.h`)
+photometric loss head (f2), the one-launch Adam step (f1) and SH colours from
+split coefficients (f4).  Same native library and C ABI (`include/gsraster.h`)
 as `rasterizer`; no CPU fallback."""
 from .loss import L1SSIMLoss, l1_ssim_loss  # noqa: F401
 from .adam import FusedAdam  # noqa: F401
+from .sh import spherical_harmonics_split  # noqa: F401

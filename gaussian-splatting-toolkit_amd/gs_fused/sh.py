@@ -1,0 +1,79 @@
+"""SH colours from split coefficients, without the `torch.cat`.
+
+The models hold the DC band and the higher bands as two parameters and join them
+for every render (gs_toolkit/models/vanilla_gs.py:809):
+
+    colors_crop = torch.cat((features_dc_crop[:, None, :], features_rest_crop), dim=1)
+    rgbs = spherical_harmonics(n, viewdirs, colors_crop)
+
+At SH degree 3 the cat is a 192-MB copy per forward and autograd splits the
+gradient back with two strided copies per backward -- more HBM traffic than the
+SH kernels themselves.  `spherical_harmonics_split(n, viewdirs, features_dc,
+features_rest)` returns the same colours and writes the two gradients in place
+(`gsr_sh_forward_split` / `gsr_sh_backward_split`, include/gsraster.h).
+"""
+import ctypes as C
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from rasterizer.cuda import _call, _check, _ptr, _stream
+from rasterizer.sh import deg_from_sh, num_sh_bases, spherical_harmonics
+
+_f32 = torch.float32
+
+
+class _SplitSH(Function):
+    @staticmethod
+    def forward(ctx, degrees_to_use: int, viewdirs: Tensor, dc: Tensor, rest: Tensor):
+        n = dc.shape[0]
+        degree = deg_from_sh(rest.shape[-2] + 1)
+        for t, nm in ((viewdirs, "viewdirs"), (dc, "features_dc"), (rest, "features_rest")):
+            _check(t, nm, _f32)
+        dev = dc.device
+        with torch.cuda.device(dev):
+            colors = torch.empty((n, 3), dtype=_f32, device=dev)
+            _call("gsr_sh_forward_split", C.c_uint(n), C.c_uint(degree), C.c_uint(degrees_to_use),
+                  _ptr(viewdirs), _ptr(dc), _ptr(rest), _ptr(colors), _stream(dev))
+        ctx.degree, ctx.degrees_to_use = degree, degrees_to_use
+        ctx.shapes = (dc.shape, rest.shape)
+        ctx.save_for_backward(viewdirs)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors: Tensor):
+        (viewdirs,) = ctx.saved_tensors
+        n = viewdirs.shape[0]
+        v_colors = _check(v_colors.contiguous(), "v_colors", _f32)
+        dev = viewdirs.device
+        with torch.cuda.device(dev):
+            v_dc = torch.empty(ctx.shapes[0], dtype=_f32, device=dev)
+            v_rest = torch.empty(ctx.shapes[1], dtype=_f32, device=dev)
+            _call("gsr_sh_backward_split", C.c_uint(n), C.c_uint(ctx.degree), C.c_uint(ctx.degrees_to_use),
+                  _ptr(viewdirs), _ptr(v_colors), _ptr(v_dc), _ptr(v_rest), _stream(dev))
+        return None, None, v_dc, v_rest
+
+
+def spherical_harmonics_split(degrees_to_use: int, viewdirs: Tensor, features_dc: Tensor,
+                              features_rest: Tensor) -> Tensor:
+    """Colours [N,3] from `features_dc` [N,3] (or [N,1,3]) and `features_rest`
+    [N,K-1,3]; equal to `spherical_harmonics(degrees_to_use, viewdirs,
+    torch.cat((features_dc[:, None], features_rest), 1))`, differentiable w.r.t.
+    both coefficient tensors.  K - 1 must be 3, 8 or 15 (degree 1..3); a model
+    without higher bands (K = 1) or with degree 4 takes the concatenating path."""
+    if features_dc.dim() == 3:
+        if features_dc.shape[1] != 1:
+            raise ValueError("features_dc must be [N,3] or [N,1,3]")
+    elif features_dc.dim() != 2:
+        raise ValueError("features_dc must be [N,3] or [N,1,3]")
+    if features_rest.dim() != 3 or features_rest.shape[0] != features_dc.shape[0] or features_rest.shape[2] != 3 \
+            or features_dc.shape[-1] != 3 or viewdirs.shape != (features_dc.shape[0], 3):
+        raise ValueError("expected viewdirs [N,3], features_dc [N,3], features_rest [N,K-1,3]")
+    K = features_rest.shape[1] + 1
+    assert K >= num_sh_bases(degrees_to_use)
+    if K not in (4, 9, 16):
+        dc3 = features_dc if features_dc.dim() == 3 else features_dc[:, None, :]
+        return spherical_harmonics(degrees_to_use, viewdirs, torch.cat((dc3, features_rest), dim=1))
+    return _SplitSH.apply(degrees_to_use, viewdirs.contiguous(), features_dc.contiguous(),
+                          features_rest.contiguous())

@@ -44,7 +44,8 @@ def render_view(
     scales: torch.Tensor,       # [N,3] already exp()'d
     quats: torch.Tensor,        # [N,4] already normalised
     opacities: torch.Tensor,    # [N,1] already sigmoid()'d
-    sh_coeffs: torch.Tensor,    # [N,K,3] (features_dc ++ features_rest)
+    sh_coeffs,                  # [N,K,3] (features_dc ++ features_rest), or the pair
+                                # (features_dc [N,3], features_rest [N,K-1,3]): no torch.cat (gs_fused)
     cam: CameraTensors,
     background: torch.Tensor,   # [3]
     sh_degree_to_use: int,
@@ -63,7 +64,12 @@ def render_view(
 
     viewdirs = means3d.detach() - cam.campos
     viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
-    rgbs = spherical_harmonics(sh_degree_to_use, viewdirs, sh_coeffs)
+    if isinstance(sh_coeffs, (tuple, list)):
+        from gs_fused import spherical_harmonics_split
+
+        rgbs = spherical_harmonics_split(sh_degree_to_use, viewdirs, sh_coeffs[0], sh_coeffs[1])
+    else:
+        rgbs = spherical_harmonics(sh_degree_to_use, viewdirs, sh_coeffs)
     rgbs = torch.clamp(rgbs + 0.5, min=0.0)
 
     if rasterize_mode == "antialiased":

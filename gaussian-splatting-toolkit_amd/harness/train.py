@@ -79,6 +79,8 @@ def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale
 
 
 class GaussianParams(torch.nn.Module):
+    split_sh = True  # evaluate SH from (features_dc, features_rest) without torch.cat
+
     def __init__(self, raw: Dict[str, np.ndarray], device):
         super().__init__()
         self.gauss = torch.nn.ParameterDict(
@@ -94,7 +96,10 @@ class GaussianParams(torch.nn.Module):
     def render(self, cam: CameraTensors, background, sh_degree_to_use: int, render_depth=False,
                retain_xys_grad=False):
         g = self.gauss
-        coeffs = torch.cat((g["features_dc"][:, None, :], g["features_rest"]), dim=1)
+        if self.split_sh and g["features_dc"].is_cuda and g["features_rest"].shape[1] in (3, 8, 15):
+            coeffs = (g["features_dc"], g["features_rest"])  # gs_fused.spherical_harmonics_split
+        else:
+            coeffs = torch.cat((g["features_dc"][:, None, :], g["features_rest"]), dim=1)
         return render_view(
             g["means"], torch.exp(g["scales"]), g["quats"] / g["quats"].norm(dim=-1, keepdim=True),
             torch.sigmoid(g["opacities"]), coeffs, cam, background, sh_degree_to_use,
@@ -145,6 +150,7 @@ class TrainConfig:
     fused_loss: bool = True   # gs_fused.l1_ssim_loss (2 HIP kernels) instead of the torch-op SSIM
     fused_adam: bool = True   # gs_fused.FusedAdam: all six parameter groups in one HIP launch
     torch_fused_adam: bool = False  # (A/B) torch's own fused multi-tensor Adam instead
+    split_sh: bool = True     # gs_fused.spherical_harmonics_split instead of torch.cat + spherical_harmonics
 
 
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
@@ -166,6 +172,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     raw["features_rest"] *= 0.0
     raw["opacities"] -= 0.5
     model = GaussianParams(raw, device)
+    model.split_sh = truth.split_sh = cfg.split_sh
     if cfg.fused_adam and device.type == "cuda":
         # one optimiser, six parameter groups with the reference's learning rates
         groups = [{"params": [model.gauss[k]], "lr": lr} for k, lr in LRS.items()]

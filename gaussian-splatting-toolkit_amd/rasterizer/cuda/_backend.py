@@ -42,6 +42,8 @@ SYMBOLS = (
     "gsr_cov2d_bounds",
     "gsr_l1_ssim_forward",
     "gsr_l1_ssim_backward",
+    "gsr_sh_forward_split",
+    "gsr_sh_backward_split",
     "gsr_adam_step",
 )
 

@@ -261,6 +261,22 @@ int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width,
                          const float *pred, const float *gt, const float *maps,
                          float *v_pred, gsr_stream_t stream);
 
+/* ---- SH colours from split coefficients (caller-side glue) --
+ * gsr_sh_forward / gsr_sh_backward for models that keep the DC band and the
+ * higher bands as two parameters (features_dc [n,3], features_rest [n,K-1,3])
+ * and torch.cat them before every render (gs_toolkit/models/vanilla_gs.py:809,
+ * `colors_crop = torch.cat(...)`): no concatenated copy is made, the gradients
+ * are written straight into v_dc [n,3] and v_rest [n,K-1,3].  degree in [1,3]
+ * (K = (degree+1)^2). */
+int gsr_sh_forward_split(unsigned num_points, unsigned degree,
+                         unsigned degrees_to_use, const float *viewdirs,
+                         const float *dc, const float *rest, float *colors,
+                         gsr_stream_t stream);
+int gsr_sh_backward_split(unsigned num_points, unsigned degree,
+                          unsigned degrees_to_use, const float *viewdirs,
+                          const float *v_colors, float *v_dc, float *v_rest,
+                          gsr_stream_t stream);
+
 /* ---- optimiser step ------------------------------------
  * Adam over up to GSR_ADAM_MAX_TENSORS tensors in one launch; replaces the
  * per-group torch.optim.Adam objects the toolkit builds

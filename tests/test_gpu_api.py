@@ -457,3 +457,37 @@ def test_speculative_list_sizing_never_changes_results():
         assert torch.equal(got[0], ref[0])
         for a, b in zip(got[1:], ref[1:]):
             assert (a - b).abs().max() <= 1e-5 * b.abs().max()
+
+
+@pytest.mark.parametrize("K,use", [(16, 3), (16, 1), (16, 0), (9, 2), (4, 1), (25, 4), (1, 0)])
+@pytest.mark.parametrize("n", [1, 64, 1000, 4097])
+def test_split_sh_equals_cat(K, use, n):
+    """gs_fused.spherical_harmonics_split == spherical_harmonics(cat(dc, rest)), values
+    and both gradients, against the oracle too (ragged last wave, unaligned rest)."""
+    from gs_fused import spherical_harmonics_split
+    from rasterizer import spherical_harmonics
+
+    rng = np.random.default_rng(K * 1000 + n)
+    dirs = rng.standard_normal((n, 3)).astype(np.float32)
+    dc = rng.standard_normal((n, 3)).astype(np.float32)
+    rest = rng.standard_normal((n, K - 1, 3)).astype(np.float32)
+    v = rng.standard_normal((n, 3)).astype(np.float32)
+    full = np.concatenate([dc[:, None, :], rest], 1)
+    deg = {1: 0, 4: 1, 9: 2, 16: 3, 25: 4}[K]
+    want = O.compute_sh_forward(n, deg, use, dirs / np.linalg.norm(dirs, axis=-1, keepdims=True), full)
+    want_g = O.compute_sh_backward(n, deg, use, dirs / np.linalg.norm(dirs, axis=-1, keepdims=True), v)
+    for offset in (0, 1):  # offset 1: `rest` only 4-byte aligned -> scalar row path
+        buf = torch.zeros(rest.size + offset, device=DEV)
+        buf[offset:] = torch.from_numpy(rest).to(DEV).reshape(-1)
+        t_rest = buf[offset:].view(n, K - 1, 3).requires_grad_(True)
+        t_dc = cu(dc, True)
+        out = spherical_harmonics_split(use, cu(dirs), t_dc, t_rest)
+        out.backward(cu(v))
+        assert np.abs(out.detach().cpu().numpy() - want).max() < 1e-5
+        got = np.concatenate([t_dc.grad.cpu().numpy()[:, None, :], t_rest.grad.cpu().numpy()], 1)
+        assert np.abs(got - want_g).max() < 1e-5
+        c = torch.from_numpy(full).to(DEV).requires_grad_(True)
+        ref = spherical_harmonics(use, cu(dirs), c)
+        ref.backward(cu(v))
+        assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+        assert np.abs(got - c.grad.cpu().numpy()).max() < 1e-6
