@@ -19,13 +19,23 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     lo, hi = float(os.environ.get("SCALE_LO", 0.0025)), float(os.environ.get("SCALE_HI", 0.025))
     W, H = 1920, 1080
-    cam = S.make_camera(W, H)
-    sc = S.make_scene(n, cam, sh_degree=0, seed=42, scale_lo=lo, scale_hi=hi)
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    if os.environ.get("BLOB"):  # the trainer harness' scene: a ball of Gaussians seen from an orbit camera
+        from harness import train as T
+
+        cam = T.orbit_cameras(16, W, H)[3]
+        raw = T.blob_scene(n, seed=0, sh_degree=0)
+        q = raw["quats"] / np.linalg.norm(raw["quats"], axis=-1, keepdims=True)
+        sc = {"means3d": raw["means"], "scales": np.exp(raw["scales"]), "quats": q.astype(np.float32),
+              "opacities": (1 / (1 + np.exp(-raw["opacities"]))).astype(np.float32)}
+    else:
+        cam = S.make_camera(W, H)
+        sc = S.make_scene(n, cam, sh_degree=0, seed=42, scale_lo=lo, scale_hi=hi)
     cov3d, xys, depths, radii, conics, comp, tiles = C.project_gaussians_forward(
         n, cu(sc["means3d"]), cu(sc["scales"]), 1.0, cu(sc["quats"]), cu(cam.viewmat[:3]), cu(cam.projmat),
         cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16, 0.01)
     opac = cu(sc["opacities"])
+    print("reference intersections", int(tiles.sum().item()), "visible", int((radii > 0).sum().item()))
     tb = ((W + 15) // 16, (H + 15) // 16, 1)
 
     def timed(fn):
