@@ -41,6 +41,7 @@ def _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, bloc
 # the device, and the host compares the two after compositing is already queued.
 # A guess that was too small costs one rebuild; the result never depends on it.
 _count_hint = {}
+_last_capacity = {}
 _pinned_count = {}
 
 
@@ -62,7 +63,16 @@ def _speculative_capacity(device, num_points, tile_bounds):
         return None
     guess = count_last * (num_points / n_last)
     cap = int(1.25 * guess) + 65536
-    return cap if cap < 2**31 - 1 else None
+    # keep the buffer sizes stable from view to view (the caching allocator then hands
+    # back the same blocks): whole Mi-elements, and no shrinking unless the need halves
+    cap = (cap + (1 << 20) - 1) & ~((1 << 20) - 1)
+    last_cap = _last_capacity.get((device, tile_bounds), 0)
+    if cap < last_cap <= 2 * cap:
+        cap = last_cap
+    if cap >= 2**31 - 1:
+        return None
+    _last_capacity[(device, tile_bounds)] = cap
+    return cap
 
 
 class _PendingCount:

@@ -412,7 +412,7 @@ def test_speculative_list_sizing_never_changes_results():
     from rasterizer import rasterize as R
 
     cam = S.make_camera(640, 360)
-    n = 30_000
+    n = 300_000
     sc = S.make_scene(n, cam, sh_degree=0, seed=9, scale_lo=0.01, scale_hi=0.1)
     ct = CameraTensors.from_numpy(cam, DEV)
     xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
@@ -438,15 +438,17 @@ def test_speculative_list_sizing_never_changes_results():
     C.bin_sorted = spy
     try:
         R._count_hint.clear()
+        R._last_capacity.clear()
         ref = run()                      # no hint: synchronous
         assert modes == [False]
         key = (xys.device, ((cam.width + 15) // 16, (cam.height + 15) // 16, 1))
         count = R._count_hint[key][1]
-        assert count > 150_000
+        assert count > 1_200_000  # more than the smallest capacity the sizing ever picks (1 Mi)
         modes.clear()
         good = run()                     # sized from the previous view
         assert modes == [True]
-        R._count_hint[key] = (n, 8)      # capacity 65546 < count: cut, then rebuilt
+        R._count_hint[key] = (n, 8)      # capacity 1 Mi entries < count: cut, then rebuilt
+        R._last_capacity.clear()
         modes.clear()
         small = run()
         assert modes == [True, False]
