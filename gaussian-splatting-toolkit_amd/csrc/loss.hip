@@ -130,8 +130,11 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(
   }
   __syncthreads();
   if (tid == 0) {
-    atomicAdd(&sums[0], (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(&sums[1], (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    // GSR_LOSS_SUM_SLOTS partial sums per quantity: 12 k workgroups adding doubles to the
+    // same two addresses serialised in the L2 (that alone was ~250 us of this kernel)
+    const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u) % GSR_LOSS_SUM_SLOTS;
+    atomicAdd(&sums[slot], (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&sums[GSR_LOSS_SUM_SLOTS + slot], (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
   }
 }
 
@@ -211,7 +214,7 @@ GSR_EXPORT int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width, cons
   GSR_REQUIRE(img_height > kHalo && img_width > kHalo, "l1_ssim_forward: image must be larger than 10x10");
   GSR_REQUIRE(pred && gt && maps && sums, "l1_ssim_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(double), s));
+  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * GSR_LOSS_SUM_SLOTS * sizeof(double), s));
   const dim3 grd(gsr_cdiv(img_width, kTW), gsr_cdiv(img_height, kTH), 3);
   hipLaunchKernelGGL(l1_ssim_fwd_kernel, grd, dim3(256), 0, s, (int)img_height, (int)img_width, pred, gt,
                      maps, sums);

@@ -21,6 +21,7 @@ from torch.autograd import Function
 from rasterizer.cuda import _call, _check, _ptr, _stream
 
 _f32 = torch.float32
+SUM_SLOTS = 64  # GSR_LOSS_SUM_SLOTS (include/gsraster.h)
 
 
 class _L1SSIM(Function):
@@ -36,11 +37,12 @@ class _L1SSIM(Function):
         dev = pred.device
         with torch.cuda.device(dev):
             maps = torch.empty((9, H - 10, W - 10), dtype=_f32, device=dev)
-            sums = torch.empty((2,), dtype=torch.float64, device=dev)
+            sums = torch.empty((2, SUM_SLOTS), dtype=torch.float64, device=dev)
             _call("gsr_l1_ssim_forward", C.c_uint(H), C.c_uint(W), _ptr(pred), _ptr(gt), _ptr(maps),
                   _ptr(sums), _stream(dev))
-        l1 = sums[0] / (3.0 * H * W)
-        ssim = sums[1] / (3.0 * (H - 10) * (W - 10))
+        tot = sums.sum(dim=1)  # the kernel spreads its atomics over SUM_SLOTS partial sums
+        l1 = tot[0] / (3.0 * H * W)
+        ssim = tot[1] / (3.0 * (H - 10) * (W - 10))
         loss = ((1.0 - ssim_lambda) * l1 + ssim_lambda * (1.0 - ssim)).to(_f32)
         ctx.save_for_backward(pred, gt, maps)
         ctx.ssim_lambda = float(ssim_lambda)

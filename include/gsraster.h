@@ -249,10 +249,13 @@ int gsr_cov2d_bounds(int num_pts, const float *cov2d, float *conics,
  * `torch.abs(gt - pred).mean()` + `1 - pytorch_msssim.SSIM(data_range=1,
  * size_average=True, channel=3)(gt, pred)` and their autograd backward.
  * pred, gt: [H,W,3] fp32.  maps: scratch [9, H-10, W-10] fp32 written by the
- * forward and consumed by the backward.  sums: 2 doubles, zeroed by the call:
- * sums[0] = sum |pred-gt|, sums[1] = sum of the SSIM map; the caller forms
- * loss = (1-l)*sums[0]/(3HW) + l*(1 - sums[1]/(3(H-10)(W-10))).
+ * forward and consumed by the backward.  sums: 2 x GSR_LOSS_SUM_SLOTS doubles,
+ * zeroed by the call: partial sums (one slot per group of workgroups, so that
+ * the atomics do not serialise on one address); S0 = sum of sums[0..SLOTS) =
+ * sum |pred-gt|, S1 = sum of sums[SLOTS..2 SLOTS) = sum of the SSIM map; the caller
+ * forms loss = (1-l)*S0/(3HW) + l*(1 - S1/(3(H-10)(W-10))).
  * backward: v_pred[H,W,3] = upstream[0] * d loss / d pred (upstream on device). */
+#define GSR_LOSS_SUM_SLOTS 64
 int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width,
                         const float *pred, const float *gt, float *maps,
                         double *sums, gsr_stream_t stream);
