@@ -169,7 +169,8 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   __shared__ int sId[kChunk];
   using BF = Butterfly<G>;
 
-  const int tile = (int)gsr_xcd_remap(blockIdx.x, (unsigned)num_tiles);
+  const int tile = gsr_xcd_remap(blockIdx.x, tiles_x, num_tiles / tiles_x);
+  if (tile < 0) return;
   const int2 range = tile_bins[tile];
   if (range.y <= range.x) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -531,7 +532,7 @@ GSR_EXPORT int gsr_rasterize_backward(
     return (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : GSR_BWD_GROUP;
   }();
 #define GSR_LAUNCH_T16(G)                                                                          \
-  hipLaunchKernelGGL(raster_bwd_tile16_kernel<G>, dim3(num_tiles), dim3(64), 0, s, tiles_x,         \
+  hipLaunchKernelGGL(raster_bwd_tile16_kernel<G>, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0, s, tiles_x,         \
                      num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,               \
                      reinterpret_cast<const int2 *>(tile_bins),                                     \
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,  \

@@ -15,8 +15,8 @@
 //    time through LDS (one gather per lane, coalesced index read) and consumed
 //    by wave-uniform broadcast reads, so every LDS word feeds 4 pixels per lane
 //    and no workgroup barrier is ever waited on by a second wave.  dx/dy terms
-//    are shared across the quad.  Workgroups are remapped so that each XCD
-//    rasterises a contiguous band of tiles (shared splats stay in one L2).
+//    are shared across the quad.  Workgroups are remapped so that 8x4-tile blocks go to the
+//    XCDs round-robin (shared splats stay in one L2, every XCD sees the whole frame).
 //  * generic (any block_width in [2,16], any channel count <= 32): one lane
 //    per pixel, block_width^2 lanes per tile.
 #include "raster_common.h"
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   __shared__ SplatB sB[kChunk];
   __shared__ SplatC sC[kChunk];
 
-  const int tile = (int)gsr_xcd_remap(blockIdx.x, (unsigned)num_tiles);
+  const int tile = gsr_xcd_remap(blockIdx.x, tiles_x, num_tiles / tiles_x);
+  if (tile < 0) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
   const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
@@ -285,7 +286,7 @@ GSR_EXPORT int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_wi
                           gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
                           background, out_img, final_Ts, final_idx, (hipStream_t)stream);
   const int num_tiles = tiles_x * tiles_y;
-  hipLaunchKernelGGL(raster_fwd_tile16_kernel, dim3(num_tiles), dim3(64), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(raster_fwd_tile16_kernel, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0, (hipStream_t)stream,
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
