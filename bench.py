@@ -47,6 +47,7 @@ KERNELS = (
     ("depth_order", "depth_order"),
     ("bin_sorted", "bin_sorted"),
     ("rasterize_forward", "raster_fwd"),
+    ("rasterize_forward_drawn", "raster_fwd"),
     ("rasterize_backward", "raster_bwd"),
     ("compute_sh_backward", "sh_bwd"),
     ("project_gaussians_backward", "project_bwd"),
@@ -271,6 +272,17 @@ def main():
             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes": alg[dominant], "kernel_ms": round(kern_ms[dominant], 4),
         }
+        # the compositing kernels are VALU-issue bound, not HBM bound:
+        # report how busy the SIMDs were, from the committed SQ counter pass of this workload
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")))["counters"]
+            kn = {"raster_bwd": "raster_bwd_tile16_kernel", "raster_fwd": "raster_fwd_tile16_kernel"}.get(dominant)
+            if traffic is not None and kn in sq:
+                simd_cycles = sq[kn]["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024.0
+                roofline["valu_busy"] = round(sq[kn]["SQ_INSTS_VALU"]["mean"] * 4.0 / simd_cycles, 3)
+                roofline["limiter"] = "VALU issue (SQ_INSTS_VALU x 4 cycles / SIMD-cycles resident, profiles/r01_pmc_sq.json)"
+        except Exception:
+            pass
         # every kernel's own fraction, and the end-to-end figure from SURVEY 8(d)
         per_kernel = {
             k: {"ms": round(kern_ms[k], 4), "GBps": round(alg[k] / (kern_ms[k] * 1e-3) / 1e9, 1) if kern_ms[k] > 0 else 0.0}
