@@ -47,7 +47,6 @@ KERNELS = (
     ("depth_order", "depth_order"),
     ("bin_sorted", "bin_sorted"),
     ("rasterize_forward", "raster_fwd"),
-    ("rasterize_forward_drawn", "raster_fwd"),
     ("rasterize_backward", "raster_bwd"),
     ("compute_sh_backward", "sh_bwd"),
     ("project_gaussians_backward", "project_bwd"),
