@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--scale-lo", type=float, default=0.0025)
     ap.add_argument("--scale-hi", type=float, default=0.025)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-every", type=int, default=5,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="bracket the native calls with HIP events on every k-th timed step (0: never, 1: all)")
     # co-gs / eval pattern (BASELINE config 5): a second rasterisation of the depths with
     # zero background (depth_gs.py:99, vanilla_gs.py:839-855), differentiable, in the step
