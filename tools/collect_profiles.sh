@@ -2,7 +2,7 @@
 # Collects the rocprofv3 evidence for profiles/ on a GPU box (run through gpurun):
 #   tools/collect_profiles.sh <tag>        e.g. r01
 # 1. kernel trace + stats of the default bench command  -> <tag>_kernel_stats.csv, <tag>_kernel_trace_summary.{json,txt}
-# 2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ busy) -> <tag>_pmc_*.{json,txt}
+# 2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ busy, LDS) -> <tag>_pmc_*.{json,txt}
 # 3. traffic.json: HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 correction,
 #    MI355X_MICROARCH.md HBM section)
 # PMC passes never combine with other trace domains (only --kernel-trace).
@@ -28,6 +28,9 @@ done
 rm -rf /tmp/prof_sq
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_sq -- $BENCH --steps 4 --warmup 2 > "$OUT/prof_sq.log" 2>&1
 python "$ROOT/tools/summarize_prof.py" /tmp/prof_sq "$OUT/${TAG}_pmc_sq.json" > "$OUT/${TAG}_pmc_sq.txt"
+rm -rf /tmp/prof_lds
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -d /tmp/prof_lds -- $BENCH --steps 4 --warmup 2 > "$OUT/prof_lds.log" 2>&1
+python "$ROOT/tools/summarize_prof.py" /tmp/prof_lds "$OUT/${TAG}_pmc_lds.json" > "$OUT/${TAG}_pmc_lds.txt"
 
 python - "$OUT" "$TAG" <<'PY'
 import json, sys
