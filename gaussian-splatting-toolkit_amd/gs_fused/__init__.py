@@ -1,7 +1,8 @@
 """Fused caller-side ops next to the rasterizer (SURVEY.md 8f "next" rows): the
 photometric loss head (f2), the one-launch Adam step (f1) and SH colours from
-split coefficients (f4).  Same native library and C ABI (`include/gsraster.h`)
+split coefficients and the per-Gaussian activations (f4).  Same native library and C ABI (`include/gsraster.h`)
 as `rasterizer`; no CPU fallback."""
 from .loss import L1SSIMLoss, l1_ssim_loss  # noqa: F401
 from .adam import FusedAdam  # noqa: F401
 from .sh import spherical_harmonics_split  # noqa: F401
+from .activations import activate_gaussians  # noqa: F401

@@ -1,0 +1,80 @@
+"""The per-Gaussian activations in front of the rasterizer in one launch.
+
+GaussianSplattingModel.get_outputs (gs_toolkit/models/vanilla_gs.py:765-826) runs
+
+    torch.exp(scales_crop);  quats_crop / quats_crop.norm(dim=-1, keepdim=True)
+    torch.sigmoid(opacities_crop)
+    viewdirs = means_crop.detach() - camera_position;  viewdirs / viewdirs.norm(...)
+
+as ~9 small launches forward and ~12 backward per iteration.  `activate_gaussians`
+returns the same four tensors from one kernel (`gsr_activate_forward`) and
+back-propagates through the first three with one kernel (`gsr_activate_backward`).
+"""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+from rasterizer.cuda import _call, _check, _ptr, _stream
+
+_f32 = torch.float32
+
+
+class _Activate(Function):
+    @staticmethod
+    def forward(ctx, means, log_scales, raw_quats, opacity_logits, campos):
+        n = log_scales.shape[0]
+        for t, nm in ((log_scales, "scales"), (raw_quats, "quats"), (opacity_logits, "opacities")):
+            _check(t, nm, _f32)
+        dev = log_scales.device
+        want_dirs = campos is not None
+        if want_dirs:
+            _check(means, "means", _f32)
+            _check(campos, "camera_position", _f32)
+        with torch.cuda.device(dev):
+            scales = torch.empty_like(log_scales)
+            quats = torch.empty_like(raw_quats)
+            opac = torch.empty_like(opacity_logits)
+            dirs = torch.empty((n, 3), dtype=_f32, device=dev) if want_dirs else None
+            _call("gsr_activate_forward", C.c_int(n), _ptr(means) if want_dirs else None, _ptr(log_scales),
+                  _ptr(raw_quats), _ptr(opacity_logits), _ptr(campos) if want_dirs else None, _ptr(scales),
+                  _ptr(quats), _ptr(opac), _ptr(dirs) if want_dirs else None, _stream(dev))
+        ctx.save_for_backward(raw_quats, scales, quats, opac)
+        ctx.set_materialize_grads(False)
+        if want_dirs:
+            ctx.mark_non_differentiable(dirs)
+            return scales, quats, opac, dirs
+        return scales, quats, opac, None
+
+    @staticmethod
+    def backward(ctx, v_scales, v_quats, v_opac, _v_dirs):
+        raw_quats, scales, quats, opac = ctx.saved_tensors
+        n = scales.shape[0]
+        dev = scales.device
+        cot = [None if t is None else _check(t.contiguous(), nm, _f32)
+               for t, nm in ((v_scales, "v_scales"), (v_quats, "v_quats"), (v_opac, "v_opacities"))]
+        with torch.cuda.device(dev):
+            g_s = torch.empty_like(scales)
+            g_q = torch.empty_like(quats)
+            g_o = torch.empty_like(opac)
+            _call("gsr_activate_backward", C.c_int(n), _ptr(raw_quats), _ptr(scales), _ptr(quats), _ptr(opac),
+                  *[None if t is None else _ptr(t) for t in cot], _ptr(g_s), _ptr(g_q), _ptr(g_o), _stream(dev))
+        return None, g_s, g_q, g_o, None
+
+
+def activate_gaussians(means: Optional[Tensor], log_scales: Tensor, raw_quats: Tensor, opacity_logits: Tensor,
+                       camera_position: Optional[Tensor] = None
+                       ) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
+    """-> (exp(log_scales) [N,3], raw_quats / |raw_quats| [N,4], sigmoid(opacity_logits) [N,1],
+    normalised (means - camera_position) [N,3] or None).  Differentiable w.r.t. the three
+    parameter tensors; the view directions carry no gradient (as in the reference)."""
+    n = log_scales.shape[0]
+    if log_scales.shape != (n, 3) or raw_quats.shape != (n, 4) or opacity_logits.numel() != n:
+        raise ValueError("expected scales [N,3], quats [N,4], opacities [N,1]")
+    if camera_position is not None and (means is None or means.shape != (n, 3) or camera_position.numel() != 3):
+        raise ValueError("view directions need means [N,3] and a camera position [3]")
+    return _Activate.apply(means.detach().contiguous() if camera_position is not None else None,
+                           log_scales.contiguous(), raw_quats.contiguous(), opacity_logits.contiguous(),
+                           camera_position.contiguous() if camera_position is not None else None)

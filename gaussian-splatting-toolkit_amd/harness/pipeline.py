@@ -53,6 +53,7 @@ def render_view(
     render_depth: bool = False,
     retain_xys_grad: bool = False,
     clamp_rgb: bool = True,
+    viewdirs: Optional[torch.Tensor] = None,  # normalised means3d - campos, if the caller already has them
 ) -> Dict[str, Optional[torch.Tensor]]:
     H, W = cam.height, cam.width
     xys, depths, radii, conics, comp, num_tiles_hit, cov3d = project_gaussians(
@@ -62,8 +63,9 @@ def render_view(
     if retain_xys_grad and xys.requires_grad:
         xys.retain_grad()  # densification reads xys.grad (vanilla_gs.py:352-353,797-798)
 
-    viewdirs = means3d.detach() - cam.campos
-    viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+    if viewdirs is None:
+        viewdirs = means3d.detach() - cam.campos
+        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
     if isinstance(sh_coeffs, (tuple, list)):
         from gs_fused import spherical_harmonics_split
 

@@ -80,6 +80,7 @@ def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale
 
 class GaussianParams(torch.nn.Module):
     split_sh = True  # evaluate SH from (features_dc, features_rest) without torch.cat
+    fused_activations = True  # exp / normalise / sigmoid / view directions in one launch (gs_fused)
 
     def __init__(self, raw: Dict[str, np.ndarray], device):
         super().__init__()
@@ -100,10 +101,17 @@ class GaussianParams(torch.nn.Module):
             coeffs = (g["features_dc"], g["features_rest"])  # gs_fused.spherical_harmonics_split
         else:
             coeffs = torch.cat((g["features_dc"][:, None, :], g["features_rest"]), dim=1)
-        return render_view(
-            g["means"], torch.exp(g["scales"]), g["quats"] / g["quats"].norm(dim=-1, keepdim=True),
-            torch.sigmoid(g["opacities"]), coeffs, cam, background, sh_degree_to_use,
-            render_depth=render_depth, retain_xys_grad=retain_xys_grad)
+        if self.fused_activations and g["means"].is_cuda:
+            from gs_fused import activate_gaussians
+
+            scales, quats, opac, dirs = activate_gaussians(g["means"], g["scales"], g["quats"], g["opacities"],
+                                                           cam.campos)
+        else:
+            scales = torch.exp(g["scales"])
+            quats = g["quats"] / g["quats"].norm(dim=-1, keepdim=True)
+            opac, dirs = torch.sigmoid(g["opacities"]), None
+        return render_view(g["means"], scales, quats, opac, coeffs, cam, background, sh_degree_to_use,
+                           render_depth=render_depth, retain_xys_grad=retain_xys_grad, viewdirs=dirs)
 
 
 def _gauss_window(size=11, sigma=1.5, device="cpu"):
@@ -151,6 +159,7 @@ class TrainConfig:
     fused_adam: bool = True   # gs_fused.FusedAdam: all six parameter groups in one HIP launch
     torch_fused_adam: bool = False  # (A/B) torch's own fused multi-tensor Adam instead
     split_sh: bool = True     # gs_fused.spherical_harmonics_split instead of torch.cat + spherical_harmonics
+    fused_activations: bool = True  # gs_fused.activate_gaussians instead of exp / normalise / sigmoid / viewdirs
 
 
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
@@ -173,6 +182,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     raw["opacities"] -= 0.5
     model = GaussianParams(raw, device)
     model.split_sh = truth.split_sh = cfg.split_sh
+    model.fused_activations = truth.fused_activations = cfg.fused_activations
     if cfg.fused_adam and device.type == "cuda":
         # one optimiser, six parameter groups with the reference's learning rates
         groups = [{"params": [model.gauss[k]], "lr": lr} for k, lr in LRS.items()]

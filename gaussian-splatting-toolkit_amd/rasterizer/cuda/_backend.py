@@ -44,6 +44,8 @@ SYMBOLS = (
     "gsr_l1_ssim_backward",
     "gsr_sh_forward_split",
     "gsr_sh_backward_split",
+    "gsr_activate_forward",
+    "gsr_activate_backward",
     "gsr_adam_step",
 )
 

@@ -280,6 +280,26 @@ int gsr_sh_backward_split(unsigned num_points, unsigned degree,
                           const float *v_colors, float *v_dc, float *v_rest,
                           gsr_stream_t stream);
 
+/* ---- per-Gaussian activations (caller-side glue) ----------
+ * exp(scales), quats / |quats|, sigmoid(opacities) and the normalised view
+ * directions means - camera_position of GaussianSplattingModel.get_outputs
+ * (gs_toolkit/models/vanilla_gs.py:765-826) in one launch, and their VJP in one
+ * launch.  camera_position: 3 floats on the device (may be NULL together with
+ * viewdirs).  Backward: v_scales / v_quats / v_opacities may each be NULL (= 0);
+ * no gradient flows to the view directions (the reference detaches the means). */
+int gsr_activate_forward(int num_points, const float *means,
+                         const float *log_scales, const float *raw_quats,
+                         const float *opacity_logits,
+                         const float *camera_position, float *scales,
+                         float *quats, float *opacities, float *viewdirs,
+                         gsr_stream_t stream);
+int gsr_activate_backward(int num_points, const float *raw_quats,
+                          const float *scales, const float *quats,
+                          const float *opacities, const float *v_scales,
+                          const float *v_quats, const float *v_opacities,
+                          float *v_log_scales, float *v_raw_quats,
+                          float *v_logits, gsr_stream_t stream);
+
 /* ---- optimiser step ------------------------------------
  * Adam over up to GSR_ADAM_MAX_TENSORS tensors in one launch; replaces the
  * per-group torch.optim.Adam objects the toolkit builds

@@ -493,3 +493,41 @@ def test_split_sh_equals_cat(K, use, n):
         ref.backward(cu(v))
         assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
         assert np.abs(got - c.grad.cpu().numpy()).max() < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 257, 10_000])
+def test_activate_gaussians_equals_torch_ops(n):
+    """gs_fused.activate_gaussians == exp / normalise / sigmoid / normalised view
+    directions of get_outputs, values and gradients (incl. unused cotangents)."""
+    from gs_fused import activate_gaussians
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    means = torch.randn(n, 3, generator=g).to(DEV)
+    ls = (torch.randn(n, 3, generator=g) - 3).to(DEV).requires_grad_(True)
+    rq = torch.randn(n, 4, generator=g).to(DEV).requires_grad_(True)
+    lo = torch.randn(n, 1, generator=g).to(DEV).requires_grad_(True)
+    campos = torch.tensor([0.3, -2.0, 5.0], device=DEV)
+    s, q, o, d = activate_gaussians(means, ls, rq, lo, campos)
+    ls2, rq2, lo2 = (t.detach().clone().requires_grad_(True) for t in (ls, rq, lo))
+    s2, q2, o2 = torch.exp(ls2), rq2 / rq2.norm(dim=-1, keepdim=True), torch.sigmoid(lo2)
+    d2 = means - campos
+    d2 = d2 / d2.norm(dim=-1, keepdim=True)
+    for a, b in ((s, s2), (q, q2), (o, o2), (d, d2)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    assert not d.requires_grad
+    ws, wq, wo = torch.randn_like(s), torch.randn_like(q), torch.randn_like(o)
+    ((s * ws).sum() + (q * wq).sum() + (o * wo).sum()).backward()
+    ((s2 * ws).sum() + (q2 * wq).sum() + (o2 * wo).sum()).backward()
+    for a, b in ((ls, ls2), (rq, rq2), (lo, lo2)):
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6)
+    # only one output used: the other cotangents arrive as None
+    ls.grad = rq.grad = lo.grad = None
+    s, q, o, d = activate_gaussians(None, ls, rq, lo)
+    assert d is None
+    (q * wq).sum().backward()
+    rq3 = rq.detach().clone().requires_grad_(True)
+    ((rq3 / rq3.norm(dim=-1, keepdim=True)) * wq).sum().backward()
+    assert torch.allclose(rq.grad, rq3.grad, rtol=1e-5, atol=1e-6)
+    assert float(ls.grad.abs().max()) == 0.0 and float(lo.grad.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        activate_gaussians(means, ls, rq[:, :3], lo)

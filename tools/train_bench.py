@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--torch-activations", action="store_true", help="A/B: torch ops for exp/normalise/sigmoid/viewdirs")
     ap.add_argument("--cat-sh", action="store_true", help="A/B: torch.cat + spherical_harmonics instead of the split op")
     ap.add_argument("--torch-fused-adam", action="store_true", help="A/B: torch's fused Adam instead of gs_fused.FusedAdam")
     args = ap.parse_args()
@@ -47,7 +48,7 @@ def main():
             dist.init_process_group("gloo")
     cfg = TrainConfig(num_gaussians=args.gaussians, width=args.width, height=args.height,
                       num_views=args.views, iters=args.iters, sh_degree_interval=max(1, args.iters // 4),
-                      torch_fused_adam=args.torch_fused_adam, split_sh=not args.cat_sh)
+                      torch_fused_adam=args.torch_fused_adam, split_sh=not args.cat_sh, fused_activations=not args.torch_activations)
     res = train(cfg, dev, rank, world)
     if world > 1:
         cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
