@@ -37,12 +37,18 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 // img: [H,W,3] interleaved.  maps: [3 derivative kinds][3 channels][Hv][Wv] planar.
 // sums[0] += sum |x-y| over the tile's own pixels, sums[1] += sum S over its valid outputs.
+// clamp_pred: the prediction is min(pred, 1) (the models clamp the rendered image at 1
+// before the loss, vanilla_gs.py:857 `torch.clamp(rgb, max=1.0)`; folding it in here
+// saves that op and its three-kernel backward).
+// *loss_out and terms_out[2] = {L1 mean, SSIM mean}: written by the workgroup that finishes last.
 __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(
-    const int H, const int W, const float *__restrict__ pred, const float *__restrict__ gt,
-    float *__restrict__ maps, double *__restrict__ sums) {
+    const int H, const int W, const float lambda, const int clamp_pred, const float *__restrict__ pred,
+    const float *__restrict__ gt, float *__restrict__ maps, double *__restrict__ sums,
+    float *__restrict__ loss_out, float *__restrict__ terms_out) {
   __shared__ float sx[kIH][kIW + 1], sy[kIH][kIW + 1];
   __shared__ float hb[5][kIH][kTW + 1];
   __shared__ float red[2][4];
+  __shared__ bool last_block;
 
   const int Hv = H - kHalo, Wv = W - kHalo;
   const int c = blockIdx.z;
@@ -57,6 +63,7 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(
     if (gy < H && gx < W) {
       const size_t o = ((size_t)gy * W + gx) * 3 + c;
       x = pred[o];
+      if (clamp_pred) x = fminf(x, 1.f);
       y = gt[o];
       if (r < kTH && q < kTW) l1 += fabsf(x - y);  // every pixel belongs to exactly one tile
     }
@@ -129,18 +136,47 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(
     red[1][tid >> 6] = ssum;
   }
   __syncthreads();
+  if (tid == 0) last_block = false;
   if (tid == 0) {
     // GSR_LOSS_SUM_SLOTS partial sums per quantity: 12 k workgroups adding doubles to the
     // same two addresses serialised in the L2 (that alone was ~250 us of this kernel)
     const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u) % GSR_LOSS_SUM_SLOTS;
     atomicAdd(&sums[slot], (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
     atomicAdd(&sums[GSR_LOSS_SUM_SLOTS + slot], (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    // the last workgroup to get here turns the partial sums into the three scalars
+    __threadfence();
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    unsigned *counter = reinterpret_cast<unsigned *>(sums + 2 * GSR_LOSS_SUM_SLOTS);
+    last_block = atomicAdd(counter, 1u) == total - 1u;
+  }
+  __syncthreads();
+  if (last_block && tid < 64) {
+    __threadfence();
+    double a = 0.0, b = 0.0;
+    for (int k = tid; k < GSR_LOSS_SUM_SLOTS; k += 64) {
+      a += __hip_atomic_load(&sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      b += __hip_atomic_load(&sums[GSR_LOSS_SUM_SLOTS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    if (tid == 0) {
+      const double l1m = a / (3.0 * (double)H * (double)W);
+      const double ssm = b / (3.0 * (double)(H - kHalo) * (double)(W - kHalo));
+      *loss_out = (float)((1.0 - (double)lambda) * l1m + (double)lambda * (1.0 - ssm));
+      if (terms_out) {
+        terms_out[0] = (float)l1m;
+        terms_out[1] = (float)ssm;
+      }
+    }
   }
 }
 
 // v_pred = up * [ (1-lambda) sign(x-y)/(3HW) - lambda/(3 Hv Wv) * ( blurT(Dmu) + 2x blurT(D11) + y blurT(D12) ) ]
 __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(
-    const int H, const int W, const float lambda, const float *__restrict__ upstream,
+    const int H, const int W, const float lambda, const int clamp_pred, const float *__restrict__ upstream,
     const float *__restrict__ pred, const float *__restrict__ gt, const float *__restrict__ maps,
     float *__restrict__ v_pred) {
   __shared__ float sm[3][kIH][kIW + 1];
@@ -200,36 +236,39 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(
       g2 += w * hb[2][r + kHalo - k][q];
     }
     const size_t o = ((size_t)gy * W + gx) * 3 + c;
-    const float x = pred[o], y = gt[o];
+    const float xr = pred[o], y = gt[o];
+    const float x = clamp_pred ? fminf(xr, 1.f) : xr;
     const float d = x - y;
     const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    v_pred[o] = k_l1 * sgn + k_ss * (g0 + 2.f * x * g1 + y * g2);
+    const float g = k_l1 * sgn + k_ss * (g0 + 2.f * x * g1 + y * g2);
+    v_pred[o] = (clamp_pred && xr > 1.f) ? 0.f : g;  // clamp(max=1) passes the gradient where pred <= 1
   }
 }
 
 }  // namespace
 
-GSR_EXPORT int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width, const float *pred,
-                                   const float *gt, float *maps, double *sums, gsr_stream_t stream) {
+GSR_EXPORT int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width, float ssim_lambda,
+                                   int clamp_pred, const float *pred, const float *gt, float *maps,
+                                   double *sums, float *loss_out, float *terms_out, gsr_stream_t stream) {
   GSR_REQUIRE(img_height > kHalo && img_width > kHalo, "l1_ssim_forward: image must be larger than 10x10");
-  GSR_REQUIRE(pred && gt && maps && sums, "l1_ssim_forward: null pointer");
+  GSR_REQUIRE(pred && gt && maps && sums && loss_out, "l1_ssim_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, 2 * GSR_LOSS_SUM_SLOTS * sizeof(double), s));
+  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, GSR_LOSS_WORKSPACE_DOUBLES * sizeof(double), s));
   const dim3 grd(gsr_cdiv(img_width, kTW), gsr_cdiv(img_height, kTH), 3);
-  hipLaunchKernelGGL(l1_ssim_fwd_kernel, grd, dim3(256), 0, s, (int)img_height, (int)img_width, pred, gt,
-                     maps, sums);
+  hipLaunchKernelGGL(l1_ssim_fwd_kernel, grd, dim3(256), 0, s, (int)img_height, (int)img_width, ssim_lambda,
+                     clamp_pred, pred, gt, maps, sums, loss_out, terms_out);
   GSR_CHECK_LAUNCH("l1_ssim_forward");
   return GSR_OK;
 }
 
 GSR_EXPORT int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width, float ssim_lambda,
-                                    const float *upstream, const float *pred, const float *gt,
+                                    int clamp_pred, const float *upstream, const float *pred, const float *gt,
                                     const float *maps, float *v_pred, gsr_stream_t stream) {
   GSR_REQUIRE(img_height > kHalo && img_width > kHalo, "l1_ssim_backward: image must be larger than 10x10");
   GSR_REQUIRE(upstream && pred && gt && maps && v_pred, "l1_ssim_backward: null pointer");
   const dim3 grd(gsr_cdiv(img_width, kTW), gsr_cdiv(img_height, kTH), 3);
   hipLaunchKernelGGL(l1_ssim_bwd_kernel, grd, dim3(256), 0, (hipStream_t)stream, (int)img_height,
-                     (int)img_width, ssim_lambda, upstream, pred, gt, maps, v_pred);
+                     (int)img_width, ssim_lambda, clamp_pred, upstream, pred, gt, maps, v_pred);
   GSR_CHECK_LAUNCH("l1_ssim_backward");
   return GSR_OK;
 }

@@ -5,4 +5,4 @@ as `rasterizer`; no CPU fallback."""
 from .loss import L1SSIMLoss, l1_ssim_loss  # noqa: F401
 from .adam import FusedAdam  # noqa: F401
 from .sh import spherical_harmonics_split  # noqa: F401
-from .activations import activate_gaussians  # noqa: F401
+from .activations import activate_gaussians, densify_stats_  # noqa: F401

@@ -78,3 +78,27 @@ def activate_gaussians(means: Optional[Tensor], log_scales: Tensor, raw_quats: T
     return _Activate.apply(means.detach().contiguous() if camera_position is not None else None,
                            log_scales.contiguous(), raw_quats.contiguous(), opacity_logits.contiguous(),
                            camera_position.contiguous() if camera_position is not None else None)
+
+
+@torch.no_grad()
+def densify_stats_(xys_grad: Optional[Tensor], radii: Tensor, image_size: int, xys_grad_norm: Tensor,
+                   vis_counts: Tensor, max_2dsize: Tensor) -> None:
+    """In place, for the Gaussians with ``radii > 0`` (GaussianSplattingModel.after_train,
+    vanilla_gs.py:344-372): ``xys_grad_norm += |xys_grad|``, ``vis_counts += 1``,
+    ``max_2dsize = max(max_2dsize, radii / image_size)`` -- one launch (``gsr_densify_stats``)."""
+    n = radii.numel()
+    _check(radii, "radii", torch.int32)
+    _check(xys_grad_norm, "xys_grad_norm", _f32)
+    _check(vis_counts, "vis_counts", torch.int32)
+    _check(max_2dsize, "max_2dsize", _f32)
+    if xys_grad is not None:
+        xys_grad = _check(xys_grad.contiguous(), "xys_grad", _f32)
+        if xys_grad.shape != (n, 2):
+            raise ValueError("xys_grad must be [N,2]")
+    if xys_grad_norm.numel() != n or vis_counts.numel() != n or max_2dsize.numel() != n:
+        raise ValueError("the accumulators must have N elements")
+    dev = radii.device
+    with torch.cuda.device(dev):
+        _call("gsr_densify_stats", C.c_int(n), _ptr(xys_grad) if xys_grad is not None else None, _ptr(radii),
+              C.c_float(1.0 / float(image_size)), _ptr(xys_grad_norm), _ptr(vis_counts), _ptr(max_2dsize),
+              _stream(dev))

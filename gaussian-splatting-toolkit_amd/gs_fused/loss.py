@@ -21,12 +21,12 @@ from torch.autograd import Function
 from rasterizer.cuda import _call, _check, _ptr, _stream
 
 _f32 = torch.float32
-SUM_SLOTS = 64  # GSR_LOSS_SUM_SLOTS (include/gsraster.h)
+WORKSPACE_DOUBLES = 2 * 64 + 1  # GSR_LOSS_WORKSPACE_DOUBLES (include/gsraster.h)
 
 
 class _L1SSIM(Function):
     @staticmethod
-    def forward(ctx, pred: Tensor, gt: Tensor, ssim_lambda: float):
+    def forward(ctx, pred: Tensor, gt: Tensor, ssim_lambda: float, clamp_pred: bool):
         if pred.dim() != 3 or pred.shape[-1] != 3 or pred.shape != gt.shape:
             raise ValueError(f"expected two [H,W,3] images, got {tuple(pred.shape)} and {tuple(gt.shape)}")
         H, W = int(pred.shape[0]), int(pred.shape[1])
@@ -37,46 +37,50 @@ class _L1SSIM(Function):
         dev = pred.device
         with torch.cuda.device(dev):
             maps = torch.empty((9, H - 10, W - 10), dtype=_f32, device=dev)
-            sums = torch.empty((2, SUM_SLOTS), dtype=torch.float64, device=dev)
-            _call("gsr_l1_ssim_forward", C.c_uint(H), C.c_uint(W), _ptr(pred), _ptr(gt), _ptr(maps),
-                  _ptr(sums), _stream(dev))
-        tot = sums.sum(dim=1)  # the kernel spreads its atomics over SUM_SLOTS partial sums
-        l1 = tot[0] / (3.0 * H * W)
-        ssim = tot[1] / (3.0 * (H - 10) * (W - 10))
-        loss = ((1.0 - ssim_lambda) * l1 + ssim_lambda * (1.0 - ssim)).to(_f32)
+            work = torch.empty((WORKSPACE_DOUBLES,), dtype=torch.float64, device=dev)
+            loss = torch.empty((), dtype=_f32, device=dev)
+            terms = torch.empty((2,), dtype=_f32, device=dev)  # L1 mean, SSIM mean
+            _call("gsr_l1_ssim_forward", C.c_uint(H), C.c_uint(W), C.c_float(ssim_lambda),
+                  C.c_int(1 if clamp_pred else 0), _ptr(pred), _ptr(gt), _ptr(maps), _ptr(work), _ptr(loss),
+                  _ptr(terms), _stream(dev))
         ctx.save_for_backward(pred, gt, maps)
         ctx.ssim_lambda = float(ssim_lambda)
+        ctx.clamp_pred = bool(clamp_pred)
         ctx.hw = (H, W)
-        l1, ssim = l1.to(_f32), ssim.to(_f32)
-        ctx.mark_non_differentiable(l1, ssim)
-        return loss, l1, ssim
+        ctx.mark_non_differentiable(terms)
+        return loss, terms
 
     @staticmethod
-    def backward(ctx, v_loss, v_l1, v_ssim):
+    def backward(ctx, v_loss, _v_terms):
         pred, gt, maps = ctx.saved_tensors
         H, W = ctx.hw
         dev = pred.device
         up = v_loss.to(_f32).reshape(1).contiguous()
         with torch.cuda.device(dev):
             v_pred = torch.empty_like(pred)
-            _call("gsr_l1_ssim_backward", C.c_uint(H), C.c_uint(W), C.c_float(ctx.ssim_lambda), _ptr(up),
-                  _ptr(pred), _ptr(gt), _ptr(maps), _ptr(v_pred), _stream(dev))
-        return v_pred, None, None
+            _call("gsr_l1_ssim_backward", C.c_uint(H), C.c_uint(W), C.c_float(ctx.ssim_lambda),
+                  C.c_int(1 if ctx.clamp_pred else 0), _ptr(up), _ptr(pred), _ptr(gt), _ptr(maps), _ptr(v_pred),
+                  _stream(dev))
+        return v_pred, None, None, None
 
 
-def l1_ssim_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2, return_terms: bool = False):
+def l1_ssim_loss(pred: Tensor, gt: Tensor, ssim_lambda: float = 0.2, return_terms: bool = False,
+                 clamp_pred: bool = False):
     """Scalar loss (fp32, on device).  With `return_terms`, also the L1 mean and the
-    SSIM value (detached diagnostics; gradients flow through the loss only)."""
-    loss, l1, ssim = _L1SSIM.apply(pred, gt, ssim_lambda)
+    SSIM value (detached diagnostics; gradients flow through the loss only).
+    `clamp_pred`: compute the loss of `torch.clamp(pred, max=1.0)` (what the models
+    feed it, vanilla_gs.py:857) without that op and its backward."""
+    loss, terms = _L1SSIM.apply(pred, gt, ssim_lambda, clamp_pred)
     if return_terms:
-        return loss, l1.detach(), ssim.detach()
+        return loss, terms[0], terms[1]
     return loss
 
 
 class L1SSIMLoss(torch.nn.Module):
-    def __init__(self, ssim_lambda: float = 0.2):
+    def __init__(self, ssim_lambda: float = 0.2, clamp_pred: bool = False):
         super().__init__()
         self.ssim_lambda = ssim_lambda
+        self.clamp_pred = clamp_pred
 
     def forward(self, pred: Tensor, gt: Tensor) -> Tensor:
-        return l1_ssim_loss(pred, gt, self.ssim_lambda)
+        return l1_ssim_loss(pred, gt, self.ssim_lambda, clamp_pred=self.clamp_pred)

@@ -20,6 +20,7 @@ The data side (cameras on a sphere, ground truth rendered by this rasterizer
 from a hidden "true" scene) replaces the toolkit's datamanager.
 """
 import math
+import os
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -95,7 +96,7 @@ class GaussianParams(torch.nn.Module):
         return [self.gauss[k] for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities")]
 
     def render(self, cam: CameraTensors, background, sh_degree_to_use: int, render_depth=False,
-               retain_xys_grad=False):
+               retain_xys_grad=False, clamp_rgb=True):
         g = self.gauss
         if self.split_sh and g["features_dc"].is_cuda and g["features_rest"].shape[1] in (3, 8, 15):
             coeffs = (g["features_dc"], g["features_rest"])  # gs_fused.spherical_harmonics_split
@@ -111,7 +112,8 @@ class GaussianParams(torch.nn.Module):
             quats = g["quats"] / g["quats"].norm(dim=-1, keepdim=True)
             opac, dirs = torch.sigmoid(g["opacities"]), None
         return render_view(g["means"], scales, quats, opac, coeffs, cam, background, sh_degree_to_use,
-                           render_depth=render_depth, retain_xys_grad=retain_xys_grad, viewdirs=dirs)
+                           render_depth=render_depth, retain_xys_grad=retain_xys_grad, viewdirs=dirs,
+                           clamp_rgb=clamp_rgb)
 
 
 def _gauss_window(size=11, sigma=1.5, device="cpu"):
@@ -195,14 +197,20 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     else:
         optims = {k: torch.optim.Adam([model.gauss[k]], lr=lr, eps=1e-15) for k, lr in LRS.items()}
     plist = model.param_list()
+    fused_clamp = False
     if cfg.fused_loss and device.type == "cuda":
         from gs_fused import l1_ssim_loss
 
-        loss_fn = lambda pred, target: l1_ssim_loss(pred, target, cfg.ssim_lambda)
+        # the clamp of the rendered image at 1 (vanilla_gs.py:857) is folded into the loss kernels
+        fused_clamp = os.environ.get("GSR_AB_LOSS_CLAMP", "1") != "0"
+        loss_fn = lambda pred, target: l1_ssim_loss(pred, target, cfg.ssim_lambda, clamp_pred=fused_clamp)
     else:
         loss_fn = lambda pred, target: ((1 - cfg.ssim_lambda) * (pred - target).abs().mean()
                                         + cfg.ssim_lambda * (1 - ssim(pred, target)))
 
+    fused_stats = cfg.fused_activations and device.type == "cuda" and os.environ.get("GSR_AB_STATS", "1") != "0"
+    if fused_stats:
+        from gs_fused import densify_stats_
     n = model.num_points
     xys_grad_norm = torch.zeros(n, device=device)
     vis_counts = torch.zeros(n, device=device, dtype=torch.int32)
@@ -225,18 +233,23 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         for o in optims.values():
             o.zero_grad(set_to_none=True)
         deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
-        out = model.render(cams[v], bg, deg, retain_xys_grad=True)
+        out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp)
         rgb = out["rgb"]
         loss = loss_fn(rgb, gt[v])
         loss.backward()
         # densification statistics (vanilla_gs.py:344-372)
-        with torch.no_grad():
-            visible = out["radii"] > 0
-            g = out["xys"].grad
-            if g is not None:
-                xys_grad_norm += torch.where(visible, g.norm(dim=-1), torch.zeros_like(xys_grad_norm))
-            vis_counts += visible.to(torch.int32)
-            max_2dsize = torch.maximum(max_2dsize, out["radii"].float() / max(cfg.width, cfg.height))
+        if fused_stats:
+            densify_stats_(out["xys"].grad, out["radii"], max(cfg.width, cfg.height), xys_grad_norm, vis_counts,
+                           max_2dsize)
+        else:
+            with torch.no_grad():
+                visible = out["radii"] > 0
+                g = out["xys"].grad
+                if g is not None:
+                    xys_grad_norm += torch.where(visible, g.norm(dim=-1), torch.zeros_like(xys_grad_norm))
+                vis_counts += visible.to(torch.int32)
+                max_2dsize = torch.where(visible, torch.maximum(
+                    max_2dsize, out["radii"].float() / max(cfg.width, cfg.height)), max_2dsize)
         if world > 1:
             allreduce_gradients(plist, average=True)
         for o in optims.values():

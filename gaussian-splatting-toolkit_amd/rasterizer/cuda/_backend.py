@@ -46,6 +46,7 @@ SYMBOLS = (
     "gsr_sh_backward_split",
     "gsr_activate_forward",
     "gsr_activate_backward",
+    "gsr_densify_stats",
     "gsr_adam_step",
 )
 

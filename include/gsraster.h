@@ -249,20 +249,25 @@ int gsr_cov2d_bounds(int num_pts, const float *cov2d, float *conics,
  * `torch.abs(gt - pred).mean()` + `1 - pytorch_msssim.SSIM(data_range=1,
  * size_average=True, channel=3)(gt, pred)` and their autograd backward.
  * pred, gt: [H,W,3] fp32.  maps: scratch [9, H-10, W-10] fp32 written by the
- * forward and consumed by the backward.  sums: 2 x GSR_LOSS_SUM_SLOTS doubles,
- * zeroed by the call: partial sums (one slot per group of workgroups, so that
- * the atomics do not serialise on one address); S0 = sum of sums[0..SLOTS) =
- * sum |pred-gt|, S1 = sum of sums[SLOTS..2 SLOTS) = sum of the SSIM map; the caller
- * forms loss = (1-l)*S0/(3HW) + l*(1 - S1/(3(H-10)(W-10))).
+ * forward and consumed by the backward.  sums: workspace of
+ * GSR_LOSS_WORKSPACE_DOUBLES doubles (partial sums in GSR_LOSS_SUM_SLOTS slots each,
+ * so that the atomics do not serialise on one address, plus a completion counter),
+ * zeroed by the call.  *loss_out = (1-l)*L1 + l*(1 - SSIM) and terms_out[2] =
+ * {L1 = mean |pred-gt|, SSIM mean} (terms_out may be NULL), written by the
+ * workgroup that finishes last.  clamp_pred != 0: the prediction is min(pred, 1), as after the models'
+ * `torch.clamp(rgb, max=1.0)`, and the gradient is zero where pred > 1.
  * backward: v_pred[H,W,3] = upstream[0] * d loss / d pred (upstream on device). */
 #define GSR_LOSS_SUM_SLOTS 64
+#define GSR_LOSS_WORKSPACE_DOUBLES (2 * GSR_LOSS_SUM_SLOTS + 1)
 int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width,
-                        const float *pred, const float *gt, float *maps,
-                        double *sums, gsr_stream_t stream);
+                        float ssim_lambda, int clamp_pred, const float *pred,
+                        const float *gt, float *maps, double *sums,
+                        float *loss_out, float *terms_out, gsr_stream_t stream);
 int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width,
-                         float ssim_lambda, const float *upstream,
-                         const float *pred, const float *gt, const float *maps,
-                         float *v_pred, gsr_stream_t stream);
+                         float ssim_lambda, int clamp_pred,
+                         const float *upstream, const float *pred,
+                         const float *gt, const float *maps, float *v_pred,
+                         gsr_stream_t stream);
 
 /* ---- SH colours from split coefficients (caller-side glue) --
  * gsr_sh_forward / gsr_sh_backward for models that keep the DC band and the
@@ -299,6 +304,16 @@ int gsr_activate_backward(int num_points, const float *raw_quats,
                           const float *v_quats, const float *v_opacities,
                           float *v_log_scales, float *v_raw_quats,
                           float *v_logits, gsr_stream_t stream);
+
+/* ---- densification statistics -----------------------------
+ * GaussianSplattingModel.after_train (gs_toolkit/models/vanilla_gs.py:344-372) in
+ * one launch: for every Gaussian with radii > 0,
+ *   xys_grad_norm += |v_xys| (skipped if v_xys is NULL), vis_counts += 1,
+ *   max_2dsize = max(max_2dsize, radii * inv_size),   inv_size = 1 / max(W, H). */
+int gsr_densify_stats(int num_points, const float *v_xys, const int32_t *radii,
+                      float inv_size, float *xys_grad_norm,
+                      int32_t *vis_counts, float *max_2dsize,
+                      gsr_stream_t stream);
 
 /* ---- optimiser step ------------------------------------
  * Adam over up to GSR_ADAM_MAX_TENSORS tensors in one launch; replaces the

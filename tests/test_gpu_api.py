@@ -531,3 +531,26 @@ def test_activate_gaussians_equals_torch_ops(n):
     assert float(ls.grad.abs().max()) == 0.0 and float(lo.grad.abs().max()) == 0.0
     with pytest.raises(ValueError):
         activate_gaussians(means, ls, rq[:, :3], lo)
+
+
+def test_densify_stats_kernel():
+    """gs_fused.densify_stats_ == the masked updates of after_train (vanilla_gs.py:344-372)."""
+    from gs_fused import densify_stats_
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = 10_001
+    grad = torch.randn(n, 2, generator=g).to(DEV)
+    radii = torch.randint(-1, 40, (n,), generator=g, dtype=torch.int32).to(DEV)
+    norm = torch.rand(n, generator=g).to(DEV)
+    cnt = torch.randint(0, 5, (n,), generator=g, dtype=torch.int32).to(DEV)
+    mx = (torch.rand(n, generator=g) * 0.02).to(DEV)
+    vis = radii > 0
+    want_norm = norm + torch.where(vis, grad.norm(dim=-1), torch.zeros_like(norm))
+    want_cnt = cnt + vis.to(torch.int32)
+    want_mx = torch.where(vis, torch.maximum(mx, radii.float() / 1920.0), mx)
+    densify_stats_(grad, radii, 1920, norm, cnt, mx)
+    assert torch.allclose(norm, want_norm, rtol=1e-6, atol=1e-7) and torch.equal(cnt, want_cnt)
+    assert torch.allclose(mx, want_mx, rtol=1e-6, atol=0)
+    before = norm.clone()
+    densify_stats_(None, radii, 1920, norm, cnt, mx)  # no gradient this step: counts only
+    assert torch.equal(norm, before) and torch.equal(cnt, want_cnt + vis.to(torch.int32))

@@ -81,3 +81,26 @@ def test_loss_errors():
         l1_ssim_loss(torch.zeros(20, 20, 3, device="cuda"), torch.zeros(20, 21, 3, device="cuda"))
     with pytest.raises(RuntimeError):
         l1_ssim_loss(torch.zeros(20, 20, 3), torch.zeros(20, 20, 3))
+
+
+@pytest.mark.gpu
+def test_clamp_pred_equals_torch_clamp():
+    """l1_ssim_loss(pred, gt, clamp_pred=True) == l1_ssim_loss(torch.clamp(pred, max=1), gt),
+    value and gradient (zero where pred > 1)."""
+    import torch
+
+    from gs_fused import l1_ssim_loss
+
+    rng = np.random.default_rng(5)
+    H, W = 97, 131
+    gt = torch.from_numpy(rng.uniform(0, 1, (H, W, 3)).astype(np.float32)).cuda()
+    base = torch.from_numpy(rng.uniform(0, 1.4, (H, W, 3)).astype(np.float32)).cuda()
+    a = base.clone().requires_grad_(True)
+    b = base.clone().requires_grad_(True)
+    la, l1a, sa = l1_ssim_loss(a, gt, 0.2, return_terms=True, clamp_pred=True)
+    lb, l1b, sb = l1_ssim_loss(torch.clamp(b, max=1.0), gt, 0.2, return_terms=True)
+    assert abs(float(la) - float(lb)) < 1e-6 and abs(float(l1a) - float(l1b)) < 1e-6 and abs(float(sa) - float(sb)) < 1e-6
+    la.backward()
+    lb.backward()
+    assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-9)
+    assert float(a.grad[base > 1].abs().max()) == 0.0 and int((base > 1).sum()) > 1000
