@@ -338,6 +338,17 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   return GSR_OK;
 }
 
+namespace {
+__global__ void publish_int_kernel(const int *__restrict__ src, int *__restrict__ dst) { *dst = *src; }
+}  // namespace
+
+GSR_EXPORT int gsr_publish_int32(const int32_t *src, int32_t *dst, gsr_stream_t stream) {
+  GSR_REQUIRE(src && dst, "publish_int32: null pointer");
+  hipLaunchKernelGGL(publish_int_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, src, dst);
+  GSR_CHECK_LAUNCH("publish_int32");
+  return GSR_OK;
+}
+
 GSR_EXPORT size_t gsr_reach_record_bytes(void) { return sizeof(SplatRec); }
 
 GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *radii, const float *conics,

@@ -253,6 +253,17 @@ def depth_order(depths: Tensor, radii: Tensor, num_tiles_hit: Tensor) -> Tuple[T
     return order, cum
 
 
+def publish_int32(src: Tensor, dst: Tensor) -> None:
+    """``gsr_publish_int32``: ``dst[0] = src[0]`` by a one-thread kernel in stream order;
+    ``dst`` may be pinned host memory (int32)."""
+    _check(src, "src", _i32)
+    if dst.dtype != _i32 or dst.numel() < 1:
+        raise RuntimeError("publish_int32: dst must be int32")
+    dev = src.device
+    with torch.cuda.device(dev):
+        _call("gsr_publish_int32", _ptr(src), _ptr(dst), _stream(dev))
+
+
 def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
                 tile_bounds: Tuple[int, int, int]) -> Tuple[Tensor, Tensor]:
     """``gsr_count_reach``: per Gaussian, the number of 16x16 tiles of its bounding

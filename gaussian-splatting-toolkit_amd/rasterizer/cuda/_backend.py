@@ -35,6 +35,7 @@ SYMBOLS = (
     "gsr_bin_sorted_workspace_bytes",
     "gsr_bin_sorted",
     "gsr_bin_sorted_dev",
+    "gsr_publish_int32",
     "gsr_rasterize_forward",
     "gsr_rasterize_backward",
     "gsr_rasterize_forward_nd",

@@ -204,13 +204,17 @@ class _RasterizeGaussians(Function):
                 # size the lists from the previous view instead of waiting for the
                 # count to reach the host (utils.py:124); checked after compositing
                 # has been enqueued
+                # (the count goes to the host right behind the depth-order scan, before the lists
+                # are built: the host wakes up early enough to queue the loss and the backward
+                # while the GPU is still compositing)
                 pending = _PendingCount(xys.device)
+                _C.publish_int32(cum_sorted[-1:], pending.buf)
+                pending.mark()
                 num_intersects = None
                 gaussian_ids_sorted, tile_bins = _C.bin_sorted(
                     num_points, capacity, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
-                    device_sized=True, count_out=pending.buf,
+                    device_sized=True,
                 )
-                pending.mark()
             else:
                 num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
                 _note_count(xys.device, num_points, tile_bounds, num_intersects)

@@ -163,6 +163,12 @@ int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                    int32_t *gaussian_ids_sorted, int32_t *tile_bins,
                    void *workspace, size_t workspace_bytes, gsr_stream_t stream);
 
+/* One int32 from device memory to any device-accessible address, e.g. pinned
+ * host memory mapped into the device's address space: a one-thread kernel in
+ * stream order instead of a copy operation.  Used to hand cum_sorted[n-1] to the
+ * host as early as possible (right after gsr_depth_order). */
+int gsr_publish_int32(const int32_t *src, int32_t *dst, gsr_stream_t stream);
+
 /* gsr_bin_sorted without the host knowing the number of intersections: the
  * length of the lists is read on the device (cum_sorted[num_points-1], as
  * written by gsr_depth_order) and `capacity` is what gaussian_ids_sorted and the
