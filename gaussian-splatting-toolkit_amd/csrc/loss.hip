@@ -40,15 +40,12 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 // clamp_pred: the prediction is min(pred, 1) (the models clamp the rendered image at 1
 // before the loss, vanilla_gs.py:857 `torch.clamp(rgb, max=1.0)`; folding it in here
 // saves that op and its three-kernel backward).
-// *loss_out and terms_out[2] = {L1 mean, SSIM mean}: written by the workgroup that finishes last.
 __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(
     const int H, const int W, const float lambda, const int clamp_pred, const float *__restrict__ pred,
-    const float *__restrict__ gt, float *__restrict__ maps, double *__restrict__ sums,
-    float *__restrict__ loss_out, float *__restrict__ terms_out) {
+    const float *__restrict__ gt, float *__restrict__ maps, double *__restrict__ sums) {
   __shared__ float sx[kIH][kIW + 1], sy[kIH][kIW + 1];
   __shared__ float hb[5][kIH][kTW + 1];
   __shared__ float red[2][4];
-  __shared__ bool last_block;
 
   const int Hv = H - kHalo, Wv = W - kHalo;
   const int c = blockIdx.z;
@@ -136,40 +133,41 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(
     red[1][tid >> 6] = ssum;
   }
   __syncthreads();
-  if (tid == 0) last_block = false;
   if (tid == 0) {
     // GSR_LOSS_SUM_SLOTS partial sums per quantity: 12 k workgroups adding doubles to the
     // same two addresses serialised in the L2 (that alone was ~250 us of this kernel)
-    const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7u) % GSR_LOSS_SUM_SLOTS;
+    const unsigned linear = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned slot = linear % GSR_LOSS_SUM_SLOTS;
     atomicAdd(&sums[slot], (double)red[0][0] + red[0][1] + red[0][2] + red[0][3]);
     atomicAdd(&sums[GSR_LOSS_SUM_SLOTS + slot], (double)red[1][0] + red[1][1] + red[1][2] + red[1][3]);
-    // the last workgroup to get here turns the partial sums into the three scalars
-    __threadfence();
-    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-    unsigned *counter = reinterpret_cast<unsigned *>(sums + 2 * GSR_LOSS_SUM_SLOTS);
-    last_block = atomicAdd(counter, 1u) == total - 1u;
   }
-  __syncthreads();
-  if (last_block && tid < 64) {
-    __threadfence();
-    double a = 0.0, b = 0.0;
-    for (int k = tid; k < GSR_LOSS_SUM_SLOTS; k += 64) {
-      a += __hip_atomic_load(&sums[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      b += __hip_atomic_load(&sums[GSR_LOSS_SUM_SLOTS + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+}
+
+// The partial sums -> the three scalars.  A separate one-wave launch: doing it in the
+// workgroup that finishes last needs an agent-scope release fence in every workgroup,
+// and on gfx950 that fence writes the XCD's whole L2 back (measured: 80 -> 520 us).
+__global__ __launch_bounds__(64) void l1_ssim_finalize_kernel(const int H, const int W, const float lambda,
+                                                              const double *__restrict__ sums,
+                                                              float *__restrict__ loss_out,
+                                                              float *__restrict__ terms_out) {
+  const int tid = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  for (int k = tid; k < GSR_LOSS_SUM_SLOTS; k += 64) {
+    a += sums[k];
+    b += sums[GSR_LOSS_SUM_SLOTS + k];
+  }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      a += __shfl_xor(a, o);
-      b += __shfl_xor(b, o);
-    }
-    if (tid == 0) {
-      const double l1m = a / (3.0 * (double)H * (double)W);
-      const double ssm = b / (3.0 * (double)(H - kHalo) * (double)(W - kHalo));
-      *loss_out = (float)((1.0 - (double)lambda) * l1m + (double)lambda * (1.0 - ssm));
-      if (terms_out) {
-        terms_out[0] = (float)l1m;
-        terms_out[1] = (float)ssm;
-      }
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  if (tid == 0) {
+    const double l1m = a / (3.0 * (double)H * (double)W);
+    const double ssm = b / (3.0 * (double)(H - kHalo) * (double)(W - kHalo));
+    *loss_out = (float)((1.0 - (double)lambda) * l1m + (double)lambda * (1.0 - ssm));
+    if (terms_out) {
+      terms_out[0] = (float)l1m;
+      terms_out[1] = (float)ssm;
     }
   }
 }
@@ -256,7 +254,9 @@ GSR_EXPORT int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width, floa
   GSR_CHECK_HIP(hipMemsetAsync(sums, 0, GSR_LOSS_WORKSPACE_DOUBLES * sizeof(double), s));
   const dim3 grd(gsr_cdiv(img_width, kTW), gsr_cdiv(img_height, kTH), 3);
   hipLaunchKernelGGL(l1_ssim_fwd_kernel, grd, dim3(256), 0, s, (int)img_height, (int)img_width, ssim_lambda,
-                     clamp_pred, pred, gt, maps, sums, loss_out, terms_out);
+                     clamp_pred, pred, gt, maps, sums);
+  hipLaunchKernelGGL(l1_ssim_finalize_kernel, dim3(1), dim3(64), 0, s, (int)img_height, (int)img_width,
+                     ssim_lambda, (const double *)sums, loss_out, terms_out);
   GSR_CHECK_LAUNCH("l1_ssim_forward");
   return GSR_OK;
 }

@@ -21,7 +21,7 @@ from torch.autograd import Function
 from rasterizer.cuda import _call, _check, _ptr, _stream
 
 _f32 = torch.float32
-WORKSPACE_DOUBLES = 2 * 64 + 1  # GSR_LOSS_WORKSPACE_DOUBLES (include/gsraster.h)
+WORKSPACE_DOUBLES = 2 * 64  # GSR_LOSS_WORKSPACE_DOUBLES (include/gsraster.h)
 
 
 class _L1SSIM(Function):

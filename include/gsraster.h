@@ -257,14 +257,14 @@ int gsr_cov2d_bounds(int num_pts, const float *cov2d, float *conics,
  * pred, gt: [H,W,3] fp32.  maps: scratch [9, H-10, W-10] fp32 written by the
  * forward and consumed by the backward.  sums: workspace of
  * GSR_LOSS_WORKSPACE_DOUBLES doubles (partial sums in GSR_LOSS_SUM_SLOTS slots each,
- * so that the atomics do not serialise on one address, plus a completion counter),
+ * so that the atomics do not serialise on one address),
  * zeroed by the call.  *loss_out = (1-l)*L1 + l*(1 - SSIM) and terms_out[2] =
- * {L1 = mean |pred-gt|, SSIM mean} (terms_out may be NULL), written by the
- * workgroup that finishes last.  clamp_pred != 0: the prediction is min(pred, 1), as after the models'
+ * {L1 = mean |pred-gt|, SSIM mean} (terms_out may be NULL), written by a
+ * one-wave kernel behind the main one.  clamp_pred != 0: the prediction is min(pred, 1), as after the models'
  * `torch.clamp(rgb, max=1.0)`, and the gradient is zero where pred > 1.
  * backward: v_pred[H,W,3] = upstream[0] * d loss / d pred (upstream on device). */
 #define GSR_LOSS_SUM_SLOTS 64
-#define GSR_LOSS_WORKSPACE_DOUBLES (2 * GSR_LOSS_SUM_SLOTS + 1)
+#define GSR_LOSS_WORKSPACE_DOUBLES (2 * GSR_LOSS_SUM_SLOTS)
 int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width,
                         float ssim_lambda, int clamp_pred, const float *pred,
                         const float *gt, float *maps, double *sums,
