@@ -1,5 +1,6 @@
+"""cProfile of the trainer harness' host side (who is waiting for whom?).  python tools/exp/prof_train.py"""
 import cProfile, pstats, sys, os, io
-ROOT="/root/repo"
+ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0]=[ROOT, os.path.join(ROOT,"gaussian-splatting-toolkit_amd")]
 import torch
 from harness.train import TrainConfig, train
