@@ -66,9 +66,7 @@ def allreduce_gradients(params: Sequence[torch.Tensor], average: bool = True, gr
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             if distributed:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group)
-                if average:
-                    p.grad.div_(ws)
+                _allreduce_inplace(p.grad, average, ws, group)
         return None
     buf = flatten_grads(params)
     if distributed:
@@ -77,6 +75,24 @@ def allreduce_gradients(params: Sequence[torch.Tensor], average: bool = True, gr
             buf.div_(dist.get_world_size(group))
     unflatten_to_grads(buf, params)
     return buf
+
+
+_avg_supported = {"ok": True}
+
+
+def _allreduce_inplace(t: torch.Tensor, average: bool, ws: int, group) -> None:
+    """RCCL averages inside the collective (ReduceOp.AVG): no extra pass over the
+    192-MB SH gradient to divide it.  Falls back to SUM + div_ once if the backend
+    refuses AVG (every rank runs the same library, so every rank falls back)."""
+    if average and _avg_supported["ok"]:
+        try:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+            return
+        except (RuntimeError, ValueError):
+            _avg_supported["ok"] = False
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        t.div_(ws)
 
 
 def allreduce_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tensor,
