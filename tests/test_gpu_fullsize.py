@@ -204,3 +204,65 @@ def test_1m_backward_is_additive_in_cotangents_and_stable(big):
     # culled Gaussians get exactly zero gradient
     culled = big["radii"] == 0
     assert ga[0][culled].abs().sum().item() == 0 and ga[2][culled].abs().sum().item() == 0
+
+
+@pytest.mark.timeout(900)
+def test_config5_shape_4k_rgb_and_depth_pass_vs_oracle():
+    """BASELINE config 5's shape at a size the oracle finishes in seconds: 4K (32 400 tiles:
+    the rocPRIM partition, not the LDS tile scatter), RGB pass + differentiable depth pass
+    (co-gs `render_depth` branch: depths as colours, zero background, second call reuses the
+    lists), forward and backward of both passes against the oracle."""
+    from rasterizer import project_gaussians, rasterize_gaussians, spherical_harmonics
+
+    W, H, n, deg = 3840, 2160, 60_000, 3
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=deg, seed=7, scale_lo=0.005, scale_hi=0.05)
+    bg = np.array(S.BACKGROUND, np.float32)
+    rng = np.random.default_rng(11)
+    v_img = rng.standard_normal((H, W, 3)).astype(np.float32)
+    v_alpha = rng.standard_normal((H, W)).astype(np.float32)
+    v_dep = rng.standard_normal((H, W, 3)).astype(np.float32)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    p = {k: cu(v, True) for k, v in sc.items()}
+    xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
+        p["means3d"], p["scales"], 1, p["quats"], ct.viewmat[:3], ct.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+        H, W, 16)
+    for t in (xys, depths, conics):
+        t.retain_grad()
+    dirs = S.viewdirs_for(sc, cam)
+    rgbs = torch.clamp(spherical_harmonics(deg, cu(dirs), p["sh_coeffs"]) + 0.5, min=0.0)
+    rgbs.retain_grad()
+    rgb, alpha = rasterize_gaussians(xys, depths, radii, conics, tiles, rgbs, p["opacities"], H, W, 16,
+                                     background=cu(bg), return_alpha=True)
+    dcol = depths[:, None].repeat(1, 3)
+    dcol.retain_grad()
+    dimg = rasterize_gaussians(xys, depths, radii, conics, tiles, dcol, p["opacities"], H, W, 16,
+                               background=torch.zeros(3, device=DEV))
+    torch.autograd.backward([rgb, alpha, dimg], [cu(v_img), cu(v_alpha), cu(v_dep)])
+    torch.cuda.synchronize()
+
+    gx, gd, gc, gr, gt = (npy(t) for t in (xys, depths, conics, radii, tiles))
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    I, cum = O.compute_cumulative_intersects(gt)
+    _, _, ks, vs, bins = O.bin_and_sort_gaussians(n, I, gx, gd, gr, cum, tb, 16)
+    col = npy(rgbs)
+    ref_img, ref_T, ref_idx, amb = O.rasterize_forward(tb, (16, 16, 1), (W, H, 1), vs, bins, gx, gc, col,
+                                                       sc["opacities"], bg, ambig_eps=1e-5)
+    dcol_np = np.repeat(gd[:, None], 3, 1).astype(np.float32)
+    ref_dep, ref_T2, ref_idx2, amb2 = O.rasterize_forward(tb, (16, 16, 1), (W, H, 1), vs, bins, gx, gc, dcol_np,
+                                                          sc["opacities"], np.zeros(3, np.float32), ambig_eps=1e-5)
+    ok = ~(amb | amb2)
+    assert ok.mean() > 0.99
+    assert np.abs(npy(rgb) - ref_img)[ok].max() < 1e-4
+    assert np.abs(npy(alpha) - (1 - ref_T))[ok].max() < 1e-4
+    scale = max(1.0, float(gd.max()))
+    assert np.abs(npy(dimg) - ref_dep)[ok].max() < 1e-4 * scale  # depths are not in [0,1]
+    a = O.rasterize_backward(H, W, 16, vs, bins, gx, gc, col, sc["opacities"], bg, ref_T, ref_idx, v_img, v_alpha,
+                             with_abs_sums=True)
+    b = O.rasterize_backward(H, W, 16, vs, bins, gx, gc, dcol_np, sc["opacities"], np.zeros(3, np.float32),
+                             ref_T2, ref_idx2, v_dep, np.zeros((H, W), np.float32), with_abs_sums=True)
+    grad_close(npy(xys.grad), a[0] + b[0], a[4] + b[4], name="xys.grad (both passes)")
+    grad_close(npy(conics.grad), a[1] + b[1], a[5] + b[5], name="conics.grad (both passes)")
+    grad_close(npy(p["opacities"].grad), a[3] + b[3], a[7] + b[7], name="opacities (both passes)")
+    grad_close(npy(rgbs.grad), a[2], a[6], name="rgbs.grad")
+    grad_close(npy(dcol.grad), b[2], b[6], name="depth colours")
