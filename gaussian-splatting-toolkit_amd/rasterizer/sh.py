@@ -1,53 +1,51 @@
-"""Spherical-harmonics colour evaluation (differentiable w.r.t. the coefficients).
+"""SH colour evaluation, differentiable in the coefficients only.
 
-Mirror of the reference's ``rasterizer/sh.py`` (``num_sh_bases`` :10,
-``deg_from_sh`` :22, ``spherical_harmonics`` :36, ``_SphericalHarmonics`` :60).
+Public surface of the reference's ``rasterizer/sh.py``: ``num_sh_bases`` (:10),
+``deg_from_sh`` (:22), ``spherical_harmonics`` (:36) and the autograd node behind
+it (:60).  The arithmetic lives in ``csrc/sh.hip``; the view directions are
+normalised inside the kernels.
 """
 from torch import Tensor
 from torch.autograd import Function
 
 import rasterizer.cuda as _C
 
-_BASES = {0: 1, 1: 4, 2: 9, 3: 16}
-_DEGREES = {1: 0, 4: 1, 9: 2, 16: 3, 25: 4}
+# band count per degree; the reference answers 25 for any degree above 3
+_BAND_COUNT = (1, 4, 9, 16)
+_DEGREE_OF = {count: degree for degree, count in enumerate(_BAND_COUNT + (25,))}
 
 
 def num_sh_bases(degree: int) -> int:
-    """(degree+1)^2 for degree 0..3, 25 for anything above (as the reference)."""
-    return _BASES.get(degree, 25)
+    return _BAND_COUNT[degree] if 0 <= degree < len(_BAND_COUNT) else 25
 
 
 def deg_from_sh(num_bases: int) -> int:
-    if num_bases in _DEGREES:
-        return _DEGREES[num_bases]
-    assert False, "Invalid number of SH bases"
-
-
-def spherical_harmonics(degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor) -> Tensor:
-    """Colours [N,3] from view directions [N,3] and coefficients [N,K,3].
-
-    ``degrees_to_use`` may be lower than the degree the coefficient tensor was
-    sized for; higher bands are ignored (and get zero gradient).  Directions are
-    normalised inside the kernel.  No gradient flows to ``viewdirs``.
-    """
-    assert coeffs.shape[-2] >= num_sh_bases(degrees_to_use)
-    return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous())
+    degree = _DEGREE_OF.get(num_bases)
+    assert degree is not None, "Invalid number of SH bases"
+    return degree
 
 
 class _SphericalHarmonics(Function):
-    @staticmethod
-    def forward(ctx, degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor):
-        num_points = coeffs.shape[0]
-        degree = deg_from_sh(coeffs.shape[-2])
-        ctx.degrees_to_use = degrees_to_use
-        ctx.degree = degree
-        ctx.save_for_backward(viewdirs)
-        return _C.compute_sh_forward(num_points, degree, degrees_to_use, viewdirs, coeffs)
+    """inputs: (bands in use, directions [N,3], coefficients [N,K,3]) -> colours [N,3]"""
 
     @staticmethod
-    def backward(ctx, v_colors: Tensor):
-        (viewdirs,) = ctx.saved_tensors
-        v_coeffs = _C.compute_sh_backward(
-            v_colors.shape[0], ctx.degree, ctx.degrees_to_use, viewdirs, v_colors
-        )
-        return None, None, v_coeffs
+    def forward(ctx, active_degree: int, dirs: Tensor, sh: Tensor):
+        ctx.sizes = (sh.shape[0], deg_from_sh(sh.shape[-2]), active_degree)
+        ctx.save_for_backward(dirs)
+        return _C.compute_sh_forward(*ctx.sizes, dirs, sh)
+
+    @staticmethod
+    def backward(ctx, grad_colors: Tensor):
+        (dirs,) = ctx.saved_tensors
+        grad_sh = _C.compute_sh_backward(*ctx.sizes, dirs, grad_colors)
+        return None, None, grad_sh  # bands above `active_degree` receive zeros
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: Tensor, coeffs: Tensor) -> Tensor:
+    """Colours [N,3] seen from ``viewdirs`` [N,3] for coefficients ``coeffs`` [N,K,3].
+
+    Only the first ``degrees_to_use`` degrees contribute (the tensor may be sized
+    for more).  No gradient reaches ``viewdirs``."""
+    if coeffs.shape[-2] < num_sh_bases(degrees_to_use):
+        raise AssertionError("coeffs hold fewer SH bands than degrees_to_use needs")
+    return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous())
