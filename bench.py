@@ -315,14 +315,17 @@ def main():
                 "gaussians": N, "visible": n_visible, "intersections": num_intersects,
                 "list_entries": list_entries,
                 "mean_gaussians_per_tile": round(num_intersects / tiles, 1),
-                "parallelism": f"dp{world} (per-view; one flat-gradient all-reduce/step, {args.backend})" if world > 1 else "single",
+                "parallelism": (f"dp{world} (per-view; gradients all-reduced in place per parameter tensor, averaged in the "
+                                f"collective, RCCL)" if args.backend == "nccl" else
+                                f"dp{world} (per-view; one flat-gradient all-reduce/step, {args.backend})")
+                               if world > 1 else "single",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": per_kernel,
             "kernel_events": f"HIP events around each native call on every {args.event_every}th timed step" if args.event_every > 1 else "HIP events around each native call on every timed step",
             "end_to_end_algorithmic_GBps": round(end_to_end, 1),
-            # N > 1: pack + all-reduce + unpack of the 59-float/Gaussian gradient (rank 0's view)
+            # N > 1: the exchange of the 59-float/Gaussian gradient as rank 0 sees it
             "allreduce_ms": (round(float(np.mean([a.elapsed_time(b) for a, b in comm_events])), 4)
                              if comm_events else None),
             "allreduce_bytes": sum(p.numel() for p in plist) * 4 if world > 1 else None,
