@@ -304,7 +304,8 @@ __device__ __forceinline__ void split_rows_from_lds(float *__restrict__ dst, con
 template <int K, bool VEC>
 __global__ __launch_bounds__(256) void sh_split_fwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
-    const float *__restrict__ dc, const float *__restrict__ rest, float *__restrict__ colors) {
+    const float *__restrict__ dc, const float *__restrict__ rest, float *__restrict__ colors,
+    const float shift, const int clamp_zero) {
   constexpr int R = SplitCfg<K>::R, STRIDE = SplitCfg<K>::STRIDE;
   __shared__ float lds[4][64 * STRIDE];
   const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -328,6 +329,15 @@ __global__ __launch_bounds__(256) void sh_split_fwd_kernel(
     gr += B[k] * row[3 * (k - 1) + 1];
     b += B[k] * row[3 * (k - 1) + 2];
   }
+  // optional epilogue of the models: rgb = clamp(sh + 0.5, min=0) (vanilla_gs.py:826)
+  r += shift;
+  gr += shift;
+  b += shift;
+  if (clamp_zero) {
+    r = fmaxf(r, 0.f);
+    gr = fmaxf(gr, 0.f);
+    b = fmaxf(b, 0.f);
+  }
   colors[3 * g] = r;
   colors[3 * g + 1] = gr;
   colors[3 * g + 2] = b;
@@ -336,7 +346,8 @@ __global__ __launch_bounds__(256) void sh_split_fwd_kernel(
 template <int K, bool VEC>
 __global__ __launch_bounds__(256) void sh_split_bwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
-    const float *__restrict__ v_colors, float *__restrict__ v_dc, float *__restrict__ v_rest) {
+    const float *__restrict__ v_colors, float *__restrict__ v_dc, float *__restrict__ v_rest,
+    const float *__restrict__ clamped_colors) {
   constexpr int R = SplitCfg<K>::R, STRIDE = SplitCfg<K>::STRIDE;
   __shared__ float lds[4][64 * STRIDE];
   const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -350,7 +361,12 @@ __global__ __launch_bounds__(256) void sh_split_bwd_kernel(
 #pragma unroll
       for (int k = 1; k < K; ++k) B[k] = 0.f;
     }
-    const float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
+    float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
+    if (clamped_colors) {  // forward output of the clamped epilogue: no gradient where it cut
+      vr = clamped_colors[3 * g] > 0.f ? vr : 0.f;
+      vg = clamped_colors[3 * g + 1] > 0.f ? vg : 0.f;
+      vb = clamped_colors[3 * g + 2] > 0.f ? vb : 0.f;
+    }
     v_dc[3 * g] = B[0] * vr;
     v_dc[3 * g + 1] = B[0] * vg;
     v_dc[3 * g + 2] = B[0] * vb;
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(256) void sh_split_bwd_kernel(
 
 GSR_EXPORT int gsr_sh_forward_split(unsigned num_points, unsigned degree, unsigned degrees_to_use,
                                     const float *viewdirs, const float *dc, const float *rest,
-                                    float *colors, gsr_stream_t stream) {
+                                    float *colors, float shift, int clamp_zero, gsr_stream_t stream) {
   GSR_REQUIRE(degree >= 1 && degree <= 3, "sh_forward_split: degree must be in [1,3]");
   GSR_REQUIRE(degrees_to_use <= degree, "sh_forward_split: degrees_to_use > degree");
   if (num_points == 0) return GSR_OK;
@@ -379,10 +395,10 @@ GSR_EXPORT int gsr_sh_forward_split(unsigned num_points, unsigned degree, unsign
 #define GSR_SPLIT_FWD(KK)                                                                                  \
   if (vec)                                                                                                 \
     hipLaunchKernelGGL((sh_split_fwd_kernel<KK, true>), grd, blk, 0, s, num_points, degrees_to_use,        \
-                       viewdirs, dc, rest, colors);                                                        \
+                       viewdirs, dc, rest, colors, shift, clamp_zero);                                     \
   else                                                                                                     \
     hipLaunchKernelGGL((sh_split_fwd_kernel<KK, false>), grd, blk, 0, s, num_points, degrees_to_use,       \
-                       viewdirs, dc, rest, colors)
+                       viewdirs, dc, rest, colors, shift, clamp_zero)
   switch (degree) {
     case 1: GSR_SPLIT_FWD(4); break;
     case 2: GSR_SPLIT_FWD(9); break;
@@ -394,8 +410,9 @@ GSR_EXPORT int gsr_sh_forward_split(unsigned num_points, unsigned degree, unsign
 }
 
 GSR_EXPORT int gsr_sh_backward_split(unsigned num_points, unsigned degree, unsigned degrees_to_use,
-                                     const float *viewdirs, const float *v_colors, float *v_dc,
-                                     float *v_rest, gsr_stream_t stream) {
+                                     const float *viewdirs, const float *v_colors,
+                                     const float *clamped_colors, float *v_dc, float *v_rest,
+                                     gsr_stream_t stream) {
   GSR_REQUIRE(degree >= 1 && degree <= 3, "sh_backward_split: degree must be in [1,3]");
   GSR_REQUIRE(degrees_to_use <= degree, "sh_backward_split: degrees_to_use > degree");
   if (num_points == 0) return GSR_OK;
@@ -406,10 +423,10 @@ GSR_EXPORT int gsr_sh_backward_split(unsigned num_points, unsigned degree, unsig
 #define GSR_SPLIT_BWD(KK)                                                                                  \
   if (vec)                                                                                                 \
     hipLaunchKernelGGL((sh_split_bwd_kernel<KK, true>), grd, blk, 0, s, num_points, degrees_to_use,        \
-                       viewdirs, v_colors, v_dc, v_rest);                                                  \
+                       viewdirs, v_colors, v_dc, v_rest, clamped_colors);                                  \
   else                                                                                                     \
     hipLaunchKernelGGL((sh_split_bwd_kernel<KK, false>), grd, blk, 0, s, num_points, degrees_to_use,       \
-                       viewdirs, v_colors, v_dc, v_rest)
+                       viewdirs, v_colors, v_dc, v_rest, clamped_colors)
   switch (degree) {
     case 1: GSR_SPLIT_BWD(4); break;
     case 2: GSR_SPLIT_BWD(9); break;

@@ -26,7 +26,8 @@ _f32 = torch.float32
 
 class _SplitSH(Function):
     @staticmethod
-    def forward(ctx, degrees_to_use: int, viewdirs: Tensor, dc: Tensor, rest: Tensor):
+    def forward(ctx, degrees_to_use: int, viewdirs: Tensor, dc: Tensor, rest: Tensor, shift: float,
+                clamp_zero: bool):
         n = dc.shape[0]
         degree = deg_from_sh(rest.shape[-2] + 1)
         for t, nm in ((viewdirs, "viewdirs"), (dc, "features_dc"), (rest, "features_rest")):
@@ -35,15 +36,17 @@ class _SplitSH(Function):
         with torch.cuda.device(dev):
             colors = torch.empty((n, 3), dtype=_f32, device=dev)
             _call("gsr_sh_forward_split", C.c_uint(n), C.c_uint(degree), C.c_uint(degrees_to_use),
-                  _ptr(viewdirs), _ptr(dc), _ptr(rest), _ptr(colors), _stream(dev))
+                  _ptr(viewdirs), _ptr(dc), _ptr(rest), _ptr(colors), C.c_float(shift),
+                  C.c_int(1 if clamp_zero else 0), _stream(dev))
         ctx.degree, ctx.degrees_to_use = degree, degrees_to_use
         ctx.shapes = (dc.shape, rest.shape)
-        ctx.save_for_backward(viewdirs)
+        ctx.clamped = bool(clamp_zero)
+        ctx.save_for_backward(viewdirs, colors if clamp_zero else None)
         return colors
 
     @staticmethod
     def backward(ctx, v_colors: Tensor):
-        (viewdirs,) = ctx.saved_tensors
+        viewdirs, colors = ctx.saved_tensors
         n = viewdirs.shape[0]
         v_colors = _check(v_colors.contiguous(), "v_colors", _f32)
         dev = viewdirs.device
@@ -51,17 +54,20 @@ class _SplitSH(Function):
             v_dc = torch.empty(ctx.shapes[0], dtype=_f32, device=dev)
             v_rest = torch.empty(ctx.shapes[1], dtype=_f32, device=dev)
             _call("gsr_sh_backward_split", C.c_uint(n), C.c_uint(ctx.degree), C.c_uint(ctx.degrees_to_use),
-                  _ptr(viewdirs), _ptr(v_colors), _ptr(v_dc), _ptr(v_rest), _stream(dev))
-        return None, None, v_dc, v_rest
+                  _ptr(viewdirs), _ptr(v_colors), _ptr(colors) if ctx.clamped else None, _ptr(v_dc),
+                  _ptr(v_rest), _stream(dev))
+        return None, None, v_dc, v_rest, None, None
 
 
 def spherical_harmonics_split(degrees_to_use: int, viewdirs: Tensor, features_dc: Tensor,
-                              features_rest: Tensor) -> Tensor:
+                              features_rest: Tensor, shift: float = 0.0, clamp_zero: bool = False) -> Tensor:
     """Colours [N,3] from `features_dc` [N,3] (or [N,1,3]) and `features_rest`
     [N,K-1,3]; equal to `spherical_harmonics(degrees_to_use, viewdirs,
     torch.cat((features_dc[:, None], features_rest), 1))`, differentiable w.r.t.
     both coefficient tensors.  K - 1 must be 3, 8 or 15 (degree 1..3); a model
-    without higher bands (K = 1) or with degree 4 takes the concatenating path."""
+    without higher bands (K = 1) or with degree 4 takes the concatenating path.
+    ``shift`` / ``clamp_zero``: the models' epilogue ``torch.clamp(rgbs + 0.5, min=0.0)``
+    (vanilla_gs.py:826) inside the same kernels: ``shift=0.5, clamp_zero=True``."""
     if features_dc.dim() == 3:
         if features_dc.shape[1] != 1:
             raise ValueError("features_dc must be [N,3] or [N,1,3]")
@@ -74,6 +80,9 @@ def spherical_harmonics_split(degrees_to_use: int, viewdirs: Tensor, features_dc
     assert K >= num_sh_bases(degrees_to_use)
     if K not in (4, 9, 16):
         dc3 = features_dc if features_dc.dim() == 3 else features_dc[:, None, :]
-        return spherical_harmonics(degrees_to_use, viewdirs, torch.cat((dc3, features_rest), dim=1))
+        out = spherical_harmonics(degrees_to_use, viewdirs, torch.cat((dc3, features_rest), dim=1))
+        if shift != 0.0:
+            out = out + shift
+        return torch.clamp(out, min=0.0) if clamp_zero else out
     return _SplitSH.apply(degrees_to_use, viewdirs.contiguous(), features_dc.contiguous(),
-                          features_rest.contiguous())
+                          features_rest.contiguous(), float(shift), bool(clamp_zero))

@@ -69,10 +69,12 @@ def render_view(
     if isinstance(sh_coeffs, (tuple, list)):
         from gs_fused import spherical_harmonics_split
 
-        rgbs = spherical_harmonics_split(sh_degree_to_use, viewdirs, sh_coeffs[0], sh_coeffs[1])
+        # `torch.clamp(rgbs + 0.5, min=0.0)` inside the SH kernels
+        rgbs = spherical_harmonics_split(sh_degree_to_use, viewdirs, sh_coeffs[0], sh_coeffs[1], shift=0.5,
+                                         clamp_zero=True)
     else:
         rgbs = spherical_harmonics(sh_degree_to_use, viewdirs, sh_coeffs)
-    rgbs = torch.clamp(rgbs + 0.5, min=0.0)
+        rgbs = torch.clamp(rgbs + 0.5, min=0.0)
 
     if rasterize_mode == "antialiased":
         opac = opacities * comp[:, None]

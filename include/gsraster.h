@@ -281,15 +281,18 @@ int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width,
  * and torch.cat them before every render (gs_toolkit/models/vanilla_gs.py:809,
  * `colors_crop = torch.cat(...)`): no concatenated copy is made, the gradients
  * are written straight into v_dc [n,3] and v_rest [n,K-1,3].  degree in [1,3]
- * (K = (degree+1)^2). */
+ * (K = (degree+1)^2).  Optional epilogue of the models (vanilla_gs.py:826,
+ * `torch.clamp(rgbs + 0.5, min=0.0)`): colors = sh + shift, cut at 0 when
+ * clamp_zero != 0; the backward then takes those colours (clamped_colors, NULL if
+ * not clamped) and passes no gradient where they are 0. */
 int gsr_sh_forward_split(unsigned num_points, unsigned degree,
                          unsigned degrees_to_use, const float *viewdirs,
                          const float *dc, const float *rest, float *colors,
-                         gsr_stream_t stream);
+                         float shift, int clamp_zero, gsr_stream_t stream);
 int gsr_sh_backward_split(unsigned num_points, unsigned degree,
                           unsigned degrees_to_use, const float *viewdirs,
-                          const float *v_colors, float *v_dc, float *v_rest,
-                          gsr_stream_t stream);
+                          const float *v_colors, const float *clamped_colors,
+                          float *v_dc, float *v_rest, gsr_stream_t stream);
 
 /* ---- per-Gaussian activations (caller-side glue) ----------
  * exp(scales), quats / |quats|, sigmoid(opacities) and the normalised view

@@ -493,6 +493,15 @@ def test_split_sh_equals_cat(K, use, n):
         ref.backward(cu(v))
         assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
         assert np.abs(got - c.grad.cpu().numpy()).max() < 1e-6
+        # the models' epilogue clamp(rgb + 0.5, min=0) inside the kernels
+        t_dc.grad = t_rest.grad = c.grad = None
+        out2 = spherical_harmonics_split(use, cu(dirs), t_dc, t_rest, shift=0.5, clamp_zero=True)
+        ref2 = torch.clamp(spherical_harmonics(use, cu(dirs), c) + 0.5, min=0.0)
+        out2.backward(cu(v))
+        ref2.backward(cu(v))
+        assert torch.allclose(out2, ref2, rtol=1e-6, atol=1e-6)
+        got2 = np.concatenate([t_dc.grad.cpu().numpy()[:, None, :], t_rest.grad.cpu().numpy()], 1)
+        assert np.abs(got2 - c.grad.cpu().numpy()).max() < 1e-6
 
 
 @pytest.mark.parametrize("n", [1, 257, 10_000])
