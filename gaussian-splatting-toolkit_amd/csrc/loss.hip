@@ -20,6 +20,8 @@
 // as planar maps, the two sums reduced to double atomics) and ONE backward kernel
 // (transposed blur of the three maps + the L1 sign term -> d loss / d pred, which
 // is exactly the `v_out_img` the compositing backward consumes).
+#include <algorithm>
+
 #include "gsr_common.h"
 
 namespace {
@@ -270,5 +272,92 @@ GSR_EXPORT int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width, flo
   hipLaunchKernelGGL(l1_ssim_bwd_kernel, grd, dim3(256), 0, (hipStream_t)stream, (int)img_height,
                      (int)img_width, ssim_lambda, clamp_pred, upstream, pred, gt, maps, v_pred);
   GSR_CHECK_LAUNCH("l1_ssim_backward");
+  return GSR_OK;
+}
+
+// ---- depth head of the co-gs model (DepthGSModel, gs_toolkit/models/depth_gs.py) --
+//   pred  = where(alpha > 0, depth / alpha, depth.detach().max())      (:356-363)
+//   loss  = | gt * (gt > 0) - pred * (gt > 0) |.mean()                   (:531-538)
+// as one kernel forward (+ the one-wave sum) and one backward that writes the
+// cotangents of the two compositing passes' outputs (accumulated depth, alpha)
+// directly -- ~8 elementwise / indexing launches forward and ~10 backward otherwise.
+namespace {
+
+__global__ __launch_bounds__(256) void depth_l1_fwd_kernel(const long long n, const float *__restrict__ depth,
+                                                           const float *__restrict__ alpha,
+                                                           const float *__restrict__ gt,
+                                                           const float *__restrict__ depth_max,
+                                                           double *__restrict__ sums) {
+  __shared__ float red[4];
+  const float far = *depth_max;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float a = alpha[i], g = gt[i];
+    const float pred = a > 0.f ? depth[i] / a : far;
+    acc += g > 0.f ? fabsf(g - pred) : 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(&sums[blockIdx.x % GSR_LOSS_SUM_SLOTS], (double)red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void depth_l1_finalize_kernel(const long long n, const double *__restrict__ sums,
+                                                               float *__restrict__ loss_out) {
+  double a = 0.0;
+  for (int k = threadIdx.x; k < GSR_LOSS_SUM_SLOTS; k += 64) a += sums[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (threadIdx.x == 0) *loss_out = (float)(a / (double)n);
+}
+
+__global__ __launch_bounds__(256) void depth_l1_bwd_kernel(const long long n, const float *__restrict__ upstream,
+                                                           const float *__restrict__ depth,
+                                                           const float *__restrict__ alpha,
+                                                           const float *__restrict__ gt,
+                                                           const float *__restrict__ depth_max,
+                                                           float *__restrict__ v_depth, float *__restrict__ v_alpha) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float a = alpha[i], g = gt[i], d = depth[i];
+  float vd = 0.f, va = 0.f;
+  if (a > 0.f && g > 0.f) {  // the far value of uncovered pixels is detached
+    const float inv = 1.f / a;
+    const float pred = d * inv;
+    const float s = pred > g ? 1.f : (pred < g ? -1.f : 0.f);
+    const float vp = upstream[0] * s / (float)n;
+    vd = vp * inv;
+    va = -vp * pred * inv;
+  }
+  v_depth[i] = vd;
+  v_alpha[i] = va;
+}
+
+}  // namespace
+
+GSR_EXPORT int gsr_depth_l1_forward(long long num_pixels, const float *depth, const float *alpha, const float *gt,
+                                    const float *depth_max, double *sums, float *loss_out, gsr_stream_t stream) {
+  GSR_REQUIRE(num_pixels > 0, "depth_l1_forward: empty image");
+  GSR_REQUIRE(depth && alpha && gt && depth_max && sums && loss_out, "depth_l1_forward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, GSR_LOSS_SUM_SLOTS * sizeof(double), s));
+  const unsigned blocks = (unsigned)std::min<long long>((num_pixels + 1023) / 1024, 4096);
+  hipLaunchKernelGGL(depth_l1_fwd_kernel, dim3(blocks), dim3(256), 0, s, num_pixels, depth, alpha, gt, depth_max,
+                     sums);
+  hipLaunchKernelGGL(depth_l1_finalize_kernel, dim3(1), dim3(64), 0, s, num_pixels, (const double *)sums, loss_out);
+  GSR_CHECK_LAUNCH("depth_l1_forward");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_depth_l1_backward(long long num_pixels, const float *upstream, const float *depth,
+                                     const float *alpha, const float *gt, const float *depth_max, float *v_depth,
+                                     float *v_alpha, gsr_stream_t stream) {
+  GSR_REQUIRE(num_pixels > 0, "depth_l1_backward: empty image");
+  GSR_REQUIRE(upstream && depth && alpha && gt && depth_max && v_depth && v_alpha, "depth_l1_backward: null pointer");
+  hipLaunchKernelGGL(depth_l1_bwd_kernel, dim3((unsigned)((num_pixels + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, num_pixels, upstream, depth, alpha, gt, depth_max, v_depth, v_alpha);
+  GSR_CHECK_LAUNCH("depth_l1_backward");
   return GSR_OK;
 }

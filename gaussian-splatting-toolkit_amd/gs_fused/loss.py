@@ -84,3 +84,44 @@ class L1SSIMLoss(torch.nn.Module):
 
     def forward(self, pred: Tensor, gt: Tensor) -> Tensor:
         return l1_ssim_loss(pred, gt, self.ssim_lambda, clamp_pred=self.clamp_pred)
+
+
+class _DepthL1(Function):
+    @staticmethod
+    def forward(ctx, depth: Tensor, alpha: Tensor, gt: Tensor):
+        if depth.numel() != alpha.numel() or depth.numel() != gt.numel() or depth.numel() == 0:
+            raise ValueError("depth, alpha and gt_depth must have the same (non-zero) number of pixels")
+        d = _check(depth.contiguous(), "depth", _f32)
+        a = _check(alpha.contiguous(), "alpha", _f32)
+        g = _check(gt.contiguous(), "gt_depth", _f32)
+        dev = d.device
+        with torch.cuda.device(dev):
+            far = d.detach().max().reshape(1)  # depth_im.detach().max() of the reference
+            work = torch.empty((64,), dtype=torch.float64, device=dev)
+            loss = torch.empty((), dtype=_f32, device=dev)
+            _call("gsr_depth_l1_forward", C.c_longlong(d.numel()), _ptr(d), _ptr(a), _ptr(g), _ptr(far),
+                  _ptr(work), _ptr(loss), _stream(dev))
+        ctx.save_for_backward(d, a, g, far)
+        ctx.shapes = (depth.shape, alpha.shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        d, a, g, far = ctx.saved_tensors
+        dev = d.device
+        up = v_loss.to(_f32).reshape(1).contiguous()
+        with torch.cuda.device(dev):
+            v_d = torch.empty_like(d)
+            v_a = torch.empty_like(a)
+            _call("gsr_depth_l1_backward", C.c_longlong(d.numel()), _ptr(up), _ptr(d), _ptr(a), _ptr(g),
+                  _ptr(far), _ptr(v_d), _ptr(v_a), _stream(dev))
+        return v_d.view(ctx.shapes[0]), v_a.view(ctx.shapes[1]), None
+
+
+def depth_l1_loss(depth_acc: Tensor, alpha: Tensor, gt_depth: Tensor) -> Tensor:
+    """Depth head of the co-gs model in two launches (+ one max): with
+    ``pred = where(alpha > 0, depth_acc / alpha, depth_acc.detach().max())``
+    (depth_gs.py:356-363) returns ``|gt * (gt > 0) - pred * (gt > 0)|.mean()``
+    (depth_gs.py:531-538).  ``depth_acc`` is the raw output of the depth compositing
+    pass, ``alpha`` the accumulated opacity of the RGB pass; differentiable w.r.t. both."""
+    return _DepthL1.apply(depth_acc, alpha, gt_depth)

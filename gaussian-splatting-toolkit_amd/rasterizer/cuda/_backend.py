@@ -43,6 +43,8 @@ SYMBOLS = (
     "gsr_cov2d_bounds",
     "gsr_l1_ssim_forward",
     "gsr_l1_ssim_backward",
+    "gsr_depth_l1_forward",
+    "gsr_depth_l1_backward",
     "gsr_sh_forward_split",
     "gsr_sh_backward_split",
     "gsr_activate_forward",

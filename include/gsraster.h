@@ -275,6 +275,23 @@ int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width,
                          const float *gt, const float *maps, float *v_pred,
                          gsr_stream_t stream);
 
+/* f2, depth head of the co-gs model (gs_toolkit/models/depth_gs.py:356-363, 531-538):
+ *   pred = alpha > 0 ? depth / alpha : *depth_max      (depth_max: device float, the
+ *                                                       detached maximum of `depth`)
+ *   loss = mean over all pixels of |gt - pred| where gt > 0 (0 elsewhere)
+ * depth = the depth pass of the compositing (depths as colours), alpha = 1 - T of the
+ * RGB pass, gt = sensor / estimated depth; all [num_pixels] fp32.  sums: workspace of
+ * GSR_LOSS_SUM_SLOTS doubles.  backward: cotangents of `depth` and `alpha`
+ * (upstream[0] = d L / d loss, on the device). */
+int gsr_depth_l1_forward(long long num_pixels, const float *depth,
+                         const float *alpha, const float *gt,
+                         const float *depth_max, double *sums, float *loss_out,
+                         gsr_stream_t stream);
+int gsr_depth_l1_backward(long long num_pixels, const float *upstream,
+                          const float *depth, const float *alpha,
+                          const float *gt, const float *depth_max,
+                          float *v_depth, float *v_alpha, gsr_stream_t stream);
+
 /* ---- SH colours from split coefficients (caller-side glue) --
  * gsr_sh_forward / gsr_sh_backward for models that keep the DC band and the
  * higher bands as two parameters (features_dc [n,3], features_rest [n,K-1,3])

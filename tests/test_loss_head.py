@@ -104,3 +104,37 @@ def test_clamp_pred_equals_torch_clamp():
     lb.backward()
     assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-9)
     assert float(a.grad[base > 1].abs().max()) == 0.0 and int((base > 1).sum()) > 1000
+
+
+@pytest.mark.gpu
+def test_depth_l1_head_equals_torch_ops():
+    """gs_fused.depth_l1_loss == the co-gs depth normalisation + masked L1 (depth_gs.py:356-363,
+    531-538), value and both gradients."""
+    import torch
+
+    from gs_fused import depth_l1_loss
+
+    rng = np.random.default_rng(9)
+    H, W = 120, 200
+    alpha = np.clip(rng.uniform(-0.3, 1.0, (H, W, 1)), 0, 1).astype(np.float32)      # ~25 % uncovered
+    depth = (alpha * rng.uniform(1, 9, (H, W, 1))).astype(np.float32)
+    gt = (rng.uniform(0.5, 10, (H, W)) * (rng.uniform(0, 1, (H, W)) > 0.2)).astype(np.float32)  # holes = 0
+    d1, a1 = (torch.from_numpy(x).cuda().requires_grad_(True) for x in (depth, alpha))
+    d2, a2 = (torch.from_numpy(x).cuda().requires_grad_(True) for x in (depth, alpha))
+    g = torch.from_numpy(gt).cuda()
+    mine = depth_l1_loss(d1, a1, g)
+    pred = torch.where(a2 > 0, d2 / a2, d2.detach().max()).squeeze(-1)
+    nz = g > 0
+    ref = torch.abs(g * nz - pred * nz).mean()
+    assert abs(float(mine) - float(ref)) < 1e-6 * max(1.0, float(ref))
+    (2.5 * mine).backward()
+    (2.5 * ref).backward()
+    # where alpha == 0 the torch ops give 0 * inf = NaN (the division's backward under a
+    # masked-out `where`); those pixels have no splats, so the value is never used -- here: 0
+    cov = a2.detach() > 0
+    assert torch.isnan(d2.grad[~cov]).all() and int((~cov).sum()) > 1000
+    assert float(d1.grad[~cov].abs().max()) == 0.0 and float(a1.grad[~cov].abs().max()) == 0.0
+    assert torch.allclose(d1.grad[cov], d2.grad[cov], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(a1.grad[cov], a2.grad[cov], rtol=1e-5, atol=1e-8)
+    with pytest.raises(ValueError):
+        depth_l1_loss(d1, a1, g[:-1])
