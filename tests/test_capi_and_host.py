@@ -198,3 +198,18 @@ def test_oracle_finite_differences():
         fd = (rloss(colors, p)[0] - rloss(colors, m)[0]) / (float(p[i, 0]) - float(m[i, 0]))
         an = float(vop[i, 0])
         assert abs(fd - an) <= 0.1 * max(abs(fd), abs(an)) + 0.05, ("opacity", i, fd, an)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gsraster.h is the drop-in boundary: it must compile as C99 on its own
+    (extern "C" guards, no C++ or torch types)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "gsraster.h"\nint main(void) { gsr_adam_tensor t; (void)t; return GSR_OK; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src),
+                           "-o", str(tmp_path / "use_header.o")])
