@@ -47,7 +47,9 @@ KERNELS = (
     ("depth_order", "depth_order"),
     ("bin_sorted", "bin_sorted"),
     ("rasterize_forward", "raster_fwd"),
+    ("rasterize_forward_rgbd", "raster_fwd"),
     ("rasterize_backward", "raster_bwd"),
+    ("rasterize_backward_rgbd", "raster_bwd"),
     ("compute_sh_backward", "sh_bwd"),
     ("project_gaussians_backward", "project_bwd"),
 )
@@ -146,6 +148,8 @@ def main():
     # co-gs / eval pattern (BASELINE config 5): a second rasterisation of the depths with
     # zero background (depth_gs.py:99, vanilla_gs.py:839-855), differentiable, in the step
     ap.add_argument("--render-depth", action="store_true")
+    ap.add_argument("--fused-depth", action="store_true",
+                    help="with --render-depth: RGB and depth from ONE compositing pass (gs_fused, SURVEY 8f row f4)")
     # "nccl" is RCCL on ROCm.  "gloo" exists so the N>1 code path can be exercised on a
     # single-GPU box (ranks then share cuda:0); it is not a measurement configuration.
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -195,7 +199,8 @@ def main():
         for p in plist:
             p.grad = None
         out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
-                          params["sh_coeffs"], camt, bg, deg, clamp_rgb=False, render_depth=args.render_depth)
+                          params["sh_coeffs"], camt, bg, deg, clamp_rgb=False, render_depth=args.render_depth,
+                          fused_depth=args.fused_depth)
         if args.render_depth:
             torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]],
                                     [v_img, v_alpha[..., None], v_alpha[..., None]])
@@ -310,7 +315,8 @@ def main():
             "config": {
                 "workload": f"{N} random Gaussians (SURVEY 8d, seed 42, scales log-U[{args.scale_lo},{args.scale_hi}]), "
                             f"SH degree {deg}, {W}x{H}, block 16, fwd+bwd through the rasterizer autograd API"
-                            + (" + differentiable depth pass" if args.render_depth else ""),
+                            + ((" + depth image from the same compositing pass (gs_fused)" if args.fused_depth
+                               else " + differentiable depth pass") if args.render_depth else ""),
                 "intersections_per_gaussian": round(num_intersects / N, 2),
                 "gaussians": N, "visible": n_visible, "intersections": num_intersects,
                 "list_entries": list_entries,

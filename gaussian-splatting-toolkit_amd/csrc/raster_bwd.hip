@@ -147,13 +147,50 @@ struct Butterfly<4> {
   }
 };
 
+// G == 4 with a tenth component (RGBD): same lane roles for components 0-7, and
+// components 8, 9 of splat l>>4 in `extra_v`, `extra2_v` (all 16 lanes of the row).
+struct Butterfly4x10 {
+  static __device__ __forceinline__ void run(float (&P)[40], int lane, float &main_v, float &extra_v,
+                                             float &extra2_v) {
+    float Q[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) Q[i] = fold32(P[i], P[i + 20]);  // lane bit 5 <-> splat bit 1
+    float R[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) R[i] = fold16(Q[i], Q[i + 10]);  // lane bit 4 <-> splat bit 0
+    const bool b3 = lane & 8, b2 = lane & 4, b0 = lane & 1;
+    float S[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S[i] = halve<DPP_ROW_ROR8>(R[i], R[i + 4], b3);
+    float U[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) U[i] = halve<DPP_ROW_HALF_MIRROR>(S[i], S[i + 2], b2);
+    const float v = halve<DPP_QUAD_XOR1>(U[0], U[1], b0);
+    main_v = v + dpp<DPP_QUAD_XOR2>(v);
+    float e = R[8], f = R[9];
+    e += dpp<DPP_ROW_ROR8>(e);
+    f += dpp<DPP_ROW_ROR8>(f);
+    e += dpp<DPP_ROW_HALF_MIRROR>(e);
+    f += dpp<DPP_ROW_HALF_MIRROR>(f);
+    e += dpp<DPP_QUAD_XOR1>(e);
+    f += dpp<DPP_QUAD_XOR1>(f);
+    e += dpp<DPP_QUAD_XOR2>(e);
+    f += dpp<DPP_QUAD_XOR2>(f);
+    extra_v = e;
+    extra2_v = f;
+  }
+};
+
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
 }
 
-template <int G>
+// RGBD (G == 4 only): a fourth colour channel (one scalar per Gaussian, composited into its
+// own image over background bg_extra by the forward) with cotangent v_out_extra [H,W];
+// its gradient goes to v_extra [N].
+template <int G, bool RGBD>
 __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
@@ -162,7 +199,11 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const float *__restrict__ background, const float *__restrict__ final_Ts,
     const int *__restrict__ final_idx, const float *__restrict__ v_output,
     const float *__restrict__ v_output_alpha, float *__restrict__ v_xy,
-    float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity) {
+    float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity,
+    const float *__restrict__ extra, const float bg_extra, const float *__restrict__ v_out_extra,
+    float *__restrict__ v_extra) {
+  static_assert(!RGBD || G == 4, "the 10-component butterfly exists for groups of 4");
+  constexpr int NC = RGBD ? 10 : 9;
   __shared__ SplatA sA[kChunk];
   __shared__ SplatB sB[kChunk];
   __shared__ SplatC sC[kChunk];
@@ -181,14 +222,14 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
   const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
 
-  float T[4], K[4], vr[4], vg[4], vb[4];
+  float T[4], K[4], vr[4], vg[4], vb[4], ve[4];
   int binf[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
     const bool inside = col < img_w && row < img_h;
     T[p] = 1.f;
-    K[p] = vr[p] = vg[p] = vb[p] = 0.f;
+    K[p] = vr[p] = vg[p] = vb[p] = ve[p] = 0.f;
     binf[p] = -1;  // `inside && idx <= bin_final` folds into one compare
     if (inside) {
       const size_t pid = (size_t)row * img_w + col;
@@ -198,7 +239,9 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
       vg[p] = v_output[3 * pid + 1];
       vb[p] = v_output[3 * pid + 2];
       // T_final*ra*v_out_alpha - T_final*ra*(bg . v_out) = ra * K
-      K[p] = Tf * ((v_output_alpha ? v_output_alpha[pid] : 0.f) - (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p]));
+      if constexpr (RGBD) ve[p] = v_out_extra[pid];
+      K[p] = Tf * ((v_output_alpha ? v_output_alpha[pid] : 0.f) -
+                   (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p] + (RGBD ? bg_extra * ve[p] : 0.f)));
       binf[p] = final_idx[pid];
     }
   }
@@ -224,17 +267,17 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     // back to front: lane l fetches sorted index hi - l; kept splats stay in that order
     const int sidx_l = hi - lane;
     const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics,
-                                  colors, opacities, sA, sB, sC, sId);
+                                  colors, opacities, sA, sB, sC, sId, RGBD ? extra : nullptr);
     __syncthreads();
 
     for (int t0 = 0; t0 < count; t0 += G) {
-      float P[9 * G];
+      float P[NC * G];
       bool lane_any = false;
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int t = t0 + j;
         float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f;
-        float sr = 0.f, sg = 0.f, sb = 0.f;
+        float sr = 0.f, sg = 0.f, sb = 0.f, se = 0.f;
         if (t < count) {  // wave-uniform
           const SplatA A = sA[t];
           const SplatB B = sB[t];
@@ -263,7 +306,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             //   = T * (rgb . v_out) + ra * (K - buffer . v_out);
             // K[p] carries  T_final*(v_out_alpha - bg.v_out) - buffer.v_out  (a scalar per
             // pixel instead of the reference's 3-channel running buffer)
-            const float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
+            const float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p] + (RGBD ? C.extra * ve[p] : 0.f);
             const float v_alpha = Tn * d + ra * K[p];
             const float w = valid ? vis * v_alpha : 0.f;
             const float fac = valid ? alpha * Tn : 0.f;
@@ -272,6 +315,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             sr += fac * vr[p];
             sg += fac * vg[p];
             sb += fac * vb[p];
+            if constexpr (RGBD) se += fac * ve[p];
             const float wx = w * dxs[p], wy = w * dys[p];
             m0 += w;
             mx += wx;
@@ -285,20 +329,22 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
         // raw moments; they are turned into gradient components AFTER the wave-wide
         // reduction (linear map: once per group by the owning lanes instead of once
         // per splat by all 64)
-        P[9 * j + 0] = mx;
-        P[9 * j + 1] = my;
-        P[9 * j + 2] = mxx;
-        P[9 * j + 3] = mxy;
-        P[9 * j + 4] = myy;
-        P[9 * j + 5] = sr;
-        P[9 * j + 6] = sg;
-        P[9 * j + 7] = sb;
-        P[9 * j + 8] = m0;
+        P[NC * j + 0] = mx;
+        P[NC * j + 1] = my;
+        P[NC * j + 2] = mxx;
+        P[NC * j + 3] = mxy;
+        P[NC * j + 4] = myy;
+        P[NC * j + 5] = sr;
+        P[NC * j + 6] = sg;
+        P[NC * j + 7] = sb;
+        P[NC * j + 8] = m0;
+        if constexpr (RGBD) P[NC * j + 9] = se;
       }
       if (!__any(lane_any)) continue;  // nothing in this group touched a live pixel
 
-      float main_v, extra_v;
-      BF::run(P, lane, main_v, extra_v);
+      float main_v, extra_v, extra2_v = 0.f;
+      if constexpr (RGBD) Butterfly4x10::run(P, lane, main_v, extra_v, extra2_v);
+      else BF::run(P, lane, main_v, extra_v);
       // v_sigma = -opac * w:  v_xy = -opac (a Sx + b Sy, b Sx + c Sy),
       // v_conic = -opac (Sxx/2, Sxy, Syy/2),  v_rgb = the colour sums,  v_opacity = S0
       const float other = BF::swap01(main_v);
@@ -314,6 +360,9 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
         if (owns_main && grad != 0.f)
           unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, grad);
         if (owns_extra && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
+        if constexpr (RGBD) {
+          if ((lane & 15) == 1 && extra2_v != 0.f) unsafeAtomicAdd(v_extra + g, extra2_v);
+        }
       }
     }
     __syncthreads();
@@ -532,15 +581,44 @@ GSR_EXPORT int gsr_rasterize_backward(
     return (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : GSR_BWD_GROUP;
   }();
 #define GSR_LAUNCH_T16(G)                                                                          \
-  hipLaunchKernelGGL(raster_bwd_tile16_kernel<G>, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0, s, tiles_x,         \
+  hipLaunchKernelGGL((raster_bwd_tile16_kernel<G, false>), dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)),      \
+                     dim3(64), 0, s, tiles_x,                                                        \
                      num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,               \
                      reinterpret_cast<const int2 *>(tile_bins),                                     \
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,  \
                      final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,        \
-                     v_opacity)
+                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr)
   if (group == 8) GSR_LAUNCH_T16(8);
   else GSR_LAUNCH_T16(4);
 #undef GSR_LAUNCH_T16
   GSR_CHECK_LAUNCH("rasterize_backward(tile16)");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_rasterize_backward_rgbd(
+    unsigned img_height, unsigned img_width, int num_points, const int32_t *gaussian_ids_sorted,
+    const int32_t *tile_bins, const float *xys, const float *conics, const float *colors, const float *extra,
+    const float *opacities, const float *background, float extra_background, const float *final_Ts,
+    const int32_t *final_idx, const float *v_output, const float *v_output_extra, const float *v_output_alpha,
+    float *v_xy, float *v_conic, float *v_colors, float *v_extra, float *v_opacity, gsr_stream_t stream) {
+  GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward_rgbd: empty image");
+  GSR_REQUIRE(num_points >= 0, "rasterize_backward_rgbd: num_points < 0");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && extra && opacities && background &&
+                  final_Ts && final_idx && v_output && v_output_extra && v_xy && v_conic && v_colors && v_extra &&
+                  v_opacity,
+              "rasterize_backward_rgbd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
+  if (rc != GSR_OK) return rc;
+  GSR_CHECK_HIP(hipMemsetAsync(v_extra, 0, sizeof(float) * (size_t)num_points, s));
+  const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
+  const int num_tiles = tiles_x * tiles_y;
+  hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, true>), dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64),
+                     0, s, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics,
+                     colors, opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic,
+                     v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra);
+  GSR_CHECK_LAUNCH("rasterize_backward_rgbd");
   return GSR_OK;
 }

@@ -9,7 +9,7 @@ constexpr int kChunk = 64;  // splats staged per LDS fill (one per lane)
 // LDS record of one staged splat; consumed by wave-uniform broadcast reads.
 struct __align__(16) SplatA { float x, y, ha, b; };     // ha = a/2
 struct __align__(16) SplatB { float hc, opac, r, g; };  // hc = c/2
-struct __align__(16) SplatC { float blue; int sidx; int mask; int pad; };
+struct __align__(16) SplatC { float blue; int sidx; int mask; float extra; };  // extra: optional 4th channel
 // (0.5*(a dx^2 + c dy^2) == (a/2) dx^2 + (c/2) dy^2 exactly: scaling by a power
 //  of two commutes with rounding)
 // sidx = index in the sorted list; mask = which of the tile's four 8x8
@@ -86,7 +86,8 @@ __device__ __forceinline__ int stage_chunk(
     const int lane, const bool live, const int sidx, const float tx0, const float ty0,
     const int *__restrict__ ids_sorted, const float2 *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
-    const float *__restrict__ opacities, SplatA *sA, SplatB *sB, SplatC *sC, int *sId) {
+    const float *__restrict__ opacities, SplatA *sA, SplatB *sB, SplatC *sC, int *sId,
+    const float *__restrict__ extra = nullptr) {
   int mask = 0;
   int g = 0;
   float2 xy = make_float2(0.f, 0.f);
@@ -109,7 +110,7 @@ __device__ __forceinline__ int stage_chunk(
                                                __builtin_amdgcn_mbcnt_lo((unsigned)kept, 0u));
     sA[slot] = SplatA{xy.x, xy.y, 0.5f * a, b};
     sB[slot] = SplatB{0.5f * c, opac, colors[3 * g], colors[3 * g + 1]};
-    sC[slot] = SplatC{colors[3 * g + 2], sidx, mask, 0};
+    sC[slot] = SplatC{colors[3 * g + 2], sidx, mask, extra ? extra[g] : 0.f};
     if (sId) sId[slot] = g;
   }
   return __popcll(kept);

@@ -36,13 +36,19 @@ using namespace gsr;
 // Per-pixel state is ONE float: T > 0 is the live transmittance, T < 0 means the
 // pixel is finished (or outside the image) and |T| is the value to report.  A
 // finished pixel gives next_T < 0, so it can neither draw nor finish again.
+//
+// RGBD: a fourth channel (one scalar per Gaussian, e.g. its depth) is composited in the
+// same pass into its own [H,W] image over background `bg_extra` (the
+// models run a second full pass for the depth image, vanilla_gs.py:840-855).
+template <bool RGBD>
 __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
     const float2 *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ background, float *__restrict__ out_img,
-    float *__restrict__ final_Ts, int *__restrict__ final_idx) {
+    float *__restrict__ final_Ts, int *__restrict__ final_idx, const float *__restrict__ extra,
+    const float bg_extra, float *__restrict__ out_extra) {
   __shared__ SplatA sA[kChunk];
   __shared__ SplatB sB[kChunk];
   __shared__ SplatC sC[kChunk];
@@ -57,13 +63,13 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
 
   // pixel p = (qx + 8*(p&1), qy + 8*(p>>1))
-  float T[4], cr[4], cg[4], cb[4];
+  float T[4], cr[4], cg[4], cb[4], ce[4];
   int last[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const bool inside = (qx + 8 * (p & 1)) < img_w && (qy + 8 * (p >> 1)) < img_h;
     T[p] = inside ? 1.f : -1.f;
-    cr[p] = cg[p] = cb[p] = 0.f;
+    cr[p] = cg[p] = cb[p] = ce[p] = 0.f;
     last[p] = 0;
   }
 
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
     const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics,
-                                  colors, opacities, sA, sB, sC, nullptr);
+                                  colors, opacities, sA, sB, sC, nullptr, RGBD ? extra : nullptr);
     __syncthreads();
     for (int t = 0; t < count; ++t) {
       if ((t & 7) == 7) {
@@ -116,6 +122,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
         cr[p] += B.r * vis;
         cg[p] += B.g * vis;
         cb[p] += C.blue * vis;
+        if constexpr (RGBD) ce[p] += C.extra * vis;
         last[p] = draw ? C.sidx : last[p];
         T[p] = hit ? upd : Tp;
       }
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       out_img[3 * pid] = cr[p] + Tp * bg0;
       out_img[3 * pid + 1] = cg[p] + Tp * bg1;
       out_img[3 * pid + 2] = cb[p] + Tp * bg2;
+      if constexpr (RGBD) out_extra[pid] = ce[p] + Tp * bg_extra;
     }
   }
 }
@@ -286,11 +294,33 @@ GSR_EXPORT int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_wi
                           gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
                           background, out_img, final_Ts, final_idx, (hipStream_t)stream);
   const int num_tiles = tiles_x * tiles_y;
-  hipLaunchKernelGGL(raster_fwd_tile16_kernel, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0, (hipStream_t)stream,
-                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+  hipLaunchKernelGGL(raster_fwd_tile16_kernel<false>, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0,
+                     (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
-                     out_img, final_Ts, final_idx);
+                     out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr);
   GSR_CHECK_LAUNCH("rasterize_forward(tile16)");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
+                                          const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                                          const float *xys, const float *conics, const float *colors,
+                                          const float *extra, const float *opacities,
+                                          const float *background, float extra_background, float *out_img,
+                                          float *out_extra, float *final_Ts, int32_t *final_idx,
+                                          gsr_stream_t stream) {
+  int rc = check_common("rasterize_forward_rgbd", tiles_x, tiles_y, 16, img_width, img_height, 3);
+  if (rc != GSR_OK) return rc;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && extra && opacities && background &&
+                  out_img && out_extra && final_Ts && final_idx,
+              "rasterize_forward_rgbd: null pointer");
+  const int num_tiles = tiles_x * tiles_y;
+  hipLaunchKernelGGL(raster_fwd_tile16_kernel<true>, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0,
+                     (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins),
+                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
+                     out_img, final_Ts, final_idx, extra, extra_background, out_extra);
+  GSR_CHECK_LAUNCH("rasterize_forward_rgbd");
   return GSR_OK;
 }

@@ -6,3 +6,4 @@ from .loss import L1SSIMLoss, depth_l1_loss, l1_ssim_loss  # noqa: F401
 from .adam import FusedAdam  # noqa: F401
 from .sh import spherical_harmonics_split  # noqa: F401
 from .activations import activate_gaussians, densify_stats_  # noqa: F401
+from .rgbd import rasterize_gaussians_rgbd  # noqa: F401

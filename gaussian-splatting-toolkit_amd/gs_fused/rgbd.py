@@ -1,0 +1,107 @@
+"""RGB and a depth image from ONE compositing pass.
+
+When a depth image is wanted the models composite twice per view
+(gs_toolkit/models/vanilla_gs.py:822-855, depth_gs.py:330-363):
+
+    rgb, alpha = rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, H, W, B,
+                                     background=background, return_alpha=True)
+    depth_im = rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3),
+                                   opacities, H, W, B, background=torch.zeros(3))[..., 0:1]
+
+i.e. two full forward and two full backward passes over the same sorted lists (the
+list building is shared through the rasterizer's cache, the compositing is not).
+`rasterize_gaussians_rgbd` composites a fourth channel in the same pass:
+
+    rgb, alpha, depth_im = rasterize_gaussians_rgbd(xys, depths, radii, conics, num_tiles_hit, rgbs, depths,
+                                                    opacities, H, W, background=background)
+
+Same values (the RGB image is bit-identical, the extra image equals channel 0 of the
+second pass) and the same gradients; block width 16 only.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+import rasterizer.cuda as _C
+
+_f32 = torch.float32
+BLOCK = 16
+
+
+class _RasterizeRGBD(Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, extra, opacity, img_height, img_width,
+                background, extra_background):
+        from rasterizer.rasterize import build_tile_lists
+
+        n = xys.size(0)
+        tile_bounds = ((img_width + BLOCK - 1) // BLOCK, (img_height + BLOCK - 1) // BLOCK, 1)
+        num_intersects, ids, bins, finish = build_tile_lists(
+            xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, BLOCK)
+        dev = xys.device
+
+        def composite(ids, bins):
+            return _C.rasterize_forward_rgbd(tile_bounds, (img_width, img_height, 1), ids, bins, xys, conics, colors,
+                                             extra, opacity, background, extra_background)
+
+        if finish is not None:  # lists sized from the previous view: composite, then check the count
+            img, ext, Ts, idx = composite(ids, bins)
+            num_intersects, ids, bins, rebuilt = finish()
+            if rebuilt:
+                img, ext, Ts, idx = composite(ids, bins)
+        elif num_intersects >= 1:
+            img, ext, Ts, idx = composite(ids, bins)
+        if num_intersects < 1:
+            img = torch.ones(img_height, img_width, 3, device=dev) * background
+            ext = torch.full((img_height, img_width), float(extra_background), device=dev)
+            Ts = torch.ones(img_height, img_width, device=dev)
+            idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
+            ids = torch.zeros(0, dtype=torch.int32, device=dev)
+            bins = torch.zeros(0, 2, dtype=torch.int32, device=dev)
+        ctx.set_materialize_grads(False)
+        ctx.meta = (img_height, img_width, num_intersects, float(extra_background))
+        ctx.save_for_backward(ids, bins, xys, conics, colors, extra, opacity, background, Ts, idx)
+        return img, 1 - Ts, ext
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha, v_ext):
+        ids, bins, xys, conics, colors, extra, opacity, background, Ts, idx = ctx.saved_tensors
+        H, W, num_intersects, ebg = ctx.meta
+        n = xys.size(0)
+        dev = xys.device
+        if num_intersects < 1:
+            z = torch.zeros_like
+            return (z(xys), None, None, z(conics), None, z(colors), z(extra), z(opacity)) + (None,) * 4
+        v_img = torch.zeros(H, W, 3, device=dev) if v_img is None else v_img
+        v_ext = torch.zeros(H, W, device=dev) if v_ext is None else v_ext
+        v_xy, v_conic, v_colors, v_extra, v_opacity = _C.rasterize_backward_rgbd(
+            H, W, ids, bins, xys, conics, colors, extra, opacity, background, ebg, Ts, idx, v_img, v_ext, v_alpha)
+        return (v_xy, None, None, v_conic, None, v_colors, v_extra.view(extra.shape),
+                v_opacity.reshape(opacity.shape)) + (None,) * 4
+
+
+def rasterize_gaussians_rgbd(xys: Tensor, depths: Tensor, radii: Tensor, conics: Tensor, num_tiles_hit: Tensor,
+                             colors: Tensor, extra: Tensor, opacity: Tensor, img_height: int, img_width: int,
+                             background: Optional[Tensor] = None, extra_background: float = 0.0
+                             ) -> Tuple[Tensor, Tensor, Tensor]:
+    """-> (rgb [H,W,3], alpha [H,W], extra image [H,W,1]): `rasterize_gaussians(..., colors,
+    return_alpha=True)` and the channel-0 image of `rasterize_gaussians(..., extra repeated
+    as 3 colours, background=extra_background)` from one pass.  ``extra``: [N] or [N,1]
+    (typically ``depths``).  Differentiable w.r.t. xys, conics, colors, extra, opacity."""
+    if colors.dim() != 2 or colors.shape[1] != 3:
+        raise ValueError("colors must have dimensions (N, 3)")
+    if extra.numel() != xys.shape[0]:
+        raise ValueError("extra must hold one scalar per Gaussian")
+    if background is None:
+        background = torch.ones(3, dtype=_f32, device=colors.device)
+    for t, nm in ((xys, "xys"), (conics, "conics"), (colors, "colors"), (extra, "extra"), (opacity, "opacity"),
+                  (background, "background")):
+        if not t.is_cuda:
+            raise RuntimeError(f"{nm} must be a CUDA tensor")
+    img, alpha, ext = _RasterizeRGBD.apply(
+        xys.contiguous(), depths.contiguous(), radii.contiguous(), conics.contiguous(), num_tiles_hit.contiguous(),
+        colors.contiguous().float(), extra.contiguous().float(), opacity.contiguous(), int(img_height),
+        int(img_width), background.contiguous().float(), float(extra_background))
+    return img, alpha, ext[..., None]

@@ -54,6 +54,7 @@ def render_view(
     retain_xys_grad: bool = False,
     clamp_rgb: bool = True,
     viewdirs: Optional[torch.Tensor] = None,  # normalised means3d - campos, if the caller already has them
+    fused_depth: bool = False,  # RGB and depth image from one compositing pass (gs_fused.rasterize_gaussians_rgbd)
 ) -> Dict[str, Optional[torch.Tensor]]:
     H, W = cam.height, cam.width
     xys, depths, radii, conics, comp, num_tiles_hit, cov3d = project_gaussians(
@@ -83,19 +84,26 @@ def render_view(
     else:
         raise ValueError("Unknown rasterize_mode: %s" % rasterize_mode)
 
-    rgb, alpha = rasterize_gaussians(
-        xys, depths, radii, conics, num_tiles_hit, rgbs, opac, H, W, BLOCK_WIDTH,
-        background=background, return_alpha=True,
-    )
+    depth_im = None
+    if render_depth and fused_depth:
+        from gs_fused import rasterize_gaussians_rgbd
+
+        rgb, alpha, depth_im = rasterize_gaussians_rgbd(xys, depths, radii, conics, num_tiles_hit, rgbs, depths, opac,
+                                                        H, W, background=background)
+    else:
+        rgb, alpha = rasterize_gaussians(
+            xys, depths, radii, conics, num_tiles_hit, rgbs, opac, H, W, BLOCK_WIDTH,
+            background=background, return_alpha=True,
+        )
     alpha = alpha[..., None]
     if clamp_rgb:
         rgb = torch.clamp(rgb, max=1.0)
-    depth_im = None
     if render_depth:
-        depth_im = rasterize_gaussians(
-            xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opac, H, W,
-            BLOCK_WIDTH, background=torch.zeros(3, device=means3d.device),
-        )[..., 0:1]
+        if depth_im is None:
+            depth_im = rasterize_gaussians(
+                xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opac, H, W,
+                BLOCK_WIDTH, background=torch.zeros(3, device=means3d.device),
+            )[..., 0:1]
         depth_im = torch.where(alpha > 0, depth_im / alpha, depth_im.detach().max())
     return {"rgb": rgb, "alpha": alpha, "depth": depth_im, "xys": xys, "radii": radii,
             "depths": depths, "conics": conics, "num_tiles_hit": num_tiles_hit, "rgbs": rgbs}

@@ -382,6 +382,54 @@ def nd_rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile
                               conics, colors, opacities, background, nd=True)
 
 
+def rasterize_forward_rgbd(tile_bounds, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors, extra,
+                           opacities, background, extra_background: float):
+    """RGB + one extra channel in one pass (``gsr_rasterize_forward_rgbd``, 16x16 tiles):
+    -> (out_img [H,W,3], out_extra [H,W], final_Ts [H,W], final_idx i32[H,W])."""
+    _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
+    _check(extra, "extra", _f32)
+    if colors.size(1) != 3 or extra.numel() != xys.size(0):
+        raise RuntimeError("rasterize_forward_rgbd expects colors [N,3] and extra [N]")
+    W, H = int(img_size[0]), int(img_size[1])
+    dev = xys.device
+    with torch.cuda.device(dev):
+        img = torch.empty((H, W, 3), dtype=_f32, device=dev)
+        ext = torch.empty((H, W), dtype=_f32, device=dev)
+        Ts = torch.empty((H, W), dtype=_f32, device=dev)
+        idx = torch.empty((H, W), dtype=_i32, device=dev)
+        _call("gsr_rasterize_forward_rgbd", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(W),
+              C.c_uint(H), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
+              _ptr(extra), _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(img), _ptr(ext),
+              _ptr(Ts), _ptr(idx), _stream(dev))
+    return img, ext, Ts, idx
+
+
+def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bins, xys, conics, colors, extra,
+                            opacities, background, extra_background, final_Ts, final_idx, v_output,
+                            v_output_extra, v_output_alpha):
+    """-> (v_xy, v_conic, v_colors, v_extra [N], v_opacity [N,1]); ``gsr_rasterize_backward_rgbd``."""
+    _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
+    _check(extra, "extra", _f32)
+    v_output = _check(v_output.contiguous(), "v_output", _f32)
+    v_output_extra = _check(v_output_extra.contiguous(), "v_output_extra", _f32)
+    if v_output_alpha is not None:
+        v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
+    n = xys.size(0)
+    dev = xys.device
+    with torch.cuda.device(dev):
+        flat = torch.empty((n * 10,), dtype=_f32, device=dev)
+        v_xy, v_conic = flat[: 2 * n].view(n, 2), flat[2 * n: 5 * n].view(n, 3)
+        v_colors, v_opacity = flat[5 * n: 8 * n].view(n, 3), flat[8 * n: 9 * n].view(n, 1)
+        v_extra = flat[9 * n:]
+        _call("gsr_rasterize_backward_rgbd", C.c_uint(img_height), C.c_uint(img_width), C.c_int(n),
+              _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors), _ptr(extra),
+              _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(final_Ts), _ptr(final_idx),
+              _ptr(v_output), _ptr(v_output_extra),
+              _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic),
+              _ptr(v_colors), _ptr(v_extra), _ptr(v_opacity), _stream(dev))
+    return v_xy, v_conic, v_colors, v_extra, v_opacity
+
+
 def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
                         conics, colors, opacities, background, final_Ts, final_idx, v_output,
                         v_output_alpha, nd: bool):

@@ -47,6 +47,8 @@ SYMBOLS = (
     "gsr_depth_l1_backward",
     "gsr_sh_forward_split",
     "gsr_sh_backward_split",
+    "gsr_rasterize_forward_rgbd",
+    "gsr_rasterize_backward_rgbd",
     "gsr_activate_forward",
     "gsr_activate_backward",
     "gsr_densify_stats",

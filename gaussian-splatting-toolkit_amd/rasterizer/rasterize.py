@@ -165,11 +165,81 @@ def rasterize_gaussians(
     )
 
 
+def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width):
+    """The per-tile depth-sorted lists every compositing call walks.
+
+    -> ``(num_intersects, gaussian_ids_sorted, tile_bins, finish)``.  Either the count is
+    known (``finish is None``; a cache hit, the first view, or a tile grid the
+    device-sized path does not serve), or the lists were sized from the previous view
+    and ``num_intersects is None``: enqueue the compositing, then call ``finish()`` ->
+    ``(num_intersects, gaussian_ids_sorted, tile_bins, rebuilt)``; with ``rebuilt`` the
+    guess was too small, the lists were built again and the compositing must be repeated.
+    The result is cached for the next call with the same geometry (the depth pass)."""
+    num_points = xys.size(0)
+    tile_bounds = ((img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width, 1)
+    key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
+    # With 16x16 tiles the lists leave out the (Gaussian, tile) pairs that cannot
+    # reach alpha >= 1/255 anywhere in the tile (about half of the reference's
+    # bounding-box pairs; the compositing rule skips them pixel by pixel, so
+    # images and gradients are unchanged).  Those lists also depend on
+    # conics and opacity.
+    exact = block_width == 16
+    if _bin_cache["key"] == key and (not exact or _same_reach_inputs(conics, opacity)):
+        return _bin_cache["value"] + (None,)
+
+    def remember(num_intersects, ids, bins):
+        _bin_cache["key"] = key
+        _bin_cache["value"] = (num_intersects, ids, bins)
+        _bin_cache["keepalive"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
+        _bin_cache["reach"] = (conics.detach(), opacity.detach(), conics._version, opacity._version)
+
+    # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
+    # compute_cumulative_intersects + bin_and_sort_gaussians (bit for bit
+    # when not `exact`: tests/test_gpu_kernels.py::
+    # test_fused_binning_equals_reference_pipeline)
+    tiles, records = num_tiles_hit, None
+    if exact:
+        tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds)
+    order, cum_sorted = _C.depth_order(depths, radii, tiles)
+
+    def build(count, device_sized=False):
+        return _C.bin_sorted(num_points, count, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
+                             device_sized=device_sized)
+
+    capacity = _speculative_capacity(xys.device, num_points, tile_bounds)
+    if capacity is None:
+        num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
+        _note_count(xys.device, num_points, tile_bounds, num_intersects)
+        ids, bins = build(num_intersects) if num_intersects >= 1 else (None, None)
+        remember(num_intersects, ids, bins)
+        return num_intersects, ids, bins, None
+
+    # Size the lists from the previous view instead of waiting for the count to reach the
+    # host (utils.py:124).  The count goes to the host right behind the depth-order scan,
+    # before the lists are built: the host wakes up early enough to queue the loss and the
+    # backward while the GPU is still compositing.
+    pending = _PendingCount(xys.device)
+    _C.publish_int32(cum_sorted[-1:], pending.buf)
+    pending.mark()
+    ids, bins = build(capacity, device_sized=True)
+
+    def finish():
+        nonlocal ids, bins
+        num_intersects = pending.resolve()
+        _note_count(xys.device, num_points, tile_bounds, num_intersects)
+        rebuilt = num_intersects > capacity  # the guess was too small: build the lists again
+        if rebuilt:
+            ids, bins = build(num_intersects)
+        remember(num_intersects, ids, bins)
+        return num_intersects, ids, bins, rebuilt
+
+    return None, ids, bins, finish
+
+
 class _RasterizeGaussians(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height,
                 img_width, block_width, background=None, return_alpha=False):
-        num_points = xys.size(0)
         tile_bounds = (
             (img_width + block_width - 1) // block_width,
             (img_height + block_width - 1) // block_width,
@@ -177,73 +247,18 @@ class _RasterizeGaussians(Function):
         )
         block = (block_width, block_width, 1)
         img_size = (img_width, img_height, 1)
-
-        key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
-        # With 16x16 tiles the lists leave out the (Gaussian, tile) pairs that cannot
-        # reach alpha >= 1/255 anywhere in the tile (about half of the reference's
-        # bounding-box pairs; the compositing rule skips them pixel by pixel, so
-        # images and gradients are unchanged).  Those lists also depend on
-        # conics and opacity.
-        exact = block_width == 16
-        pending = None
-        cached = _bin_cache["key"] == key and (not exact or _same_reach_inputs(conics, opacity))
-        if cached:
-            num_intersects, gaussian_ids_sorted, tile_bins = _bin_cache["value"]
-        else:
-            # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
-            # compute_cumulative_intersects + bin_and_sort_gaussians (bit for bit
-            # when not `exact`: tests/test_gpu_kernels.py::
-            # test_fused_binning_equals_reference_pipeline)
-            tiles, records = num_tiles_hit, None
-            if exact:
-                tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds)
-            order, cum_sorted = _C.depth_order(depths, radii, tiles)
-            capacity = _speculative_capacity(xys.device, num_points, tile_bounds)
-            gaussian_ids_sorted = tile_bins = None
-            if capacity is not None:
-                # size the lists from the previous view instead of waiting for the
-                # count to reach the host (utils.py:124); checked after compositing
-                # has been enqueued
-                # (the count goes to the host right behind the depth-order scan, before the lists
-                # are built: the host wakes up early enough to queue the loss and the backward
-                # while the GPU is still compositing)
-                pending = _PendingCount(xys.device)
-                _C.publish_int32(cum_sorted[-1:], pending.buf)
-                pending.mark()
-                num_intersects = None
-                gaussian_ids_sorted, tile_bins = _C.bin_sorted(
-                    num_points, capacity, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
-                    device_sized=True,
-                )
-            else:
-                num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
-                _note_count(xys.device, num_points, tile_bounds, num_intersects)
-                if num_intersects >= 1:
-                    gaussian_ids_sorted, tile_bins = _C.bin_sorted(
-                        num_points, num_intersects, order, cum_sorted, xys, radii, tile_bounds, block_width, records
-                    )
-
         rasterize_fn = _C.rasterize_forward if colors.shape[-1] == 3 else _C.nd_rasterize_forward
-        if pending is not None:
-            out_img, final_Ts, final_idx = rasterize_fn(
-                tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
-                opacity, background,
-            )
-            num_intersects = pending.resolve()
-            _note_count(xys.device, num_points, tile_bounds, num_intersects)
-            if num_intersects > capacity:  # the guess was too small: build the lists again, composite again
-                gaussian_ids_sorted, tile_bins = _C.bin_sorted(
-                    num_points, num_intersects, order, cum_sorted, xys, radii, tile_bounds, block_width, records
-                )
-                out_img, final_Ts, final_idx = rasterize_fn(
-                    tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
-                    opacity, background,
-                )
-        if not cached:
-            _bin_cache["key"] = key
-            _bin_cache["value"] = (num_intersects, gaussian_ids_sorted, tile_bins)
-            _bin_cache["keepalive"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
-            _bin_cache["reach"] = (conics.detach(), opacity.detach(), conics._version, opacity._version)
+
+        def composite(ids, bins):
+            return rasterize_fn(tile_bounds, block, img_size, ids, bins, xys, conics, colors, opacity, background)
+
+        num_intersects, gaussian_ids_sorted, tile_bins, finish = build_tile_lists(
+            xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width)
+        if finish is not None:
+            out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
+            num_intersects, gaussian_ids_sorted, tile_bins, rebuilt = finish()
+            if rebuilt:
+                out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
 
         if num_intersects < 1:
             # nothing on screen: background everywhere (rasterize.py:119-127)
@@ -252,11 +267,8 @@ class _RasterizeGaussians(Function):
             tile_bins = torch.zeros(0, 2, device=xys.device)
             final_Ts = torch.zeros(img_height, img_width, device=xys.device)
             final_idx = torch.zeros(img_height, img_width, device=xys.device)
-        elif pending is None:
-            out_img, final_Ts, final_idx = rasterize_fn(
-                tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors,
-                opacity, background,
-            )
+        elif finish is None:
+            out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
 
         ctx.set_materialize_grads(False)
         ctx.img_width = img_width

@@ -311,6 +311,38 @@ int gsr_sh_backward_split(unsigned num_points, unsigned degree,
                           const float *v_colors, const float *clamped_colors,
                           float *v_dc, float *v_rest, gsr_stream_t stream);
 
+/* ---- RGB + one extra channel in ONE compositing pass -------
+ * The models composite twice per view when they need a depth image: RGB, then
+ * depths repeated as three colours over a zero background (vanilla_gs.py:840-855,
+ * depth_gs.py:346-363).  These two calls composite colors [n,3] and extra [n]
+ * (one scalar per Gaussian, e.g. its depth) together: out_img [H,W,3] over
+ * `background`, out_extra [H,W] over `extra_background`; final_Ts / final_idx as
+ * gsr_rasterize_forward.  block_width is 16.  The backward takes the cotangents of
+ * both images (and of alpha, NULL = 0) and returns v_extra [n] next to the usual four. */
+int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img_width,
+                               unsigned img_height,
+                               const int32_t *gaussian_ids_sorted,
+                               const int32_t *tile_bins, const float *xys,
+                               const float *conics, const float *colors,
+                               const float *extra, const float *opacities,
+                               const float *background, float extra_background,
+                               float *out_img, float *out_extra,
+                               float *final_Ts, int32_t *final_idx,
+                               gsr_stream_t stream);
+int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
+                                int num_points,
+                                const int32_t *gaussian_ids_sorted,
+                                const int32_t *tile_bins, const float *xys,
+                                const float *conics, const float *colors,
+                                const float *extra, const float *opacities,
+                                const float *background, float extra_background,
+                                const float *final_Ts, const int32_t *final_idx,
+                                const float *v_output,
+                                const float *v_output_extra,
+                                const float *v_output_alpha, float *v_xy,
+                                float *v_conic, float *v_colors, float *v_extra,
+                                float *v_opacity, gsr_stream_t stream);
+
 /* ---- per-Gaussian activations (caller-side glue) ----------
  * exp(scales), quats / |quats|, sigmoid(opacities) and the normalised view
  * directions means - camera_position of GaussianSplattingModel.get_outputs

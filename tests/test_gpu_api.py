@@ -563,3 +563,57 @@ def test_densify_stats_kernel():
     before = norm.clone()
     densify_stats_(None, radii, 1920, norm, cnt, mx)  # no gradient this step: counts only
     assert torch.equal(norm, before) and torch.equal(cnt, want_cnt + vis.to(torch.int32))
+
+
+@pytest.mark.parametrize("n,W,H", [(3000, 160, 96), (40_000, 640, 360)])
+def test_rgbd_single_pass_equals_two_passes(n, W, H):
+    """gs_fused.rasterize_gaussians_rgbd == the models' RGB pass + depth pass
+    (vanilla_gs.py:822-855): RGB and alpha bit-identical, the extra image equal to channel 0
+    of the second pass, gradients equal to the sums over both passes."""
+    from gs_fused import rasterize_gaussians_rgbd
+    from rasterizer import project_gaussians, rasterize_gaussians
+    from rasterizer import rasterize as R
+
+    cam = S.make_camera(W, H, yaw=0.1)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=21, scale_lo=0.01, scale_hi=0.1)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    col_np = torch.rand(n, 3, generator=g)
+    v_img = torch.randn(H, W, 3, generator=g).to(DEV)
+    v_alpha = torch.randn(H, W, generator=g).to(DEV)
+    v_dep = torch.randn(H, W, 1, generator=g).to(DEV)
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+
+    def inputs():
+        p = {k: cu(v, True) for k, v in sc.items() if k in ("means3d", "scales", "quats", "opacities")}
+        xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
+            p["means3d"], p["scales"], 1, p["quats"], ct.viewmat[:3], ct.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+            H, W, 16)
+        colors = col_np.to(DEV).requires_grad_(True)
+        return p, xys, depths, radii, conics, tiles, colors
+
+    # two passes, as the models do it
+    R._bin_cache["key"] = None
+    p, xys, depths, radii, conics, tiles, colors = inputs()
+    rgb, alpha = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, p["opacities"], H, W, 16,
+                                     background=bg, return_alpha=True)
+    dimg = rasterize_gaussians(xys, depths, radii, conics, tiles, depths[:, None].repeat(1, 3), p["opacities"], H, W,
+                               16, background=torch.zeros(3, device=DEV))[..., 0:1]
+    torch.autograd.backward([rgb, alpha, dimg], [v_img, v_alpha, v_dep])
+    ref = [t.grad.clone() for t in (p["means3d"], p["scales"], p["quats"], p["opacities"], colors)]
+
+    # one pass
+    R._bin_cache["key"] = None
+    p2, xys, depths, radii, conics, tiles, colors2 = inputs()
+    rgb2, alpha2, dimg2 = rasterize_gaussians_rgbd(xys, depths, radii, conics, tiles, colors2, depths,
+                                                   p2["opacities"], H, W, background=bg)
+    assert torch.equal(rgb2, rgb) and torch.equal(alpha2, alpha)
+    assert dimg2.shape == (H, W, 1)
+    assert torch.allclose(dimg2, dimg, rtol=1e-6, atol=1e-6)
+    torch.autograd.backward([rgb2, alpha2, dimg2], [v_img, v_alpha, v_dep])
+    got = [t.grad for t in (p2["means3d"], p2["scales"], p2["quats"], p2["opacities"], colors2)]
+    for a, b, nm in zip(got, ref, ("means3d", "scales", "quats", "opacities", "colors")):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-12, nm
+        assert (a - b).norm() <= 2e-5 * b.norm(), nm
+    with pytest.raises(ValueError):
+        rasterize_gaussians_rgbd(xys, depths, radii, conics, tiles, colors2[:, :2], depths, p2["opacities"], H, W)
