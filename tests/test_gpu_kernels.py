@@ -434,6 +434,20 @@ def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
     I2 = int(cum2[-1].item())
     assert 0 < I2 < I
     ids_ex, bins_ex = C.bin_sorted(n, I2, order2, cum2, g["xys"], g["radii"], tb, bw, recs)
+    # device-sized variant: capacity instead of the exact length, count handed back through
+    # device-accessible (pinned host) memory; a capacity that is too small cuts the lists
+    if tb[0] * tb[1] <= C.MAX_SCATTER_TILES:
+        count = torch.zeros(1, dtype=torch.int32).pin_memory()
+        ids_cap, bins_cap = C.bin_sorted(n, I2 + 1000, order2, cum2, g["xys"], g["radii"], tb, bw, recs,
+                                         device_sized=True, count_out=count)
+        torch.cuda.synchronize()
+        assert int(count[0]) == I2
+        assert torch.equal(ids_cap[:I2], ids_ex) and torch.equal(bins_cap, bins_ex)
+        small = I2 // 2
+        ids_cut, bins_cut = C.bin_sorted(n, small, order2, cum2, g["xys"], g["radii"], tb, bw, recs,
+                                         device_sized=True, count_out=count)
+        torch.cuda.synchronize()
+        assert int(count[0]) == I2 and int(bins_cut.max()) <= small  # memory-safe, caller rebuilds
     ids_ref_n, bins_ref_n, ids_ex_n, bins_ex_n = npy(ids_ref), npy(bins_ref), npy(ids_ex), npy(bins_ex)
     assert np.array_equal(np.bincount(ids_ex_n, minlength=n), npy(cnt))
     px = np.arange(bw, dtype=np.float32)
