@@ -105,27 +105,37 @@ GSR_EXPORT int gsr_activate_backward(int num_points, const float *raw_quats, con
 // ---- densification statistics (GaussianSplattingModel.after_train,
 // gs_toolkit/models/vanilla_gs.py:344-372): for the Gaussians visible in this view
 //   xys_grad_norm += |xys.grad|;  vis_counts += 1;  max_2dsize = max(max_2dsize, radius / max(W, H))
-// -- ~10 masked-indexing launches per iteration there, one here.
+// -- ~10 masked-indexing launches per iteration there, one here.  `first` is the
+// reference's first call after a refinement (:354-356): every Gaussian starts with
+// count 1 and its own gradient norm, whether visible or not.
 namespace {
 __global__ __launch_bounds__(256) void densify_stats_kernel(const int n, const float2 *__restrict__ v_xys,
                                                             const int *__restrict__ radii, const float inv_size,
-                                                            float *__restrict__ xys_grad_norm,
+                                                            const int first, float *__restrict__ xys_grad_norm,
                                                             int *__restrict__ vis_counts,
                                                             float *__restrict__ max_2dsize) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int r = radii[i];
-  if (r <= 0) return;
-  if (v_xys) {
+  float norm = 0.f;
+  if (v_xys && (first || r > 0)) {
     const float2 g = v_xys[i];
-    xys_grad_norm[i] += sqrtf(g.x * g.x + g.y * g.y);
+    norm = sqrtf(g.x * g.x + g.y * g.y);
   }
+  if (first) {
+    xys_grad_norm[i] = norm;
+    vis_counts[i] = 1;
+    max_2dsize[i] = r > 0 ? fmaxf(0.f, (float)r * inv_size) : 0.f;
+    return;
+  }
+  if (r <= 0) return;
+  if (v_xys) xys_grad_norm[i] += norm;
   vis_counts[i] += 1;
   max_2dsize[i] = fmaxf(max_2dsize[i], (float)r * inv_size);
 }
 }  // namespace
 
-GSR_EXPORT int gsr_densify_stats(int num_points, const float *v_xys, const int32_t *radii, float inv_size,
+GSR_EXPORT int gsr_densify_stats(int num_points, const float *v_xys, const int32_t *radii, float inv_size, int first,
                                  float *xys_grad_norm, int32_t *vis_counts, float *max_2dsize,
                                  gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0, "densify_stats: num_points < 0");
@@ -133,7 +143,7 @@ GSR_EXPORT int gsr_densify_stats(int num_points, const float *v_xys, const int32
   GSR_REQUIRE(radii && xys_grad_norm && vis_counts && max_2dsize, "densify_stats: null pointer");
   GSR_REQUIRE(v_xys == nullptr || (reinterpret_cast<uintptr_t>(v_xys) & 7u) == 0, "densify_stats: v_xys must be 8-byte aligned");
   hipLaunchKernelGGL(densify_stats_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream,
-                     num_points, reinterpret_cast<const float2 *>(v_xys), radii, inv_size, xys_grad_norm,
+                     num_points, reinterpret_cast<const float2 *>(v_xys), radii, inv_size, first, xys_grad_norm,
                      vis_counts, max_2dsize);
   GSR_CHECK_LAUNCH("densify_stats");
   return GSR_OK;

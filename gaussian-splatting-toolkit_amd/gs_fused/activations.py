@@ -82,10 +82,13 @@ def activate_gaussians(means: Optional[Tensor], log_scales: Tensor, raw_quats: T
 
 @torch.no_grad()
 def densify_stats_(xys_grad: Optional[Tensor], radii: Tensor, image_size: int, xys_grad_norm: Tensor,
-                   vis_counts: Tensor, max_2dsize: Tensor) -> None:
+                   vis_counts: Tensor, max_2dsize: Tensor, first: bool = False) -> None:
     """In place, for the Gaussians with ``radii > 0`` (GaussianSplattingModel.after_train,
     vanilla_gs.py:344-372): ``xys_grad_norm += |xys_grad|``, ``vis_counts += 1``,
-    ``max_2dsize = max(max_2dsize, radii / image_size)`` -- one launch (``gsr_densify_stats``)."""
+    ``max_2dsize = max(max_2dsize, radii / image_size)`` -- one launch (``gsr_densify_stats``).
+    ``first=True`` is the reference's first call after a refinement (:354-356, the
+    accumulators are ``None`` there): every Gaussian starts with count 1 and its own
+    gradient norm, visible or not; the accumulators need not be initialised."""
     n = radii.numel()
     _check(radii, "radii", torch.int32)
     _check(xys_grad_norm, "xys_grad_norm", _f32)
@@ -100,5 +103,5 @@ def densify_stats_(xys_grad: Optional[Tensor], radii: Tensor, image_size: int, x
     dev = radii.device
     with torch.cuda.device(dev):
         _call("gsr_densify_stats", C.c_int(n), _ptr(xys_grad) if xys_grad is not None else None, _ptr(radii),
-              C.c_float(1.0 / float(image_size)), _ptr(xys_grad_norm), _ptr(vis_counts), _ptr(max_2dsize),
-              _stream(dev))
+              C.c_float(1.0 / float(image_size)), C.c_int(1 if first else 0), _ptr(xys_grad_norm),
+              _ptr(vis_counts), _ptr(max_2dsize), _stream(dev))

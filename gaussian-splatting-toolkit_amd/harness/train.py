@@ -14,8 +14,13 @@ calls the real models make):
   * one Adam optimiser per parameter group with the learning rates of
     gs_toolkit/configs/method_configs.py:98-132;
   * `xys.retain_grad()` and the densification statistics of `after_train`
-    (vanilla_gs.py:344-372) -- accumulated (and all-reduced) but, in this
-    harness, not acted upon: N stays fixed so iterations are comparable.
+    (vanilla_gs.py:344-372), and -- with `TrainConfig.densify` -- the refinement
+    schedule of `refinement_after` (:381-497) every `refine_every` iterations:
+    split / duplicate / cull / opacity reset with the Adam state carried along
+    (`gs_fused.refine_gaussians`, one compaction launch).  Under data parallelism
+    the statistics are all-reduced first and the split samples come from a
+    counter-based generator keyed on (seed, step, Gaussian index), so every replica
+    takes the same decisions and stays bit-identical.
 The data side (cameras on a sphere, ground truth rendered by this rasterizer
 from a hidden "true" scene) replaces the toolkit's datamanager.
 """
@@ -33,6 +38,8 @@ import torch.nn.functional as F
 from . import scene as S
 from .parallel import allreduce_densify_stats, allreduce_gradients, view_for_rank
 from .pipeline import CameraTensors, render_view
+
+PARAM_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
 
 LRS = {"means": 1.6e-4, "features_dc": 0.0025, "features_rest": 0.0025 / 20, "opacities": 0.05,
        "scales": 0.005, "quats": 0.001}
@@ -93,7 +100,13 @@ class GaussianParams(torch.nn.Module):
         return self.gauss["means"].shape[0]
 
     def param_list(self) -> List[torch.nn.Parameter]:
-        return [self.gauss[k] for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities")]
+        return [self.gauss[k] for k in PARAM_NAMES]
+
+    def replace(self, new: Dict[str, torch.Tensor]) -> None:
+        """Install refined tensors as the model's parameters (vanilla_gs.py:440-447, 532)."""
+        for k in PARAM_NAMES:
+            if new[k] is not self.gauss[k]:
+                self.gauss[k] = torch.nn.Parameter(new[k])
 
     def render(self, cam: CameraTensors, background, sh_degree_to_use: int, render_depth=False,
                retain_xys_grad=False, clamp_rgb=True):
@@ -162,6 +175,11 @@ class TrainConfig:
     torch_fused_adam: bool = False  # (A/B) torch's own fused multi-tensor Adam instead
     split_sh: bool = True     # gs_fused.spherical_harmonics_split instead of torch.cat + spherical_harmonics
     fused_activations: bool = True  # gs_fused.activate_gaussians instead of exp / normalise / sigmoid / viewdirs
+    # refinement (vanilla_gs.py:381-497).  Off: N stays fixed and iterations are comparable.
+    densify: bool = False
+    init_gaussians: Optional[int] = None  # the model starts from this many (coarser) Gaussians; default: all
+    refine: Optional[object] = None       # gs_fused.RefineConfig; default: the reference's values
+    refine_seed: int = 20240807           # broadcast by construction: the same on every rank
 
 
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
@@ -182,6 +200,12 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     raw["features_dc"] *= 0.3
     raw["features_rest"] *= 0.0
     raw["opacities"] -= 0.5
+    if cfg.init_gaussians is not None and cfg.init_gaussians < cfg.num_gaussians:
+        # a coarser start for densification to refine: a subset, each Gaussian standing in for
+        # num/init of the truth's (scales grown by the cube root of that ratio)
+        keep = np.sort(rng.choice(cfg.num_gaussians, cfg.init_gaussians, replace=False))
+        raw = {k: np.ascontiguousarray(v[keep]) for k, v in raw.items()}
+        raw["scales"] += np.float32(math.log(cfg.num_gaussians / cfg.init_gaussians) / 3.0)
     model = GaussianParams(raw, device)
     model.split_sh = truth.split_sh = cfg.split_sh
     model.fused_activations = truth.fused_activations = cfg.fused_activations
@@ -196,7 +220,6 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             optims = {"all": FusedAdam(groups, eps=1e-15)}
     else:
         optims = {k: torch.optim.Adam([model.gauss[k]], lr=lr, eps=1e-15) for k, lr in LRS.items()}
-    plist = model.param_list()
     fused_clamp = False
     if cfg.fused_loss and device.type == "cuda":
         from gs_fused import l1_ssim_loss
@@ -211,10 +234,19 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     fused_stats = cfg.fused_activations and device.type == "cuda" and os.environ.get("GSR_AB_STATS", "1") != "0"
     if fused_stats:
         from gs_fused import densify_stats_
-    n = model.num_points
+    n = n0 = model.num_points
     xys_grad_norm = torch.zeros(n, device=device)
     vis_counts = torch.zeros(n, device=device, dtype=torch.int32)
     max_2dsize = torch.zeros(n, device=device)
+    stats_first = cfg.densify  # the reference's `xys_grad_norm is None` (vanilla_gs.py:354)
+    rcfg = cfg.refine
+    if cfg.densify:
+        if rcfg is None:
+            from gs_fused import RefineConfig
+
+            rcfg = RefineConfig()
+    history = []  # (step, N) after every refinement that changed the model
+    max_dim = max(cfg.width, cfg.height)
 
     def evaluate():
         with torch.no_grad():
@@ -237,23 +269,56 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         rgb = out["rgb"]
         loss = loss_fn(rgb, gt[v])
         loss.backward()
-        # densification statistics (vanilla_gs.py:344-372)
-        if fused_stats:
-            densify_stats_(out["xys"].grad, out["radii"], max(cfg.width, cfg.height), xys_grad_norm, vis_counts,
-                           max_2dsize)
+        # densification statistics (vanilla_gs.py:344-372; not updated past stop_split_at, :347)
+        if cfg.densify and step >= rcfg.stop_split_at:
+            pass
+        elif fused_stats:
+            densify_stats_(out["xys"].grad, out["radii"], max_dim, xys_grad_norm, vis_counts, max_2dsize,
+                           first=stats_first)
         else:
             with torch.no_grad():
                 visible = out["radii"] > 0
                 g = out["xys"].grad
-                if g is not None:
-                    xys_grad_norm += torch.where(visible, g.norm(dim=-1), torch.zeros_like(xys_grad_norm))
-                vis_counts += visible.to(torch.int32)
-                max_2dsize = torch.where(visible, torch.maximum(
-                    max_2dsize, out["radii"].float() / max(cfg.width, cfg.height)), max_2dsize)
+                gnorm = torch.zeros_like(xys_grad_norm) if g is None else g.norm(dim=-1)
+                size = out["radii"].float() / max_dim
+                if stats_first:
+                    xys_grad_norm, vis_counts = gnorm.clone(), torch.ones_like(vis_counts)
+                    max_2dsize = torch.where(visible, size, torch.zeros_like(size))
+                else:
+                    xys_grad_norm += torch.where(visible, gnorm, torch.zeros_like(xys_grad_norm))
+                    vis_counts += visible.to(torch.int32)
+                    max_2dsize = torch.where(visible, torch.maximum(max_2dsize, size), max_2dsize)
+        stats_first = False
         if world > 1:
-            allreduce_gradients(plist, average=True)
+            allreduce_gradients(model.param_list(), average=True)
         for o in optims.values():
             o.step()
+        # refinement_after: every refine_every iterations, after the optimizer step
+        # (TrainingCallback(update_every_num_iters=refine_every), vanilla_gs.py:610-616)
+        if cfg.densify and step % rcfg.refine_every == 0 and step > rcfg.warmup_length:
+            branch, reset = _refinement_branch(rcfg, step, cfg.num_views)
+            if branch != "none" or reset:
+                if world > 1 and branch == "densify":
+                    allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize)
+                old = {k: model.gauss[k] for k in PARAM_NAMES}
+                moments = {}
+                for o in optims.values():
+                    moments.update(_adam_moments(o, old))
+                new, new_moments, info = _refine(old, moments, (xys_grad_norm, vis_counts, max_2dsize), rcfg, step,
+                                                 cfg.num_views, max_dim, seed=cfg.refine_seed + step)
+                if any(new[k] is not old[k] for k in PARAM_NAMES):
+                    model.replace(new)
+                    cur = {k: model.gauss[k] for k in PARAM_NAMES}
+                    for o in optims.values():
+                        _swap_parameters(o, old, cur, new_moments)
+                    if info["n_out"] != info["n_in"]:
+                        n = info["n_out"]
+                        xys_grad_norm = torch.empty(n, device=device)
+                        vis_counts = torch.empty(n, device=device, dtype=torch.int32)
+                        max_2dsize = torch.empty(n, device=device)
+                    history.append((step, model.num_points))
+            # the statistics restart after every refinement_after past the warm-up (:491-493)
+            stats_first = True
         if cfg.log_every and step % cfg.log_every == 0:
             losses.append(float(loss.detach()))
     if world > 1:
@@ -263,7 +328,33 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     psnr1 = evaluate()
-    checksum = float(sum(p.detach().double().sum() for p in plist))
+    checksum = float(sum(p.detach().double().sum() for p in model.param_list()))
     return {"iters": cfg.iters, "seconds": elapsed, "iters_per_s": cfg.iters / elapsed, "psnr_start": psnr0,
             "psnr_end": psnr1, "losses": losses, "param_checksum": checksum,
-            "views_per_s": world * cfg.iters / elapsed}
+            "views_per_s": world * cfg.iters / elapsed, "num_gaussians_start": n0,
+            "num_gaussians_end": model.num_points, "refinements": history}
+
+
+# the refinement backend (module-level so that CPU tests can substitute stand-ins)
+def _refinement_branch(rcfg, step, num_train_data):
+    from gs_fused import refinement_branch
+
+    return refinement_branch(rcfg, step, num_train_data)
+
+
+def _adam_moments(optimizer, params):
+    from gs_fused import adam_moments
+
+    return adam_moments(optimizer, params)
+
+
+def _swap_parameters(optimizer, old, new, new_moments):
+    from gs_fused import swap_parameters
+
+    return swap_parameters(optimizer, old, new, new_moments)
+
+
+def _refine(params, moments, stats, rcfg, step, num_train_data, max_dim, seed):
+    from gs_fused import refine_gaussians
+
+    return refine_gaussians(params, moments, stats, rcfg, step, num_train_data, max_dim, seed=seed)

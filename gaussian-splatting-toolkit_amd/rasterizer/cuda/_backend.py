@@ -52,6 +52,9 @@ SYMBOLS = (
     "gsr_activate_forward",
     "gsr_activate_backward",
     "gsr_densify_stats",
+    "gsr_refine_workspace_bytes",
+    "gsr_refine_plan",
+    "gsr_refine_apply",
     "gsr_adam_step",
 )
 
@@ -80,6 +83,7 @@ def _load():
     lib.gsr_reach_record_bytes.restype = C.c_size_t
     lib.gsr_depth_order_workspace_bytes.restype = C.c_size_t
     lib.gsr_bin_sorted_workspace_bytes.restype = C.c_size_t
+    lib.gsr_refine_workspace_bytes.restype = C.c_size_t
     return lib
 
 

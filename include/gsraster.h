@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 100 /* 0.1.0 */
+#define GSR_VERSION 200 /* 0.2.0 */
 
 #define GSR_OK 0
 #define GSR_EINVAL -1   /* bad argument (shape / range / null pointer) */
@@ -367,11 +367,85 @@ int gsr_activate_backward(int num_points, const float *raw_quats,
  * GaussianSplattingModel.after_train (gs_toolkit/models/vanilla_gs.py:344-372) in
  * one launch: for every Gaussian with radii > 0,
  *   xys_grad_norm += |v_xys| (skipped if v_xys is NULL), vis_counts += 1,
- *   max_2dsize = max(max_2dsize, radii * inv_size),   inv_size = 1 / max(W, H). */
+ *   max_2dsize = max(max_2dsize, radii * inv_size),   inv_size = 1 / max(W, H).
+ * first != 0 is the reference's first call after a refinement (:354-356,
+ * `xys_grad_norm = grads; vis_counts = ones`): EVERY Gaussian gets count 1 and its
+ * gradient norm (zero for the invisible ones), max_2dsize starts from 0; the three
+ * arrays need not be initialised. */
 int gsr_densify_stats(int num_points, const float *v_xys, const int32_t *radii,
-                      float inv_size, float *xys_grad_norm,
+                      float inv_size, int first, float *xys_grad_norm,
                       int32_t *vis_counts, float *max_2dsize,
                       gsr_stream_t stream);
+
+/* ---- refinement: densify / split / duplicate / cull --------
+ * GaussianSplattingModel.refinement_after (gs_toolkit/models/vanilla_gs.py:381-497)
+ * with split_gaussians :540-592, dup_gaussians :594-603, cull_gaussians :499-538 and
+ * the optimizer surgery dup_in_optim :303-337 / remove_from_optim :282-301, as a
+ * plan (decisions + final positions) and ONE compaction launch over all tensors.
+ * The host decides the branch from the step counter and fills the config:
+ *   densify              step < stop_split_at and step % (reset_alpha_every *
+ *                        refine_every) > num_train_data + refine_every  (:390-395);
+ *                        0 = cull only (:459-463)
+ *   split_by_screen_size step < stop_screen_size_at (:421)
+ *   cull_big             step > refine_every * reset_alpha_every (:512)
+ *   cull_by_screen_size  step < stop_screen_size_at (:518)
+ *   half_max_dim         0.5 * max(W, H) of the last rendered view (:404-408)
+ * gsr_refine_plan writes flags[n] (bit 0: the original survives, 1: its split
+ * children survive, 2: its duplicate survives, 3: it was split), offsets[n,4] (i32,
+ * 16-byte aligned: exclusive prefix counts of those four bits) and counts[4] =
+ * {kept originals K0, kept split sources Ks, kept duplicates Kd, split sources}.
+ * The output has K0 + n_split_samples * Ks + Kd rows: the caller reads counts back,
+ * allocates, and calls gsr_refine_apply, which moves/creates the rows of up to
+ * GSR_REFINE_MAX_TENSORS tensors ([n, width] fp32 each) in one launch:
+ * originals in order, then split children sample by sample, then duplicates -- the
+ * order of the reference's cat + cull.  kind says what new rows hold:
+ *   COPY        the parent's row (quats, features_dc, features_rest, opacities)
+ *   LOG_SCALES  log(exp(s) / 1.6) for children (and duplicates) of a split Gaussian
+ *   MEANS       split children: mean + R(q/|q|) (exp(s) * z), z ~ N(0,1)
+ *   MOMENT      zeros (exp_avg / exp_avg_sq of the new rows)
+ * z comes from samples [n_split_samples * split sources, 3] (row j * sources +
+ * rank, the reference's torch.randn layout) or, if samples is NULL, from
+ * Philox4x32-10 with key = seed and counter = (Gaussian index, j, 0, 0) + Box-Muller.
+ * vis_counts is int32 (gsr_densify_stats); max_2dsize may be NULL when no
+ * screen-size rule is on. */
+typedef struct {
+  float densify_grad_thresh;
+  float densify_size_thresh;
+  float split_screen_size;
+  float cull_alpha_thresh;
+  float cull_scale_thresh;
+  float cull_screen_size;
+  float half_max_dim;
+  int n_split_samples;
+  int densify;
+  int split_by_screen_size;
+  int cull_big;
+  int cull_by_screen_size;
+} gsr_refine_config;
+#define GSR_REFINE_COPY 0
+#define GSR_REFINE_LOG_SCALES 1
+#define GSR_REFINE_MEANS 2
+#define GSR_REFINE_MOMENT 3
+#define GSR_REFINE_MAX_TENSORS 24
+typedef struct {
+  const float *in; /* [n, width] */
+  float *out;      /* [K0 + n_split_samples * Ks + Kd, width] */
+  int width;
+  int kind;
+} gsr_refine_tensor;
+size_t gsr_refine_workspace_bytes(int num_points);
+int gsr_refine_plan(int num_points, const float *log_scales,
+                    const float *opacity_logits, const float *xys_grad_norm,
+                    const int32_t *vis_counts, const float *max_2dsize,
+                    const gsr_refine_config *cfg, uint8_t *flags,
+                    int32_t *offsets, int32_t *counts, void *workspace,
+                    size_t workspace_bytes, gsr_stream_t stream);
+int gsr_refine_apply(int num_points, int n_split_samples, const uint8_t *flags,
+                     const int32_t *offsets, const int32_t *counts,
+                     const float *log_scales, const float *raw_quats,
+                     const float *samples, unsigned long long seed,
+                     int num_tensors, const gsr_refine_tensor *tensors,
+                     gsr_stream_t stream);
 
 /* ---- optimiser step ------------------------------------
  * Adam over up to GSR_ADAM_MAX_TENSORS tensors in one launch; replaces the

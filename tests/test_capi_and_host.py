@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"{s} declared in gsraster.h but not exported"
     assert sorted(_backend.SYMBOLS) == header_symbols()
     lib.gsr_version.restype = ctypes.c_int
-    assert lib.gsr_version() == 100
+    assert lib.gsr_version() == 200
     lib.gsr_last_error.restype = ctypes.c_char_p
     assert lib.gsr_last_error() == b""
 
