@@ -69,19 +69,36 @@ def orbit_cameras(n_views: int, width: int, height: int, radius: float = 6.0, fo
     return cams
 
 
-def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale_lo=0.01, scale_hi=0.06):
-    """Gaussians in a ball around the origin (raw, pre-activation parameters)."""
+def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale_lo=0.01, scale_hi=0.06,
+               kind: str = "ball"):
+    """Raw (pre-activation) Gaussians around the origin.  kind="ball": semi-transparent
+    Gaussians filling a ball (a smooth volume).  kind="shell": opaque, small, flat-ish
+    Gaussians on three nested textured spheres -- surfaces with detail at the pixel scale,
+    the kind of scene densification exists for."""
     rng = np.random.default_rng(seed)
     p = rng.standard_normal((n, 3))
-    p *= (extent * rng.uniform(0, 1, (n, 1)) ** (1 / 3)) / np.linalg.norm(p, axis=-1, keepdims=True)
+    p /= np.linalg.norm(p, axis=-1, keepdims=True)
     K = S.num_sh_bases(sh_degree)
     f32 = np.float32
+    if kind == "shell":
+        radius = np.array([0.7, 1.1, 1.5])[rng.integers(0, 3, n)][:, None]
+        means = p * (radius + 0.004 * rng.standard_normal((n, 1)))
+        # texture: colour varies smoothly over the sphere plus per-Gaussian contrast
+        tex = 0.5 + 0.5 * np.sin(9.0 * p @ rng.standard_normal((3, 3)) + 5.0 * radius)
+        dc = (0.7 * tex + 0.3 * rng.uniform(0, 1, (n, 3)) - 0.5) / SH_C0
+        scales = rng.uniform(math.log(scale_lo), math.log(scale_hi), (n, 3))
+        opac = rng.uniform(1.0, 4.0, (n, 1))
+    else:
+        means = p * (extent * rng.uniform(0, 1, (n, 1)) ** (1 / 3))
+        dc = (rng.uniform(0, 1, (n, 3)) - 0.5) / SH_C0
+        scales = np.log(np.exp(rng.uniform(math.log(scale_lo), math.log(scale_hi), (n, 3))))
+        opac = rng.uniform(-1.0, 2.0, (n, 1))  # logits
     return {
-        "means": p.astype(f32),
-        "scales": np.log(np.exp(rng.uniform(math.log(scale_lo), math.log(scale_hi), (n, 3)))).astype(f32),
+        "means": means.astype(f32),
+        "scales": scales.astype(f32),
         "quats": rng.standard_normal((n, 4)).astype(f32),
-        "opacities": rng.uniform(-1.0, 2.0, (n, 1)).astype(f32),  # logits
-        "features_dc": (rng.uniform(0, 1, (n, 3)) - 0.5).astype(f32) / f32(SH_C0),
+        "opacities": opac.astype(f32),
+        "features_dc": dc.astype(f32),
         "features_rest": (rng.standard_normal((n, K - 1, 3)) * 0.05).astype(f32),
     }
 
@@ -180,6 +197,8 @@ class TrainConfig:
     init_gaussians: Optional[int] = None  # the model starts from this many (coarser) Gaussians; default: all
     refine: Optional[object] = None       # gs_fused.RefineConfig; default: the reference's values
     refine_seed: int = 20240807           # broadcast by construction: the same on every rank
+    scene: str = "ball"                   # blob_scene kind
+    scene_scale: tuple = (0.01, 0.06)     # range of the truth's Gaussian scales
 
 
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
@@ -189,12 +208,14 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     cams = [CameraTensors.from_numpy(c, device) for c in cams_np]
     bg = torch.tensor(S.BACKGROUND, device=device)
 
-    truth = GaussianParams(blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree), device)
+    mk = lambda: blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree, kind=cfg.scene,
+                            scale_lo=cfg.scene_scale[0], scale_hi=cfg.scene_scale[1])
+    truth = GaussianParams(mk(), device)
     with torch.no_grad():
         gt = [truth.render(c, bg, cfg.sh_degree)["rgb"] for c in cams]
 
     # the model starts from the truth with perturbed geometry / washed-out colour
-    raw = blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree)
+    raw = mk()
     rng = np.random.default_rng(cfg.seed + 1)
     raw["means"] += rng.standard_normal(raw["means"].shape).astype(np.float32) * 0.01
     raw["features_dc"] *= 0.3

@@ -1,0 +1,80 @@
+"""CPU, world_size 2, gloo: the trainer's data-parallel logic end to end
+(`harness.train.train(world=2)`: per-rank views, gradient all-reduce, Adam,
+all-reduced densification statistics, refinement with counter-based split samples,
+optimizer-state surgery) on CPU stand-ins of the native ops (tests/cpu_standins.py,
+backed by the oracle).  Both replicas must end bit-identical, with the same N.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRAD_THRESH = 0.001  # 64x48 images: the per-pixel gradients are far above those at 1080p
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(2)
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cpu_standins as SI
+    import harness.pipeline as HP
+    import harness.train as HT
+    from gs_fused import RefineConfig
+    from oracle import oracle as O
+
+    O.set_threads(2)
+    HP.project_gaussians, HP.spherical_harmonics, HP.rasterize_gaussians = (
+        SI.project_gaussians, SI.spherical_harmonics, SI.rasterize_gaussians)
+    HT._refine = lambda params, moments, stats, rcfg, step, ntd, max_dim, seed: SI.refine_gaussians(
+        params, moments, stats, rcfg, step, ntd, max_dim, seed=seed)
+    # compressed schedule: densify at steps 20 and 50 (step % 30 > num_views + 10), opacity reset at
+    # 10 and 40, cull only from step 55 on
+    rcfg = RefineConfig(warmup_length=9, refine_every=10, reset_alpha_every=3, stop_screen_size_at=30,
+                        stop_split_at=55, densify_grad_thresh=GRAD_THRESH, cull_alpha_thresh=0.05)
+    cfg = HT.TrainConfig(num_gaussians=600, init_gaussians=200, width=64, height=48, num_views=4, iters=62,
+                         sh_degree=1, sh_degree_interval=10, eval_views=2, densify=True, refine=rcfg,
+                         scene_scale=(0.03, 0.15))
+    res = HT.train(cfg, torch.device("cpu"), rank, world)
+    q.put((rank, res["param_checksum"], res["num_gaussians_start"], res["num_gaussians_end"], res["refinements"],
+           res["psnr_start"], res["psnr_end"]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_training_with_refinement_keeps_replicas_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = results
+    assert a[2] == b[2] == 200
+    assert a[4] == b[4] and len(a[4]) >= 2, (a[4], b[4])       # same refinement history, N changed
+    assert a[3] == b[3] and a[3] != 200                          # same final N on both ranks
+    assert a[1] == b[1], (a[1], b[1])                            # bit-identical parameters (checksum in double)
+    import math
+
+    assert math.isfinite(a[1]) and math.isfinite(a[6])

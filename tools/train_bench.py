@@ -30,6 +30,13 @@ def main():
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--densify", action="store_true", help="refinement_after every refine_every iterations (config 3/5)")
+    ap.add_argument("--init-gaussians", type=int, default=None, help="the model starts from this many coarser Gaussians")
+    ap.add_argument("--sh-interval", type=int, default=None, help="SH degree warm-up interval (reference: 1000)")
+    ap.add_argument("--grad-thresh", type=float, default=None, help="densify_grad_thresh (reference: 0.0002)")
+    ap.add_argument("--log-every", type=int, default=0)
+    ap.add_argument("--scene", default="ball", choices=["ball", "shell"])
+    ap.add_argument("--scene-scale", type=float, nargs=2, default=[0.01, 0.06])
     ap.add_argument("--torch-activations", action="store_true", help="A/B: torch ops for exp/normalise/sigmoid/viewdirs")
     ap.add_argument("--cat-sh", action="store_true", help="A/B: torch.cat + spherical_harmonics instead of the split op")
     ap.add_argument("--torch-fused-adam", action="store_true", help="A/B: torch's fused Adam instead of gs_fused.FusedAdam")
@@ -46,9 +53,20 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
+    rcfg = None
+    if args.densify:
+        from gs_fused import RefineConfig
+
+        rcfg = RefineConfig()
+        if args.grad_thresh is not None:
+            rcfg.densify_grad_thresh = args.grad_thresh
     cfg = TrainConfig(num_gaussians=args.gaussians, width=args.width, height=args.height,
-                      num_views=args.views, iters=args.iters, sh_degree_interval=max(1, args.iters // 4),
-                      torch_fused_adam=args.torch_fused_adam, split_sh=not args.cat_sh, fused_activations=not args.torch_activations)
+                      num_views=args.views, iters=args.iters,
+                      sh_degree_interval=args.sh_interval or max(1, args.iters // 4),
+                      torch_fused_adam=args.torch_fused_adam, split_sh=not args.cat_sh,
+                      fused_activations=not args.torch_activations, densify=args.densify,
+                      init_gaussians=args.init_gaussians, refine=rcfg, log_every=args.log_every,
+                      scene=args.scene, scene_scale=tuple(args.scene_scale))
     res = train(cfg, dev, rank, world)
     if world > 1:
         cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
@@ -57,7 +75,9 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         res["replicas_identical"] = bool(lo.item() == hi.item())
     if rank == 0:
-        res.pop("losses", None)
+        losses = res.pop("losses", None)
+        if losses:
+            res["loss_first_last"] = [losses[0], losses[-1]]
         res.update(metric="train iters/s", n_gpus=world, gaussians=args.gaussians,
                    resolution=f"{args.width}x{args.height}")
         print(json.dumps(res), flush=True)
