@@ -32,9 +32,10 @@ int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsig
                        hipStream_t s);
 
 // tile_scatter.hip
-bool gsr_tile_scatter_supported(int num_tiles);
-size_t gsr_tile_scatter_workspace_bytes(int I, int num_tiles);
-int gsr_tile_scatter(int I, const int *I_dev, const unsigned *keys, const int *gids, int num_tiles,
+int gsr_tile_band_rows(int tiles_x, int tiles_y, int *rows_per_band);
+bool gsr_tile_scatter_supported(int tiles_x, int tiles_y);
+size_t gsr_tile_scatter_workspace_bytes(int I, int tiles_per_band, int bands);
+int gsr_tile_scatter(int I, const int *cum, int n, const unsigned *keys, const int *gids, int tiles_x, int tiles_y,
                      int *ids_sorted, int *tile_bins, int *count_out, void *workspace, size_t workspace_bytes,
                      hipStream_t s);
 
@@ -44,9 +45,15 @@ namespace {
 constexpr int kMidSortMin = 1 << 16, kMidSortMax = 1 << 22;
 inline bool use_mid_sort(int n) { return n > kMidSortMin && n <= kMidSortMax; }
 
+// element j of the (band, depth position) sequence the tile counts are scanned in:
+// counts[band j / n][order[j % n]]
 struct TilesInOrder {
-  const int *tiles;
-  __device__ __forceinline__ int operator()(int g) const { return tiles[g]; }
+  const int *tiles, *order;
+  int n;
+  __device__ __forceinline__ int operator()(int j) const {
+    const int b = j / n;
+    return tiles[(size_t)b * n + order[j - b * n]];
+  }
 };
 
 __global__ __launch_bounds__(256) void depth_keys_kernel(const int n, const float *__restrict__ depths,
@@ -133,27 +140,33 @@ __device__ __forceinline__ void row_range(const SplatRec &r, const RowParams &p,
 // and lane l takes rows l, l+64, ... -- a lane per Gaussian looping over its own
 // box leaves most of the wave idle behind the largest splat.
 //
-//   mode 0 (count): Gaussians in index order; writes counts[g] and recs[g]
-//   mode 1 (emit):  Gaussians in depth order (`order`); the tiles of a row are
-//           written at cum[first Gaussian of the wave - 1] + rank, which keeps the
-//           stream ordered by (depth position, tile row-major)
+//   mode 0 (count): Gaussians in index order; writes counts[band][g] and recs[g]
+//   mode 1 (emit):  Gaussians in depth order (`order`), one band of tile rows per
+//           blockIdx.y; the tiles of a row are written at
+//           cum[band n + first Gaussian of the wave - 1] + rank, which keeps the
+//           stream ordered by (band, depth position, tile row-major)
 //
 // With `recs == nullptr` (mode 1 only) every box tile is emitted: the reference's
 // lists.  Both modes evaluate row_range() with the same instructions on the same
-// record, so counts and emission agree exactly.
+// record, so counts and emission agree exactly.  kBands: more than one band of
+// `rows_per_band` tile rows (tile_scatter.hip); the single-band instantiation keeps
+// one counter per Gaussian in LDS.
+constexpr int kMaxBands = 16;
+template <bool kBands>
 __global__ __launch_bounds__(256) void tile_rows_kernel(
     const int mode, const int n, const int *__restrict__ order, const int *__restrict__ cum,
     const float *__restrict__ xys, const int *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ opacities, const int tiles_x, const int tiles_y, const int bw,
     SplatRec *__restrict__ recs, unsigned *__restrict__ tile_keys, int *__restrict__ gaussian_ids,
-    int *__restrict__ counts, const int capacity) {
+    int *__restrict__ counts, const int capacity, const int num_bands, const int rows_per_band) {
   __shared__ int s_pref[4][64];
-  __shared__ int s_cnt[4][64];
+  __shared__ int s_cnt[4][kBands ? kMaxBands : 1][64];
   __shared__ int s_gid[4][64];
   __shared__ SplatRec s_rec[4][64];
   __shared__ RowParams s_par[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i0 = (blockIdx.x * 4 + w) * 64, i = i0 + lane;
+  const int band = kBands ? (int)blockIdx.y : 0;  // mode 1
   const int g = i < n ? (mode ? order[i] : i) : 0;
   SplatRec rec{0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0u, 0u};
   if (i < n) {
@@ -182,6 +195,12 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(
       }
       if (!mode) recs[g] = rec;
     }
+    if (kBands && mode) {  // keep the rows of this band only
+      const int miny = (int)(rec.box0 >> 16), maxy = miny + (int)(rec.box1 >> 16);
+      const int lo = max(miny, band * rows_per_band), hi = min(maxy, (band + 1) * rows_per_band);
+      rec.box0 = (rec.box0 & 0xffffu) | ((unsigned)lo << 16);
+      rec.box1 = (rec.box1 & 0xffffu) | ((unsigned)(hi > lo ? hi - lo : 0) << 16);
+    }
   }
   const int rows = (int)(rec.box1 >> 16);
   int incl = rows;
@@ -192,13 +211,20 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(
   }
   const int total = __shfl(incl, 63);
   s_pref[w][lane] = incl;
-  s_cnt[w][lane] = 0;
+  if (kBands) {
+    for (int b = 0; b < num_bands; ++b) s_cnt[w][b][lane] = 0;
+  } else {
+    s_cnt[w][0][lane] = 0;
+  }
   s_gid[w][lane] = g;
   s_rec[w][lane] = rec;
   s_par[w][lane] = make_row_params(rec);
   __syncthreads();
   int out = 0;
-  if (mode) out = (i0 > 0 && i0 < n) ? cum[i0 - 1] : 0;
+  if (mode && i0 < n) {
+    const long long ci = (long long)band * n + i0;
+    out = ci > 0 ? cum[ci - 1] : 0;
+  }
   for (int q0 = 0; q0 < total; q0 += 64) {
     const int q = q0 + lane;
     int k = 0;  // number of Gaussians whose rows all precede q
@@ -227,10 +253,16 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(
       }
       out += __shfl(sc, 63);
     } else if (cnt > 0) {
-      atomicAdd(&s_cnt[w][k], cnt);
+      atomicAdd(&s_cnt[w][kBands ? ty / rows_per_band : 0][k], cnt);
     }
   }
-  if (!mode && i < n) counts[i] = s_cnt[w][lane];
+  if (!mode && i < n) {
+    if (kBands) {
+      for (int b = 0; b < num_bands; ++b) counts[(size_t)b * n + i] = s_cnt[w][b][lane];
+    } else {
+      counts[i] = s_cnt[w][0][lane];
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void tile_bins_clear_kernel(const int num_tiles, int2 *__restrict__ tile_bins) {
@@ -277,10 +309,10 @@ size_t depth_sort_temp(int n) {
                                                      (int *)nullptr, (size_t)n, 0, 31);
   return b;
 }
-size_t scan_temp(int n) {
+size_t scan_temp(size_t n) {
   size_t b = 0;
-  auto in = rocprim::make_transform_iterator((const int *)nullptr, TilesInOrder{nullptr});
-  (void)rocprim::inclusive_scan(nullptr, b, in, (int *)nullptr, (size_t)n, rocprim::plus<int>());
+  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), TilesInOrder{nullptr, nullptr, 1});
+  (void)rocprim::inclusive_scan(nullptr, b, in, (int *)nullptr, n, rocprim::plus<int>());
   return b;
 }
 size_t tile_sort_temp(int I) {
@@ -292,22 +324,31 @@ size_t tile_sort_temp(int I) {
 
 }  // namespace
 
-GSR_EXPORT size_t gsr_depth_order_workspace_bytes(int num_points) {
+GSR_EXPORT int gsr_tile_bands(int tiles_x, int tiles_y) {
+  const int b = gsr_tile_band_rows(tiles_x, tiles_y, nullptr);
+  return b > 0 ? b : 1;
+}
+
+GSR_EXPORT size_t gsr_depth_order_workspace_bytes(int num_points, int num_bands) {
   if (num_points <= 0) return 0;
+  if (num_bands < 1) num_bands = 1;
   const size_t kb = align_up(sizeof(unsigned) * (size_t)num_points);
+  const size_t st = scan_temp((size_t)num_points * num_bands);
   // [depth keys][ either: rocPRIM (sorted keys + temp)  or: sort_mid workspace ; scan temp shares it ]
-  const size_t rocprim_need = kb + align_up(std::max(depth_sort_temp(num_points), scan_temp(num_points)));
-  const size_t mid_need = align_up(std::max(gsr_sort_mid_workspace_bytes(num_points), scan_temp(num_points)));
+  const size_t rocprim_need = kb + align_up(std::max(depth_sort_temp(num_points), st));
+  const size_t mid_need = align_up(std::max(gsr_sort_mid_workspace_bytes(num_points), st));
   return kb + (use_mid_sort(num_points) ? mid_need : rocprim_need);
 }
 
 GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
-                               const int32_t *num_tiles_hit, int32_t *order, int32_t *cum_sorted,
+                               const int32_t *num_tiles_hit, int num_bands, int32_t *order, int32_t *cum_sorted,
                                void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0, "depth_order: num_points < 0");
+  GSR_REQUIRE(num_bands >= 1 && num_bands <= kMaxBands, "depth_order: num_bands must be in [1,16]");
+  GSR_REQUIRE((long long)num_points * num_bands < (1ll << 31), "depth_order: num_points * num_bands too large");
   if (num_points == 0) return GSR_OK;
   GSR_REQUIRE(depths && radii && num_tiles_hit && order && cum_sorted && workspace, "depth_order: null pointer");
-  const size_t need = gsr_depth_order_workspace_bytes(num_points);
+  const size_t need = gsr_depth_order_workspace_bytes(num_points, num_bands);
   if (workspace_bytes < need) {
     gsr_set_error("depth_order: workspace %zu < %zu bytes", workspace_bytes, need);
     return GSR_ENOMEM;
@@ -332,8 +373,9 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
         order, (size_t)num_points, 0u, 31u, s));
   }
   // the sort is finished with its workspace (stream order): reuse it for the scan
-  auto in = rocprim::make_transform_iterator((const int *)order, TilesInOrder{num_tiles_hit});
-  GSR_CHECK_HIP(rocprim::inclusive_scan(rest, rest_bytes, in, cum_sorted, (size_t)num_points,
+  auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0),
+                                             TilesInOrder{num_tiles_hit, order, num_points});
+  GSR_CHECK_HIP(rocprim::inclusive_scan(rest, rest_bytes, in, cum_sorted, (size_t)num_points * num_bands,
                                         rocprim::plus<int>(), s));
   return GSR_OK;
 }
@@ -359,10 +401,14 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
   GSR_REQUIRE(xys && radii && conics && opacities && counts && reach_records, "count_reach: null pointer");
   GSR_REQUIRE(tiles_x > 0 && tiles_y > 0 && tiles_x <= 65535 && tiles_y <= 65535, "count_reach: bad tile grid");
   GSR_REQUIRE((reinterpret_cast<uintptr_t>(reach_records) & 15) == 0, "count_reach: reach_records must be 16-byte aligned");
-  hipLaunchKernelGGL(tile_rows_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream, 0,
+  int rpb = tiles_y;
+  int bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
+  if (bands < 1) bands = 1, rpb = tiles_y;  // grids the scatter does not serve: one count per Gaussian
+  auto kernel = bands > 1 ? tile_rows_kernel<true> : tile_rows_kernel<false>;
+  hipLaunchKernelGGL(kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream, 0,
                      num_points, (const int *)nullptr, (const int *)nullptr, xys, radii, conics, opacities,
                      tiles_x, tiles_y, 16, static_cast<SplatRec *>(reach_records), (unsigned *)nullptr,
-                     (int *)nullptr, counts, 0);
+                     (int *)nullptr, counts, 0, bands, rpb);
   GSR_CHECK_LAUNCH("count_reach");
   return GSR_OK;
 }
@@ -371,28 +417,29 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
 //   's' (default when the tile grid fits): single-pass counting sort, tile_scatter.hip
 //   'r': rocPRIM radix sort on the tile bits + edge detection
 //   'm': sort_mid.hip + edge detection
-// GSR_TILE_SORT=r|m|s overrides (A/B measurements).
-char tile_sort_mode(int num_tiles) {
+// GSR_TILE_SORT=r|m|s overrides (A/B measurements).  Grids of more than one
+// band need the per-band counts of gsr_count_reach, i.e. reach records.
+char tile_sort_mode(int tiles_x, int tiles_y, bool have_records) {
   static const char forced = [] {
     const char *e = getenv("GSR_TILE_SORT");
     return e ? e[0] : '\0';
   }();
   if (forced == 'r' || forced == 'm') return forced;
-  return gsr_tile_scatter_supported(num_tiles) ? 's' : 'r';
+  const int bands = gsr_tile_band_rows(tiles_x, tiles_y, nullptr);
+  return (bands == 1 || (bands > 1 && have_records)) ? 's' : 'r';
 }
 
-// upper bound over the tile grids the scatter path supports
-size_t tile_scatter_temp(int I) { return gsr_tile_scatter_workspace_bytes(I, 16384); }
-
-GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects) {
+GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects, int tiles_x, int tiles_y) {
   if (num_intersects <= 0) return 0;
+  int rpb = 0;
+  const int bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
+  const size_t scatter = bands > 0 ? gsr_tile_scatter_workspace_bytes(num_intersects, rpb * tiles_x, bands) : 0;
   return 3 * align_up(4 * (size_t)num_intersects) +
-         align_up(std::max({tile_sort_temp(num_intersects), gsr_sort_mid_workspace_bytes(num_intersects),
-                            tile_scatter_temp(num_intersects)}));
+         align_up(std::max({tile_sort_temp(num_intersects), gsr_sort_mid_workspace_bytes(num_intersects), scatter}));
 }
 
 namespace {
-// device_sized: the stream length is cum_sorted[num_points - 1] on the device and
+// device_sized: the stream length is cum_sorted[bands * num_points - 1] on the device and
 // `num_intersects` is the capacity the caller sized its buffers for
 int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const int32_t *order,
                     const int32_t *cum_sorted, const float *xys, const int32_t *radii,
@@ -407,8 +454,14 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   GSR_REQUIRE(tiles_x <= 65535 && tiles_y <= 65535, "bin_sorted: tile grid too large");
   hipStream_t s = (hipStream_t)stream;
   const int num_tiles = tiles_x * tiles_y;
-  const char mode = tile_sort_mode(num_tiles);
-  GSR_REQUIRE(!device_sized || mode == 's', "bin_sorted_dev: needs the single-pass tile scatter (<= 16384 tiles)");
+  const char mode = tile_sort_mode(tiles_x, tiles_y, reach_records != nullptr);
+  GSR_REQUIRE(!device_sized || mode == 's',
+              "bin_sorted_dev: needs the single-pass tile scatter (<= 16384 tiles, or reach records)");
+  int rpb = tiles_y, bands = 1;
+  if (reach_records) {
+    bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
+    if (bands < 1) bands = 1, rpb = tiles_y;
+  }
   const bool nothing = num_points == 0 || num_intersects == 0;
   if (nothing || mode != 's') {  // the scatter path writes every entry of tile_bins itself
     hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
@@ -417,7 +470,7 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   }
   if (num_points == 0 || num_intersects == 0) return GSR_OK;
   GSR_REQUIRE(order && cum_sorted && xys && radii && gaussian_ids_sorted && workspace, "bin_sorted: null pointer");
-  const size_t need = gsr_bin_sorted_workspace_bytes(num_intersects);
+  const size_t need = gsr_bin_sorted_workspace_bytes(num_intersects, tiles_x, tiles_y);
   if (workspace_bytes < need) {
     gsr_set_error("bin_sorted: workspace %zu < %zu bytes", workspace_bytes, need);
     return GSR_ENOMEM;
@@ -429,15 +482,17 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   int *ids_in = reinterpret_cast<int *>(ws + 2 * ib);
   void *temp = ws + 3 * ib;
   size_t temp_bytes = workspace_bytes - 3 * ib;
-  hipLaunchKernelGGL(tile_rows_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, 1, num_points,
+  auto kernel = bands > 1 ? tile_rows_kernel<true> : tile_rows_kernel<false>;
+  hipLaunchKernelGGL(kernel, dim3(gsr_cdiv(num_points, 256), bands), dim3(256), 0, s, 1, num_points,
                      order, cum_sorted, xys, radii, (const float *)nullptr, (const float *)nullptr, tiles_x,
                      tiles_y, (int)block_width,
                      const_cast<SplatRec *>(static_cast<const SplatRec *>(reach_records)), tile_in, ids_in,
-                     (int *)nullptr, num_intersects);
+                     (int *)nullptr, num_intersects, bands, rpb);
   GSR_CHECK_LAUNCH("bin_sorted(emit)");
   if (mode == 's')
-    return gsr_tile_scatter(num_intersects, device_sized ? cum_sorted + (num_points - 1) : nullptr, tile_in,
-                            ids_in, num_tiles, gaussian_ids_sorted, tile_bins, count_out, temp, temp_bytes, s);
+    return gsr_tile_scatter(num_intersects, cum_sorted, num_points, tile_in, ids_in, tiles_x, tiles_y,
+                            gaussian_ids_sorted, tile_bins, count_out, temp, temp_bytes, s);
+  // (bands == 1 here: the stream is in depth order over the whole grid)
   if (mode == 'm') {
     int rc = gsr_sort_mid_pairs(num_intersects, tile_in, ids_in, tile_out, gaussian_ids_sorted,
                                 (int)tile_bits(num_tiles), temp, temp_bytes, s);
@@ -474,4 +529,3 @@ GSR_EXPORT int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *o
                          tiles_y, block_width, gaussian_ids_sorted, tile_bins, count_out, workspace, workspace_bytes,
                          stream);
 }
-

@@ -56,7 +56,10 @@ class _RasterizeRGBD(Function):
         if num_intersects < 1:
             img = torch.ones(img_height, img_width, 3, device=dev) * background
             ext = torch.full((img_height, img_width), float(extra_background), device=dev)
-            Ts = torch.ones(img_height, img_width, device=dev)
+            # final_Ts = 0, i.e. alpha = 1, for a view with nothing on screen: the quirk of
+            # `rasterize_gaussians(return_alpha=True)` (rasterize.py:119-127), kept so that the
+            # fused and the two-pass route agree (tests/test_gpu_api.py::test_empty_view_*)
+            Ts = torch.zeros(img_height, img_width, device=dev)
             idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
             ids = torch.zeros(0, dtype=torch.int32, device=dev)
             bins = torch.zeros(0, 2, dtype=torch.int32, device=dev)

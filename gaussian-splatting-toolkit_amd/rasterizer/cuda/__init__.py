@@ -236,21 +236,31 @@ def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: Tensor,
 
 def depth_order(depths: Tensor, radii: Tensor, num_tiles_hit: Tensor) -> Tuple[Tensor, Tensor]:
     """First half of the fused binning pipeline (``gsr_depth_order``):
-    -> (order i32[N], cum_sorted i32[N]); ``cum_sorted[-1]`` is the number of
-    intersections."""
+    -> (order i32[N], cum_sorted i32[B*N]); ``cum_sorted[-1]`` is the number of
+    intersections.  ``num_tiles_hit`` is [N], or the band-major [B*N] counts of
+    :func:`count_reach` on a tile grid of B = :func:`tile_bands` bands."""
     _check(depths, "depths", _f32)
     _check(radii, "radii", _i32)
     _check(num_tiles_hit, "num_tiles_hit", _i32)
     n = depths.numel()
+    bands = num_tiles_hit.numel() // n if n else 1
+    if n and (num_tiles_hit.numel() != bands * n or bands < 1):
+        raise RuntimeError("depth_order: num_tiles_hit must hold N (or bands * N) counts")
     dev = depths.device
     with torch.cuda.device(dev):
         order = torch.empty((n,), dtype=_i32, device=dev)
-        cum = torch.empty((n,), dtype=_i32, device=dev)
-        nbytes = int(_lib().gsr_depth_order_workspace_bytes(C.c_int(n)))
+        cum = torch.empty((bands * n,), dtype=_i32, device=dev)
+        nbytes = int(_lib().gsr_depth_order_workspace_bytes(C.c_int(n), C.c_int(bands)))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
-        _call("gsr_depth_order", C.c_int(n), _ptr(depths), _ptr(radii), _ptr(num_tiles_hit), _ptr(order),
-              _ptr(cum), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+        _call("gsr_depth_order", C.c_int(n), _ptr(depths), _ptr(radii), _ptr(num_tiles_hit), C.c_int(bands),
+              _ptr(order), _ptr(cum), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
     return order, cum
+
+
+def tile_bands(tile_bounds: Tuple[int, int, int]) -> int:
+    """``gsr_tile_bands``: 1 up to 16384 tiles; above, the number of tile-row bands the
+    fused binning works in (4K at 16 px: 4)."""
+    return int(_lib().gsr_tile_bands(C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
 
 
 def publish_int32(src: Tensor, dst: Tensor) -> None:
@@ -267,8 +277,9 @@ def publish_int32(src: Tensor, dst: Tensor) -> None:
 def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
                 tile_bounds: Tuple[int, int, int]) -> Tuple[Tensor, Tensor]:
     """``gsr_count_reach``: per Gaussian, the number of 16x16 tiles of its bounding
-    box in which it can reach alpha >= 1/255 -> (counts i32[N] <= num_tiles_hit,
-    opaque per-Gaussian records for :func:`bin_sorted`)."""
+    box in which it can reach alpha >= 1/255 -> (counts i32[B*N], band-major, summing to
+    <= num_tiles_hit per Gaussian, B = :func:`tile_bands`; opaque per-Gaussian records for
+    :func:`bin_sorted`)."""
     _check(xys, "xys", _f32)
     _check(radii, "radii", _i32)
     _check(conics, "conics", _f32)
@@ -278,14 +289,14 @@ def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
         raise RuntimeError("count_reach: xys [N,2], conics [N,3], opacities [N,1] expected")
     dev = xys.device
     with torch.cuda.device(dev):
-        counts = torch.empty((n,), dtype=_i32, device=dev)
+        counts = torch.empty((tile_bands(tile_bounds) * n,), dtype=_i32, device=dev)
         recs = torch.empty((n, int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
         _call("gsr_count_reach", C.c_int(n), _ptr(xys), _ptr(radii), _ptr(conics), _ptr(opacities),
               C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(counts), _ptr(recs), _stream(dev))
     return counts, recs
 
 
-MAX_SCATTER_TILES = 16384  # tile grids the device-sized path supports (tile_scatter.hip)
+MAX_SCATTER_TILES = 16384  # tile grids the device-sized path supports without reach records (tile_scatter.hip)
 
 
 def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Tensor, xys: Tensor,
@@ -315,7 +326,8 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     with torch.cuda.device(dev):
         ids = torch.empty((I,), dtype=_i32, device=dev)
         tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
-        nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I)))
+        nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I), C.c_int(tile_bounds[0]),
+                                                           C.c_int(tile_bounds[1])))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         head = (C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted), _ptr(xys), _ptr(radii),
                 _ptr(reach_records) if reach_records is not None else None, C.c_int(tile_bounds[0]),

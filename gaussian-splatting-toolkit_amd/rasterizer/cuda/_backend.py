@@ -29,6 +29,7 @@ SYMBOLS = (
     "gsr_sort_intersects",
     "gsr_tile_bin_edges",
     "gsr_reach_record_bytes",
+    "gsr_tile_bands",
     "gsr_count_reach",
     "gsr_depth_order_workspace_bytes",
     "gsr_depth_order",

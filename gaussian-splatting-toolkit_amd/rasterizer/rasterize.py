@@ -16,6 +16,7 @@ for another tensor while the entry exists (an address match therefore means
 the same memory), and an in-place update bumps the version and misses.
 """
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -43,6 +44,7 @@ def _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, bloc
 _count_hint = {}
 _last_capacity = {}
 _pinned_count = {}
+_state_lock = threading.Lock()  # guards the three dictionaries above and the list cache
 
 
 def _speculation_enabled() -> bool:
@@ -54,9 +56,12 @@ def _note_count(device, num_points, tile_bounds, num_intersects):
     _count_hint[(device, tile_bounds)] = (num_points, num_intersects)
 
 
-def _speculative_capacity(device, num_points, tile_bounds):
+def _speculative_capacity(device, num_points, tile_bounds, exact):
     hint = _count_hint.get((device, tile_bounds))
-    if hint is None or tile_bounds[0] * tile_bounds[1] > _C.MAX_SCATTER_TILES or not _speculation_enabled():
+    # the device-sized lists need the single-pass tile scatter: any grid with the exact
+    # lists' per-band counts (block_width 16), up to 16384 tiles otherwise
+    if hint is None or not _speculation_enabled() or \
+            (not exact and tile_bounds[0] * tile_bounds[1] > _C.MAX_SCATTER_TILES):
         return None
     n_last, count_last = hint
     if n_last < 1 or count_last < 1:
@@ -81,11 +86,18 @@ class _PendingCount:
     -- no copy operation in the stream -- and `resolve` waits for the event recorded
     behind that call."""
 
+    SLOTS = 16  # pinned slots per device, handed out round-robin: a count in flight keeps
+    # its own slot, so forwards interleaved on one device (side streams, an eval thread)
+    # cannot overwrite each other's published count
+
     def __init__(self, device):
-        buf = _pinned_count.get(device)
-        if buf is None:
-            buf = _pinned_count[device] = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        self.buf = buf
+        with _state_lock:
+            ring = _pinned_count.get(device)
+            if ring is None:
+                ring = _pinned_count[device] = [torch.empty(self.SLOTS, dtype=torch.int32, pin_memory=True), 0]
+            slot = ring[1]
+            ring[1] = (slot + 1) % self.SLOTS
+        self.buf = ring[0][slot:slot + 1]
         self.device = device
         self.event = None
 
@@ -206,7 +218,7 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
         return _C.bin_sorted(num_points, count, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
                              device_sized=device_sized)
 
-    capacity = _speculative_capacity(xys.device, num_points, tile_bounds)
+    capacity = _speculative_capacity(xys.device, num_points, tile_bounds, exact)
     if capacity is None:
         num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
         _note_count(xys.device, num_points, tile_bounds, num_intersects)

@@ -144,18 +144,27 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  * gsr_bin_sorted builds the lists without the dead pairs: images and gradients
  * are unchanged, `gaussian_ids_sorted` is a subsequence of the reference's.
  * With reach_records == NULL gsr_bin_sorted reproduces the reference's lists
- * bit for bit. */
+ * bit for bit.
+ *
+ * Tile-row bands.  Tile grids above 16384 tiles (4K at 16 px: 240 x 135) are
+ * binned in gsr_tile_bands(tiles_x, tiles_y) bands of whole tile rows (1 for
+ * smaller grids): gsr_count_reach then writes counts[bands, n] (band-major),
+ * gsr_depth_order scans them in (band, depth) order into cum_sorted[bands * n]
+ * (cum_sorted[bands * n - 1] = number of list entries), and gsr_bin_sorted(_dev)
+ * -- which needs the reach records for such grids -- partitions band by band. */
 size_t gsr_reach_record_bytes(void);
+int gsr_tile_bands(int tiles_x, int tiles_y);
 int gsr_count_reach(int num_points, const float *xys, const int32_t *radii,
                     const float *conics, const float *opacities, int tiles_x,
                     int tiles_y, int32_t *counts, void *reach_records,
                     gsr_stream_t stream);
-size_t gsr_depth_order_workspace_bytes(int num_points);
+size_t gsr_depth_order_workspace_bytes(int num_points, int num_bands);
 int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
-                    const int32_t *num_tiles_hit, int32_t *order,
-                    int32_t *cum_sorted, void *workspace,
+                    const int32_t *num_tiles_hit, int num_bands,
+                    int32_t *order, int32_t *cum_sorted, void *workspace,
                     size_t workspace_bytes, gsr_stream_t stream);
-size_t gsr_bin_sorted_workspace_bytes(int num_intersects);
+size_t gsr_bin_sorted_workspace_bytes(int num_intersects, int tiles_x,
+                                      int tiles_y);
 int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                    const int32_t *cum_sorted, const float *xys,
                    const int32_t *radii, const void *reach_records, int tiles_x,
@@ -170,17 +179,17 @@ int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
 int gsr_publish_int32(const int32_t *src, int32_t *dst, gsr_stream_t stream);
 
 /* gsr_bin_sorted without the host knowing the number of intersections: the
- * length of the lists is read on the device (cum_sorted[num_points-1], as
+ * length of the lists is read on the device (the last element of cum_sorted, as
  * written by gsr_depth_order) and `capacity` is what gaussian_ids_sorted and the
- * workspace (gsr_bin_sorted_workspace_bytes(capacity)) were sized for.  If the
+ * workspace (gsr_bin_sorted_workspace_bytes(capacity, ...)) were sized for.  If the
  * length exceeds the capacity the lists are cut there (memory-safe, results
  * incomplete): the caller compares the two once the value has reached the host
  * and repeats the call with a larger capacity.  This removes the host round
  * trip of rasterizer/utils.py:124 (`cum_tiles_hit[-1].item()`) from the critical
  * path.  count_out (nullable) receives the uncut length; it only has to be
  * device-accessible, e.g. pinned host memory mapped into the device's address
- * space, which spares the copy as well.  Tile grids above 16384 tiles:
- * GSR_EINVAL, use gsr_bin_sorted. */
+ * space, which spares the copy as well.  Tile grids above 16384 tiles need the
+ * reach records (bands, above); without them: GSR_EINVAL, use gsr_bin_sorted. */
 int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
                        const int32_t *cum_sorted, const float *xys,
                        const int32_t *radii, const void *reach_records,

@@ -215,8 +215,16 @@ def test_empty_scene_and_all_culled():
     img, alpha = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac, 48, 64, 16,
                                      background=bg, return_alpha=True)
     assert img.shape == (48, 64, 3) and torch.allclose(img, bg.expand(48, 64, 3))
+    # the reference returns final_Ts = zeros here, i.e. alpha = 1 (rasterize.py:119-127): kept
+    assert torch.equal(alpha, torch.ones(48, 64, device=DEV))
     (img.sum() + alpha.sum()).backward()
     assert colors.grad.abs().sum().item() == 0 and means.grad.abs().sum().item() == 0
+    # the fused RGB + depth route agrees with the two-pass route on an empty view too
+    from gs_fused import rasterize_gaussians_rgbd
+
+    img2, alpha2, dep2 = rasterize_gaussians_rgbd(xys, depths, radii, conics, tiles, colors, depths, opac, 48, 64,
+                                                  background=bg)
+    assert torch.equal(img2, img) and torch.equal(alpha2, alpha) and dep2.abs().sum().item() == 0
 
 
 def test_single_gaussian_single_intersection():

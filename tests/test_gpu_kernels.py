@@ -402,16 +402,18 @@ def test_depth_order_sort_is_exact_and_stable(n, dist):
 
 
 @pytest.mark.parametrize("n,W,H,ck,opac_hi", [(3000, 160, 96, {}, 1.0), (20_000, 317, 203, {"yaw": 0.3}, 1.0),
-                                             (5000, 256, 256, {}, 0.02), (200_000, 640, 360, {}, 1.0)])
+                                             (5000, 256, 256, {}, 0.02), (200_000, 640, 360, {}, 1.0),
+                                             (30_000, 3840, 2160, {}, 1.0), (20_000, 2560, 1440, {"yaw": 0.2}, 1.0)])
 def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
     """count_reach + bin_sorted(conics, opacities): per tile, the list is a
     subsequence of the reference's; every dropped (Gaussian, tile) pair has
     alpha < 1/255 at every pixel of the tile; the image composited from the short
-    lists is bit-identical, gradients equal up to atomic summation order."""
+    lists is bit-identical, gradients equal up to atomic summation order.  The 4K and
+    1440p cases run in 4 and 2 tile-row bands (grids above 16384 tiles)."""
     import rasterizer.cuda as C
 
     bw = 16
-    cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2)
+    cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2 if W < 2000 else 0.08)
     rng = np.random.default_rng(n)
     cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
     opac = (sc["opacities"] * opac_hi).astype(np.float32)
@@ -426,17 +428,22 @@ def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
     I = int(cum[-1].item())
     ids_ref, bins_ref = C.bin_sorted(n, I, order, cum, g["xys"], g["radii"], tb, bw)
     # exact lists
-    cnt, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
-    assert (cnt <= g["tiles"]).all() and (cnt >= 0).all()
+    cnt_bands, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
+    bands = C.tile_bands(tb)
+    assert bands == (1 if tb[0] * tb[1] <= 16384 else -(-tb[1] // (8192 // tb[0])))
+    assert cnt_bands.shape == (bands * n,) and (cnt_bands >= 0).all()
+    cnt = cnt_bands.view(bands, n).sum(0).to(torch.int32)
+    assert (cnt <= g["tiles"]).all()
     assert (cnt[g["radii"] <= 0] == 0).all()
-    order2, cum2 = C.depth_order(g["depths"], g["radii"], cnt)
+    order2, cum2 = C.depth_order(g["depths"], g["radii"], cnt_bands)
+    assert cum2.shape == (bands * n,)
     assert torch.equal(order, order2)
     I2 = int(cum2[-1].item())
     assert 0 < I2 < I
     ids_ex, bins_ex = C.bin_sorted(n, I2, order2, cum2, g["xys"], g["radii"], tb, bw, recs)
     # device-sized variant: capacity instead of the exact length, count handed back through
     # device-accessible (pinned host) memory; a capacity that is too small cuts the lists
-    if tb[0] * tb[1] <= C.MAX_SCATTER_TILES:
+    if True:
         count = torch.zeros(1, dtype=torch.int32).pin_memory()
         ids_cap, bins_cap = C.bin_sorted(n, I2 + 1000, order2, cum2, g["xys"], g["radii"], tb, bw, recs,
                                          device_sized=True, count_out=count)
