@@ -49,7 +49,7 @@ constexpr int kMaxTiles = 16384;      // tiles per band: 64 KB of LDS counters
 constexpr int kBandTiles = 8192;      // band size chosen for grids above kMaxTiles
 constexpr int kMaxBands = 16;
 constexpr int kMinChunk = GSR_TS_CHUNK;   // stream elements per chunk (per wave in S3)
-constexpr int kMaxChunks = 1024;
+constexpr int kMaxChunks = 3072;
 constexpr int kMaxGroups = 32;
 
 struct Plan {

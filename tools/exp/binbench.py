@@ -18,7 +18,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     lo, hi = float(os.environ.get("SCALE_LO", 0.0025)), float(os.environ.get("SCALE_HI", 0.025))
-    W, H = 1920, 1080
+    W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     if os.environ.get("BLOB"):  # the trainer harness' scene: a ball of Gaussians seen from an orbit camera
         from harness import train as T
