@@ -126,6 +126,67 @@ def cpu_baseline(sc, cam, bg, v_img, v_alpha, deg):
     }, r["num_intersects"]
 
 
+def _spawned(rank, world, port, argv):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.argv = argv
+    main()
+
+
+def cpu_baseline_one_thread(sc, cam, bg, v_img, v_alpha, deg, budget_gaussians=60_000):
+    """The same port on ONE host thread (SURVEY 8d asks for OMP_NUM_THREADS = all and = 1),
+    on a bounded sample: the first `budget_gaussians` Gaussians of the same scene, same camera
+    and image size (about 10-30 s of CPU work; the full workload takes minutes on one thread)."""
+    from oracle import oracle as O
+
+    n = min(budget_gaussians, sc["means3d"].shape[0])
+    sub = {k: np.ascontiguousarray(v[:n]) for k, v in sc.items()}
+    before = O.num_threads()
+    O.set_threads(1)
+    try:
+        res, I = cpu_baseline(sub, cam, bg, v_img, v_alpha, deg)
+    finally:
+        O.set_threads(before)
+    res["cores"] = 1
+    res["sample"] = (f"first {n} Gaussians of the workload ({I} reference list entries) at {cam.width}x{cam.height}, one "
+                     f"thread; " + res["sample"].split("; ", 1)[1])
+    return res
+
+
+def pmc_pass(counters, argv, kernel_substr, timeout_s=240):
+    """One separate `rocprofv3 --kernel-trace --pmc <counters>` pass over a short run of this
+    script (MI355X_MICROARCH.md, HBM section: counters in their own pass, kernel trace only).
+    -> {counter: mean per launch of the kernels whose name contains `kernel_substr`} or None."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="gsr_pmc_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", out, "--",
+           sys.executable, os.path.abspath(__file__), *argv]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=timeout_s, check=True)
+        vals = {}
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row["Kernel_Name"]:
+                    vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        return {k: float(np.mean(v)) for k, v in vals.items()} or None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +204,9 @@ def main():
     ap.add_argument("--scale-lo", type=float, default=0.0025)
     ap.add_argument("--scale-hi", type=float, default=0.025)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the rocprofv3 counter passes (HBM traffic, VALU busy) that rank 0 runs after the timed "
+                         "region at N=1")
     ap.add_argument("--event-every", type=int, default=10,
                     help="bracket the native calls with HIP events on every k-th timed step (0: never, 1: all)")
     # co-gs / eval pattern (BASELINE config 5): a second rasterisation of the depths with
@@ -152,28 +216,49 @@ def main():
                     help="with --render-depth: RGB and depth from ONE compositing pass (gs_fused, SURVEY 8f row f4)")
     # "nccl" is RCCL on ROCm.  "gloo" exists so the N>1 code path can be exercised on a
     # single-GPU box (ranks then share cuda:0); it is not a measurement configuration.
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="auto: nccl (= RCCL) when every rank has its own GPU, gloo otherwise")
+    ap.add_argument("--sh-degree-to-use", type=int, default=None,
+                    help="evaluate only the first bands (the models' SH warm-up, vanilla_gs.py:811-820); the "
+                         "gradient exchange then leaves the inactive bands out")
+    ap.add_argument("--scene", default="uniform", choices=["uniform", "longtail"],
+                    help="longtail: 10 %% of the tiles hold ~10x the list depth (clustered Gaussians)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): spawn one rank per GPU ourselves, as the
+        # reference's launcher does (gs_toolkit/scripts/train.py:169, torch.multiprocessing.spawn)
+        import socket
+
+        import torch.multiprocessing as mp
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        mp.spawn(_spawned, args=(args.gpus, port, list(sys.argv)), nprocs=args.gpus, join=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = args.backend
+    if backend == "auto":
+        backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    args.backend = backend
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend="gloo")
 
-    from harness.parallel import allreduce_gradients
+    from harness.parallel import GradientExchange
     from harness.pipeline import CameraTensors, render_view
 
     timers = KernelTimers()
@@ -181,7 +266,8 @@ def main():
     # ---- workload: SURVEY.md 8(d), seed 42; one scene, one camera per rank
     W, H, N, deg = args.width, args.height, args.gaussians, args.sh_degree
     cam0 = S.make_camera(W, H)
-    sc = S.make_scene(N, cam0, sh_degree=deg, seed=42, scale_lo=args.scale_lo, scale_hi=args.scale_hi)
+    sc = S.make_scene(N, cam0, sh_degree=deg, seed=42, scale_lo=args.scale_lo, scale_hi=args.scale_hi,
+                      longtail=args.scene == "longtail")
     # rank r looks at the same cloud from a slightly different direction
     cam = cam0 if rank == 0 else S.make_camera(W, H, yaw=0.02 * rank, pitch=0.01 * (rank % 3))
     bg_np = np.array(S.BACKGROUND, np.float32)
@@ -194,12 +280,18 @@ def main():
     bg, v_img, v_alpha = t(bg_np), t(v_img_np), t(v_alpha_np)
 
     comm_events = []
+    deg_use = deg if args.sh_degree_to_use is None else min(args.sh_degree_to_use, deg)
+    # the exchange starts per parameter from autograd hooks, as soon as a gradient exists (the SH
+    # block while project_backward still runs), and leaves inactive SH bands out
+    exchange = GradientExchange({k: params[k] for k in ("means3d", "scales", "quats", "opacities", "sh_coeffs")},
+                                average=True).attach()
+    exchange.active_rows["sh_coeffs"] = (deg_use + 1) ** 2
 
     def step():
         for p in plist:
             p.grad = None
         out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
-                          params["sh_coeffs"], camt, bg, deg, clamp_rgb=False, render_depth=args.render_depth,
+                          params["sh_coeffs"], camt, bg, deg_use, clamp_rgb=False, render_depth=args.render_depth,
                           fused_depth=args.fused_depth)
         if args.render_depth:
             torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]],
@@ -207,14 +299,14 @@ def main():
         else:
             torch.autograd.backward([out["rgb"], out["alpha"]], [v_img, v_alpha[..., None]])
         if world > 1:
-            if timers.enabled:
+            if timers.enabled:  # what is left of the exchange once the backward has been queued
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                allreduce_gradients(plist, average=True)
+                exchange.finish()
                 e1.record()
                 comm_events.append((e0, e1))
             else:
-                allreduce_gradients(plist, average=True)
+                exchange.finish()
         return out
 
     def barrier():
@@ -228,17 +320,40 @@ def main():
     from rasterizer import rasterize as _R
     list_entries = int(_R._bin_cache["value"][0])  # what the kernels walk (dead pairs left out)
     n_visible = int((out["radii"] > 0).sum().item())
+    _bins = _R._bin_cache["value"][2]
+    _lens = (_bins[:, 1] - _bins[:, 0]).float().cpu().numpy()
+    tile_hist = {"p50": int(np.percentile(_lens, 50)), "p90": int(np.percentile(_lens, 90)),
+                 "p99": int(np.percentile(_lens, 99)), "max": int(_lens.max()), "mean": round(float(_lens.mean()), 1)}
+
+    # list entries the compositing kernels really stage (tiles stop once saturated): one
+    # untimed step with the library's measurement hook on
+    import ctypes
+
+    from rasterizer.cuda._backend import lib as _native
+
+    staged = torch.zeros(2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    _native().gsr_debug_count_staged(ctypes.c_void_p(staged.data_ptr()))
+    step()
+    torch.cuda.synchronize()
+    _native().gsr_debug_count_staged(None)
+    raster_launches = 2 if (args.render_depth and not args.fused_depth) else 1
+    staged_fwd, staged_bwd = (int(v) // raster_launches for v in staged.tolist())
 
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         # per-kernel HIP events on every `event_every`-th timed step: a pair of event
         # records per native call costs ~4 us of GPU idle time (18 pairs: 5 % of a step)
         timers.enabled = args.event_every > 0 and i % args.event_every == 0
         step()
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     timers.enabled = False
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)])
 
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -257,36 +372,44 @@ def main():
         # the end-to-end figure prices the job as SURVEY 8(d) defines it (the reference's lists)
         alg = S.algorithmic_bytes(N, list_entries, pixels, tiles, K)
         alg_job = S.algorithmic_bytes(N, num_intersects, pixels, tiles, K)
+        # the compositing kernels are priced on the list entries they really stage (a tile stops
+        # once all its pixels are saturated), not on the whole lists: 40 B (fwd) / 76 B (bwd) per
+        # entry + the per-pixel images (40 I + 20 P, 76 I + 24 P)
+        alg["raster_fwd"] = 40 * staged_fwd + 20 * pixels
+        alg["raster_bwd"] = 76 * staged_bwd + 24 * pixels
         dominant = max(kern_ms, key=lambda k: kern_ms[k])
         ach = alg[dominant] / (kern_ms[dominant] * 1e-3) / 1e9 if kern_ms[dominant] > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                td = json.load(open(tf))
-                wl = td.get("_workload", {})
-                # PMC passes were collected on the default workload only
-                if (wl.get("gaussians"), wl.get("width"), wl.get("height"), wl.get("sh_degree"),
-                        wl.get("scale_lo"), wl.get("scale_hi")) == (N, W, H, deg, args.scale_lo, args.scale_hi):
-                    traffic = td.get(dominant)
-            except Exception:
-                traffic = None
         roofline = {
             "kernel": dominant, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
             "algorithmic_bytes": alg[dominant], "kernel_ms": round(kern_ms[dominant], 4),
+            "staged_list_entries": {"raster_fwd": staged_fwd, "raster_bwd": staged_bwd, "lists": list_entries},
         }
-        # the compositing kernels are VALU-issue bound, not HBM bound:
-        # report how busy the SIMDs were, from the committed SQ counter pass of this workload
-        try:
-            sq = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")))["counters"]
-            kn = {"raster_bwd": "raster_bwd_tile16_kernel", "raster_fwd": "raster_fwd_tile16_kernel"}.get(dominant)
-            if traffic is not None and kn in sq:
-                simd_cycles = sq[kn]["GRBM_GUI_ACTIVE"]["mean"] / 8.0 * 1024.0
-                roofline["valu_busy"] = round(sq[kn]["SQ_INSTS_VALU"]["mean"] * 4.0 / simd_cycles, 3)
-                roofline["limiter"] = "VALU issue (SQ_INSTS_VALU x 4 cycles / SIMD-cycles resident, profiles/r01_pmc_sq.json)"
-        except Exception:
-            pass
+        # HBM traffic and VALU occupancy of the dominant kernel, measured now: separate rocprofv3
+        # counter passes over a short run of this same command (skipped with --no-pmc / N > 1)
+        kn = {"raster_bwd": "raster_bwd_tile16_kernel", "raster_fwd": "raster_fwd_tile16_kernel",
+              "sh_fwd": "sh16_fwd_kernel", "sh_bwd": "sh16_bwd_kernel", "project_fwd": "project_fwd_kernel",
+              "project_bwd": "project_bwd_kernel"}.get(dominant)
+        if world == 1 and not args.no_pmc and kn is not None:
+            sub = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
+            for flag in ("--steps", "--warmup", "--event-every", "--gpus"):
+                while flag in sub:
+                    i = sub.index(flag)
+                    del sub[i:i + 2]
+            sub += ["--steps", "3", "--warmup", "2", "--event-every", "0", "--no-cpu-baseline", "--no-pmc"]
+            f = pmc_pass(["FETCH_SIZE"], sub, kn)
+            w = pmc_pass(["WRITE_SIZE"], sub, kn)
+            if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
+                # KB units; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section)
+                roofline["traffic"] = int((2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024)
+                roofline["traffic_raw"] = {"FETCH_SIZE_KB": round(f["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(w["WRITE_SIZE"], 1)}
+            q = pmc_pass(["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], sub, kn)
+            if q and "SQ_INSTS_VALU" in q and q.get("GRBM_GUI_ACTIVE", 0) > 0:
+                # the compositing kernels are VALU-issue bound, not HBM bound:
+                # wave64 VALU instructions x 4 cycles / SIMD-cycles the kernel was resident
+                simd_cycles = q["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+                roofline["valu_busy"] = round(q["SQ_INSTS_VALU"] * 4.0 / simd_cycles, 3)
+                roofline["limiter"] = "VALU issue (SQ_INSTS_VALU x 4 cycles / SIMD-cycles resident, this run)"
         # every kernel's own fraction, and the end-to-end figure from SURVEY 8(d)
         per_kernel = {
             k: {"ms": round(kern_ms[k], 4), "GBps": round(alg[k] / (kern_ms[k] * 1e-3) / 1e9, 1) if kern_ms[k] > 0 else 0.0}
@@ -294,19 +417,26 @@ def main():
         }
         end_to_end = alg_job["total"] / (ms_per_step * 1e-3) / 1e9
 
-        cpu = None
+        cpu = cpu1 = None
         if world == 1 and not args.no_cpu_baseline:
             cpu, _ = cpu_baseline(sc, cam, bg_np, v_img_np, v_alpha_np, deg)
             cpu["value"] = round(cpu["value"], 4)
+            cpu1 = cpu_baseline_one_thread(sc, cam, bg_np, v_img_np, v_alpha_np, deg)
+            cpu1["value"] = round(cpu1["value"], 4)
+        res_name = "1080p" if (W, H) == (1920, 1080) else ("4K" if (W, H) == (3840, 2160) else f"{W}x{H}")
+        n_name = f"{N // 1_000_000}M" if N % 1_000_000 == 0 else (f"{N // 1000}k" if N % 1000 == 0 else str(N))
 
         line = {
-            "metric": "raster fwd+bwd Mpix/s @1080p (1M Gaussians, SH3)",
+            "metric": f"raster fwd+bwd Mpix/s @{res_name} ({n_name} Gaussians, SH{deg})",
             "value": round(value, 2),
             "unit": "Mpix/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median": round(float(np.median(step_ms)), 4),
+            "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, 10)), 4),
+                                    round(float(np.percentile(step_ms, 90)), 4)],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -321,20 +451,24 @@ def main():
                 "gaussians": N, "visible": n_visible, "intersections": num_intersects,
                 "list_entries": list_entries,
                 "mean_gaussians_per_tile": round(num_intersects / tiles, 1),
-                "parallelism": (f"dp{world} (per-view; gradients all-reduced in place per parameter tensor, averaged in the "
-                                f"collective, RCCL)" if args.backend == "nccl" else
-                                f"dp{world} (per-view; one flat-gradient all-reduce/step, {args.backend})")
+                "tile_list_length": tile_hist, "scene": args.scene,
+                "parallelism": (f"dp{world} (per-view; per-parameter all-reduce started from autograd hooks, overlapping "
+                                f"the backward; active SH bands only; "
+                                + ("averaged in the collective, RCCL)" if args.backend == "nccl" else
+                                   f"{args.backend}: ranks share GPUs, not a measurement configuration)"))
                                if world > 1 else "single",
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_one_thread": cpu1,
             "kernels": per_kernel,
             "kernel_events": f"HIP events around each native call on every {args.event_every}th timed step" if args.event_every > 1 else "HIP events around each native call on every timed step",
             "end_to_end_algorithmic_GBps": round(end_to_end, 1),
             # N > 1: the exchange of the 59-float/Gaussian gradient as rank 0 sees it
             "allreduce_ms": (round(float(np.mean([a.elapsed_time(b) for a, b in comm_events])), 4)
                              if comm_events else None),
-            "allreduce_bytes": sum(p.numel() for p in plist) * 4 if world > 1 else None,
+            "allreduce_ms_note": "exposed part: from the end of the queued backward to the last collective" if comm_events else None,
+            "allreduce_bytes": exchange.bytes_last if world > 1 else None,
         }
         print(json.dumps(line), flush=True)
 

@@ -36,6 +36,11 @@
 #endif
 
 namespace {
+// measurement hook, see raster_fwd.hip
+__device__ unsigned long long *g_bwd_staged = nullptr;
+}  // namespace
+
+namespace {
 
 using namespace gsr;
 
@@ -263,11 +268,12 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   const float sel_no = (comp == 2 || comp == 4) ? 0.5f : (comp == 3 ? 1.f : 0.f);
   const float sel_one = comp >= 5 ? 1.f : 0.f;
 
+  unsigned long long *const staged = g_bwd_staged;
   for (int hi = top; hi >= range.x; hi -= kChunk) {
     // back to front: lane l fetches sorted index hi - l; kept splats stay in that order
     const int sidx_l = hi - lane;
     const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics,
-                                  colors, opacities, sA, sB, sC, sId, RGBD ? extra : nullptr);
+                                  colors, opacities, sA, sB, sC, sId, RGBD ? extra : nullptr, staged);
     __syncthreads();
 
     for (int t0 = 0; t0 < count; t0 += G) {
@@ -620,5 +626,15 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
                      colors, opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic,
                      v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra);
   GSR_CHECK_LAUNCH("rasterize_backward_rgbd");
+  return GSR_OK;
+}
+
+int gsr_set_fwd_staged_counter(unsigned long long *counter);  // raster_fwd.hip
+
+GSR_EXPORT int gsr_debug_count_staged(unsigned long long *counters) {
+  int rc = gsr_set_fwd_staged_counter(counters);
+  if (rc != GSR_OK) return rc;
+  unsigned long long *b = counters ? counters + 1 : nullptr;
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_staged), &b, sizeof(b)));
   return GSR_OK;
 }

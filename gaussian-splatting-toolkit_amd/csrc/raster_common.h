@@ -87,7 +87,12 @@ __device__ __forceinline__ int stage_chunk(
     const int *__restrict__ ids_sorted, const float2 *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacities, SplatA *sA, SplatB *sB, SplatC *sC, int *sId,
-    const float *__restrict__ extra = nullptr) {
+    const float *__restrict__ extra = nullptr, unsigned long long *staged_counter = nullptr) {
+  // measurement hook (gsr_debug_count_staged): list entries read by this launch
+  if (staged_counter) {
+    const int n = __popcll(__ballot(live));
+    if (lane == 0) atomicAdd(staged_counter, (unsigned long long)n);
+  }
   int mask = 0;
   int g = 0;
   float2 xy = make_float2(0.f, 0.f);

@@ -25,6 +25,11 @@ namespace {
 
 using namespace gsr;
 
+// measurement hook: when non-null, the tile16 kernels add the number of list entries they
+// stage to *g_fwd_staged (gsr_debug_count_staged, used by bench.py to price the roofline on
+// the entries actually touched -- tiles stop early once every pixel is saturated)
+__device__ unsigned long long *g_fwd_staged = nullptr;
+
 // ------------------------------------------------------------------ tile16
 // The kernel is VALU-issue bound (rocprof: VALU busy ~86 %, LDS and memory
 // idle).  Measured dead ends, kept out on purpose: writing the pixel math on
@@ -82,11 +87,12 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   };
 
   const int2 range = tile_bins[tile];
+  unsigned long long *const staged = g_fwd_staged;
   int live = live_subtiles();
   for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
     const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics,
-                                  colors, opacities, sA, sB, sC, nullptr, RGBD ? extra : nullptr);
+                                  colors, opacities, sA, sB, sC, nullptr, RGBD ? extra : nullptr, staged);
     __syncthreads();
     for (int t = 0; t < count; ++t) {
       if ((t & 7) == 7) {
@@ -322,5 +328,11 @@ GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
                      out_img, final_Ts, final_idx, extra, extra_background, out_extra);
   GSR_CHECK_LAUNCH("rasterize_forward_rgbd");
+  return GSR_OK;
+}
+
+// internal: see gsr_debug_count_staged (raster_bwd.hip)
+int gsr_set_fwd_staged_counter(unsigned long long *counter) {
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_staged), &counter, sizeof(counter)));
   return GSR_OK;
 }

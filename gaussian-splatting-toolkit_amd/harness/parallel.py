@@ -95,6 +95,101 @@ def _allreduce_inplace(t: torch.Tensor, average: bool, ws: int, group) -> None:
         t.div_(ws)
 
 
+class GradientExchange:
+    """The per-view data-parallel exchange, overlapped with the backward and cut to what
+    is non-zero.
+
+    * A post-accumulate hook on every parameter starts its all-reduce (``async_op``) the
+      moment autograd has produced that gradient: the SH block -- 3/4 of the bytes at SH
+      degree 3, and the first to finish (its node was created after the projection's, so
+      it runs before it) -- is on the wire while ``project_backward`` still computes.  On
+      RCCL the collectives run on the process group's own stream, ordered after the
+      producing kernel by an event; ``finish()`` makes the current stream wait for them.
+    * ``active_rows[name] = k``: only ``grad[:, :k]`` of that parameter can be non-zero
+      (SH bands above the warm-up degree, vanilla_gs.py:811-820: the kernels write exact
+      zeros there on every rank), so only that slice is exchanged -- 0 rows: nothing.
+      45 of 59 floats per Gaussian are SH bands 1-3: during the first
+      ``sh_degree_interval`` iterations the exchange is 56 B instead of 236 B per Gaussian.
+    * averaging happens inside the collective on RCCL (``ReduceOp.AVG``), by one in-place
+      division elsewhere.
+
+    ``bytes_last`` holds the bytes exchanged by the last ``finish()``.
+    """
+
+    def __init__(self, named_params, average: bool = True, group=None):
+        self.named = dict(named_params)
+        self.average, self.group = average, group
+        self.active_rows = {}
+        self.pending = []
+        self.bytes_last = 0
+        self._bytes = 0
+        self._handles = []
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self._ws = dist.get_world_size(group) if self.enabled else 1
+        self._avg_in_collective = self.enabled and dist.get_backend(group) == "nccl" and average
+
+    def attach(self) -> "GradientExchange":
+        """(Re-)register the hooks, e.g. after refinement replaced the parameter objects."""
+        self.detach()
+        if self.enabled:
+            for name, p in self.named.items():
+                self._handles.append(p.register_post_accumulate_grad_hook(
+                    lambda param, name=name: self._start(name, param)))
+        return self
+
+    def detach(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def rebind(self, named_params) -> "GradientExchange":
+        self.named = dict(named_params)
+        return self.attach()
+
+    def _start(self, name, p) -> None:
+        g = p.grad
+        rows = self.active_rows.get(name)
+        stage = None
+        if rows is not None and g.dim() >= 2 and rows < g.shape[1]:
+            if rows <= 0:
+                return  # exact zeros on every rank
+            stage = g[:, :rows].contiguous()  # the active bands, packed
+            buf = stage
+        else:
+            buf = g
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        try:
+            work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+        except (RuntimeError, ValueError):
+            if op != dist.ReduceOp.AVG:
+                raise
+            self._avg_in_collective = False  # every rank runs the same library: all fall back together
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._bytes += buf.numel() * buf.element_size()
+        self.pending.append((work, buf, g, rows if stage is not None else None, op))
+
+    def finish(self) -> int:
+        """Wait for the collectives started during this backward; parameters that received
+        no gradient on this rank are exchanged as zeros.  Returns the bytes exchanged."""
+        if not self.enabled:
+            return 0
+        seen = {id(g) for _, _, g, _, _ in self.pending}
+        for name, p in self.named.items():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            if id(p.grad) not in seen and (self.active_rows.get(name) is None or self.active_rows[name] > 0):
+                self._start(name, p)
+        for work, buf, g, rows, op in self.pending:
+            work.wait()
+            if self.average and op != dist.ReduceOp.AVG:
+                buf.div_(self._ws)
+            if rows is not None:
+                g[:, :rows].copy_(buf)
+        self.pending = []
+        self.bytes_last, self._bytes = self._bytes, 0
+        return self.bytes_last
+
+
 def allreduce_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tensor,
                             max_2dsize: torch.Tensor, group=None) -> None:
     """Keep the densification statistics (vanilla_gs.py:351-372) identical on

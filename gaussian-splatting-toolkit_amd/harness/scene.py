@@ -78,14 +78,24 @@ def num_sh_bases(degree: int) -> int:
 
 def make_scene(n: int, cam: Camera, sh_degree: int = 3, seed: int = 42,
                scale_lo: float = 0.005, scale_hi: float = 0.05,
-               z_lo: float = 2.0, z_hi: float = 10.0) -> Dict[str, np.ndarray]:
-    """Random Gaussian cloud in front of `cam`."""
+               z_lo: float = 2.0, z_hi: float = 10.0, longtail: bool = False) -> Dict[str, np.ndarray]:
+    """Random Gaussian cloud in front of `cam`.  longtail: half of the
+    Gaussians are concentrated on 16 square patches that together cover 10 % of the
+    frame, so ~10 % of the tiles hold ~10x the list depth of the rest (same total)."""
     rng = np.random.default_rng(seed)
     tanx = 0.5 * cam.width / cam.fx
     tany = 0.5 * cam.height / cam.fy
     z = rng.uniform(z_lo, z_hi, n)
-    x = rng.uniform(-1, 1, n) * 1.1 * tanx * z
-    y = rng.uniform(-1, 1, n) * 1.1 * tany * z
+    ux, uy = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    if longtail:
+        patches, hs = 16, math.sqrt(0.10 * 4.0 / 16) / 2  # normalised frame = [-1,1]^2, area 4
+        centres = rng.uniform(-1 + hs, 1 - hs, (patches, 2))
+        which = rng.integers(0, patches, n)
+        clustered = rng.uniform(0, 1, n) < 0.5
+        ux = np.where(clustered, centres[which, 0] + rng.uniform(-hs, hs, n), ux)
+        uy = np.where(clustered, centres[which, 1] + rng.uniform(-hs, hs, n), uy)
+    x = ux * 1.1 * tanx * z
+    y = uy * 1.1 * tany * z
     p_cam = np.stack([x, y, z], -1)
     R, t = cam.viewmat[:3, :3].astype(np.float64), cam.viewmat[:3, 3].astype(np.float64)
     means = (p_cam - t) @ R  # R^T (p - t)

@@ -36,7 +36,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import scene as S
-from .parallel import allreduce_densify_stats, allreduce_gradients, view_for_rank
+from .parallel import GradientExchange, allreduce_densify_stats, view_for_rank
 from .pipeline import CameraTensors, render_view
 
 PARAM_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
@@ -276,6 +276,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
 
     psnr0 = evaluate()
     losses = []
+    # gradient exchange: started per parameter from autograd hooks (overlaps the rest of the
+    # backward), SH bands above the warm-up degree left out
+    exchange = GradientExchange({k: model.gauss[k] for k in PARAM_NAMES}, average=True).attach()
+    exchanged_bytes = []
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     if world > 1:
@@ -286,6 +290,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         for o in optims.values():
             o.zero_grad(set_to_none=True)
         deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
+        exchange.active_rows["features_rest"] = (deg + 1) ** 2 - 1
         out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp)
         rgb = out["rgb"]
         loss = loss_fn(rgb, gt[v])
@@ -311,7 +316,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                     max_2dsize = torch.where(visible, torch.maximum(max_2dsize, size), max_2dsize)
         stats_first = False
         if world > 1:
-            allreduce_gradients(model.param_list(), average=True)
+            b = exchange.finish()
+            if not exchanged_bytes or exchanged_bytes[-1][1] != b:
+                exchanged_bytes.append((step, b))
         for o in optims.values():
             o.step()
         # refinement_after: every refine_every iterations, after the optimizer step
@@ -338,6 +345,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                         vis_counts = torch.empty(n, device=device, dtype=torch.int32)
                         max_2dsize = torch.empty(n, device=device)
                     history.append((step, model.num_points))
+                    exchange.rebind({k: model.gauss[k] for k in PARAM_NAMES})
             # the statistics restart after every refinement_after past the warm-up (:491-493)
             stats_first = True
         if cfg.log_every and step % cfg.log_every == 0:
@@ -353,7 +361,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     return {"iters": cfg.iters, "seconds": elapsed, "iters_per_s": cfg.iters / elapsed, "psnr_start": psnr0,
             "psnr_end": psnr1, "losses": losses, "param_checksum": checksum,
             "views_per_s": world * cfg.iters / elapsed, "num_gaussians_start": n0,
-            "num_gaussians_end": model.num_points, "refinements": history}
+            "num_gaussians_end": model.num_points, "refinements": history,
+            # (step, bytes) whenever the per-step exchange volume changed: SH warm-up, refinement
+            "allreduce_bytes": exchanged_bytes}
 
 
 # the refinement backend (module-level so that CPU tests can substitute stand-ins)

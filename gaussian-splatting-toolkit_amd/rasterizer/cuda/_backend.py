@@ -57,6 +57,7 @@ SYMBOLS = (
     "gsr_refine_plan",
     "gsr_refine_apply",
     "gsr_adam_step",
+    "gsr_debug_count_staged",
 )
 
 

@@ -480,6 +480,14 @@ int gsr_adam_step(int num_tensors, const gsr_adam_tensor *tensors,
                   double beta1, double beta2, double eps, long long step,
                   gsr_stream_t stream);
 
+/* ---- measurement hook ---------------------------------------------------------
+ * counters: two device uint64 (or NULL = off, the default).  While set, the 16x16
+ * compositing kernels add the number of list entries they stage to counters[0]
+ * (forward) / counters[1] (backward): tiles stop once every pixel is saturated, so
+ * this is what a launch really reads of the lists (bench.py prices the roofline on
+ * it).  Device-wide setting (synchronises the device); not for production loops. */
+int gsr_debug_count_staged(unsigned long long *counters);
+
 #ifdef __cplusplus
 }
 #endif

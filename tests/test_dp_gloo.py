@@ -128,3 +128,57 @@ def test_flatten_roundtrip_single_process():
     allreduce_gradients(ps)  # no process group: identity
     for p, b in zip(ps, before):
         assert torch.equal(p.grad, b * 2)
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness.parallel import GradientExchange
+
+    g = torch.Generator().manual_seed(5)
+    n = 40
+    named = {"means": torch.randn(n, 3, generator=g).requires_grad_(True),
+             "features_rest": torch.randn(n, 15, 3, generator=g).requires_grad_(True),
+             "unused": torch.randn(n, 2, generator=g).requires_grad_(True)}
+    ex = GradientExchange(named, average=True).attach()
+    out = {}
+    for active in (0, 3, 15):  # SH warm-up: degree 0, 1, 3
+        ex.active_rows["features_rest"] = active
+        for p in named.values():
+            p.grad = None
+        w = torch.full((n, 15, 3), float(rank + 1))
+        w[:, active:] = 0  # the SH kernels write exact zeros for the inactive bands
+        loss = (named["means"] * (rank + 1)).sum() + (named["features_rest"] * w).sum()
+        loss.backward()  # the hooks start the collectives here
+        nbytes = ex.finish()
+        out[active] = (nbytes, named["means"].grad.clone(), named["features_rest"].grad.clone(),
+                       named["unused"].grad.clone())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_hooked_exchange_skips_inactive_sh_bands():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = 40
+    for active in (0, 3, 15):
+        (b0, m0, f0, u0), (b1, m1, f1, u1) = results[0][1][active], results[1][1][active]
+        assert b0 == b1 == 4 * (n * 3 + n * active * 3 + n * 2)  # the bytes shrink with the active bands
+        assert torch.equal(m0, m1) and torch.equal(f0, f1)      # replicas agree bit for bit
+        assert torch.allclose(m0, torch.full((n, 3), 1.5))       # mean of 1 and 2
+        exp = torch.zeros(n, 15, 3)
+        exp[:, :active] = 1.5
+        assert torch.equal(f0, exp)
+        assert torch.equal(u0, torch.zeros(n, 2))                 # no gradient anywhere: zeros, exchanged
