@@ -8,6 +8,13 @@
 // Behaviour restated from the reference kernels (gs_toolkit/gs_components/
 // rasterizer/cuda/csrc): forward.cu:13-90,398-464, backward.cu:305-453,
 // helpers.cuh:7-219.  3x3 algebra is written out on row-major scalars.
+//
+// Parity: this file is compiled with -ffp-contract=off (Makefile), like the CPU oracle
+// (oracle/Makefile), and evaluates every expression in the oracle's operation order with
+// correctly rounded division and square root (hipcc's default): the forward outputs --
+// including the integer radii / num_tiles_hit, which sit behind a ceil() -- are then
+// bit-identical to the oracle's (tests/test_gpu_kernels.py::test_project_forward).  The
+// kernels are HBM-bound, so the few un-fused multiply-adds cost nothing measurable.
 #include "gsr_common.h"
 
 namespace {
@@ -36,7 +43,7 @@ __device__ __forceinline__ M3 transpose(const M3 &A) {
 // (w,x,y,z) quaternion -> rotation; renormalises (helpers.cuh:144-159)
 __device__ __forceinline__ M3 quat_to_rot(float qw, float qx, float qy, float qz,
                                           float &w, float &x, float &y, float &z) {
-  const float s = rsqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+  const float s = 1.f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);  // (not rsqrtf: see the parity note)
   w = qw * s;
   x = qx * s;
   y = qy * s;

@@ -29,20 +29,39 @@ def npy(t):
     return t.detach().cpu().numpy()
 
 
-def grad_close(mine, ref, abs_sum=None, name=""):
-    """Per-Gaussian gradients are sums over up to ~1e4 pixels with heavy
-    cancellation.  Criteria:
-      * |err| <= 1e-3 |ref| + 5e-4 * abs_sum for all but a 1e-4 fraction of elements, abs_sum = sum of |per-pixel terms| from
-        the oracle (the scale on which fp32 rounding and the 1/(1-alpha) amplified
-        1-ulp differences of exp() live) -- where the oracle provides it;
+def stable_gaussians(amb_pixels, amb_gaussians, xys, radii, W, H):
+    """Gaussians none of whose discrete decisions can legitimately differ between two
+    correct fp32 implementations: not flagged by the oracle's backward (own alpha / sigma
+    within 1e-5 of a threshold) and with no forward-unstable pixel (termination or threshold
+    within 1e-5 of flipping, which changes final_T / final_idx of that pixel for every
+    Gaussian drawn there) inside their 3-sigma box."""
+    ii = np.zeros((H + 1, W + 1), np.int64)
+    ii[1:, 1:] = amb_pixels.astype(np.int64).cumsum(0).cumsum(1)
+    x, y, rad = xys[:, 0], xys[:, 1], radii.astype(np.float32)
+    x0 = np.clip(np.floor(x - rad), 0, W).astype(int)
+    x1 = np.clip(np.ceil(x + rad) + 1, 0, W).astype(int)
+    y0 = np.clip(np.floor(y - rad), 0, H).astype(int)
+    y1 = np.clip(np.ceil(y + rad) + 1, 0, H).astype(int)
+    touched = (ii[y1, x1] - ii[y0, x1] - ii[y1, x0] + ii[y0, x0]) > 0
+    return ~(touched | amb_gaussians)
+
+
+def grad_close(mine, ref, abs_sum=None, name="", stable=None):
+    """Per-Gaussian gradients are sums over up to ~1e4 pixels with heavy cancellation.
+      * STABLE Gaussians (see `stable_gaussians`): north_star's bar, |err| <= 1e-3 |ref|
+        elementwise, with |ref| floored at 1e-4 max|ref| (elements that cancel to ~0);
+      * the others (a pixel's decision may differ): |err| <= 1e-3 |ref| + 5e-4 * abs_sum for all
+        but a 1e-4 fraction of elements, none by more than 20x (abs_sum = sum of |per-pixel
+        terms| from the oracle, the scale a flipped pixel perturbs);
       * max |err| <= 1e-3 max|ref|  and  ||err||_2 <= 1e-4 ||ref||_2  always."""
     err = np.abs(mine - ref)
+    if stable is not None:
+        assert stable.mean() > 0.05, f"{name}: only {stable.mean():.3f} of the Gaussians are stable"
+        rel = err[stable] / np.maximum(np.abs(ref[stable]), 1e-4 * np.abs(ref).max())
+        assert rel.max() <= 1e-3, f"{name}: stable Gaussians differ by {rel.max():.3e} relative"
     if abs_sum is not None:
         bound = 1e-3 * np.abs(ref) + 5e-4 * abs_sum
         ratio = err / np.maximum(bound, 1e-30)
-        # a numerically unstable pixel that flipped in the forward (see module docstring of
-        # test_gpu_kernels.py) perturbs every Gaussian of that pixel: allow a 1e-4 fraction of
-        # elements to exceed the bound, none by more than 20x
         assert (ratio > 1).mean() <= 1e-4 and ratio.max() < 20, (
             f"{name}: {(ratio > 1).sum()} elements exceed 1e-3|ref| + 5e-4*abs_sum (worst {ratio.max():.2f}x)")
     assert err.max() <= 1e-3 * np.abs(ref).max(), f"{name}: max abs err {err.max():.3e} vs max|ref| {np.abs(ref).max():.3e}"
@@ -75,12 +94,10 @@ def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
         n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat, cam.fx, cam.fy,
         cam.cx, cam.cy, H, W, 16, 0.01)
     g_radii, g_tiles = npy(out["radii"]), npy(out["num_tiles_hit"])
-    same = g_radii == radii
-    assert same.mean() > 0.9995
-    assert np.array_equal(g_tiles[same], tiles[same])
-    vis = (radii > 0) & same
-    np.testing.assert_allclose(npy(out["xys"])[vis], xys[vis], rtol=1e-5, atol=5e-3)
-    np.testing.assert_allclose(npy(out["conics"])[vis], conics[vis], rtol=2e-3, atol=1e-6)
+    # bit-exact: same FMA policy and operation order as the oracle (csrc/project.hip header)
+    assert np.array_equal(g_radii, radii) and np.array_equal(g_tiles, tiles)
+    assert np.array_equal(npy(out["xys"]), xys) and np.array_equal(npy(out["conics"]), conics)
+    assert np.array_equal(npy(out["depths"]), depths)
     # (2) binning + compositing on the GPU's projection outputs
     gx, gd, gc = npy(out["xys"]), npy(out["depths"]), npy(out["conics"])
     rgbs = npy(out["rgbs"])
@@ -96,20 +113,21 @@ def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
     assert np.abs((1 - npy(out["alpha"])[..., 0]) - ref_T)[ok].max() < 1e-4
     assert np.abs(img - ref_img).max() < 0.05
     # (3) backward of the compositing + projection + SH
-    vxy, vconic, vcol, vop, axy, aconic, acol, aop = O.rasterize_backward(
+    vxy, vconic, vcol, vop, axy, aconic, acol, aop, amb_g = O.rasterize_backward(
         H, W, 16, vs, bins, gx, gc, rgbs, sc["opacities"], bg, ref_T, ref_idx, v_img, v_alpha,
-        with_abs_sums=True)
-    grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad")
-    grad_close(npy(params["opacities"].grad), vop, aop, name="opacities")
+        with_abs_sums=True, ambig_eps=1e-5)
+    stable = stable_gaussians(amb, amb_g, gx, g_radii, W, H)
+    grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable)
+    grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable)
     vsh = O.compute_sh_backward(n, deg, deg, dirs, (vcol * (sh + 0.5 > 0)).astype(np.float32))
-    grad_close(npy(params["sh_coeffs"].grad), vsh, name="sh_coeffs")
+    grad_close(npy(params["sh_coeffs"].grad), vsh, name="sh_coeffs", stable=stable)
     zeros = np.zeros(n, np.float32)
     _, _, vmean, vscale, vquat = O.project_gaussians_backward(
         n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat, cam.fx, cam.fy,
         cam.cx, cam.cy, H, W, cov3d, g_radii, gc, comp, vxy, zeros, vconic, zeros)
-    grad_close(npy(params["means3d"].grad), vmean, name="means3d")
-    grad_close(npy(params["scales"].grad), vscale, name="scales")
-    grad_close(npy(params["quats"].grad), vquat, name="quats")
+    grad_close(npy(params["means3d"].grad), vmean, name="means3d", stable=stable)
+    grad_close(npy(params["scales"].grad), vscale, name="scales", stable=stable)
+    grad_close(npy(params["quats"].grad), vquat, name="quats", stable=stable)
 
 
 @pytest.fixture(scope="module")

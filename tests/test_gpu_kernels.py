@@ -75,19 +75,13 @@ def test_project_forward(n, W, H, bw, ck):
     names = ["cov3d", "xys", "depths", "radii", "conics", "compensation", "num_tiles_hit"]
     r = dict(zip(names, ref))
     o = dict(zip(names, out))
-    # the radius is ceil(3 sqrt(lambda)): 1-ulp differences may move it by one
-    # on exact integers; such Gaussians are excluded from the exact checks.
-    same = o["radii"] == r["radii"]
-    assert same.mean() > 0.999
-    vis = (r["radii"] > 0) & same
-    assert np.array_equal(o["num_tiles_hit"][same], r["num_tiles_hit"][same])
-    np.testing.assert_allclose(o["xys"][vis], r["xys"][vis], rtol=1e-5, atol=2e-3)
-    np.testing.assert_allclose(o["depths"][vis], r["depths"][vis], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(o["cov3d"][vis], r["cov3d"][vis], rtol=1e-4, atol=1e-8)
-    np.testing.assert_allclose(o["conics"][vis], r["conics"][vis], rtol=2e-3, atol=1e-6)
-    np.testing.assert_allclose(o["compensation"][vis], r["compensation"][vis], rtol=1e-3, atol=1e-5)
+    # project.hip and the oracle are both compiled without FMA contraction and evaluate the
+    # same expressions in the same order with correctly rounded / and sqrt: every output is
+    # BIT-IDENTICAL, the integer ones (radii sit behind a ceil) included
+    for k in names:
+        assert np.array_equal(o[k], r[k]), f"{k}: {(o[k] != r[k]).sum()} elements differ"
     # culled splats: everything the consumers read is zero
-    cul = (r["radii"] == 0) & same
+    cul = r["radii"] == 0
     for k in ("xys", "depths", "compensation", "num_tiles_hit"):
         assert np.all(o[k][cul] == 0), k
 
@@ -313,7 +307,7 @@ def test_tile16_matches_generic_kernel():
     g1 = C.rasterize_backward(*b)
     g2 = C.nd_rasterize_backward(*b)
     for x, y in zip(g1, g2):
-        grad_close(npy(x), npy(y), tol=2e-3)
+        grad_close(npy(x), npy(y), tol=1e-3)
 
 
 def test_backward_alpha_saturation_follows_cuda_rule():
