@@ -334,9 +334,12 @@ __global__ __launch_bounds__(256) void sh_split_fwd_kernel(
   gr += shift;
   b += shift;
   if (clamp_zero) {
-    r = fmaxf(r, 0.f);
-    gr = fmaxf(gr, 0.f);
-    b = fmaxf(b, 0.f);
+    // a channel the clamp cut is stored as -0.0 (== 0 for every consumer), a channel at exactly
+    // zero as +0.0: the backward tells them apart, because torch.clamp(x, min=0) passes the
+    // gradient where x >= 0 and blocks it where x < 0
+    r = r < 0.f ? -0.f : r + 0.f;
+    gr = gr < 0.f ? -0.f : gr + 0.f;
+    b = b < 0.f ? -0.f : b + 0.f;
   }
   colors[3 * g] = r;
   colors[3 * g + 1] = gr;
@@ -362,10 +365,10 @@ __global__ __launch_bounds__(256) void sh_split_bwd_kernel(
       for (int k = 1; k < K; ++k) B[k] = 0.f;
     }
     float vr = v_colors[3 * g], vg = v_colors[3 * g + 1], vb = v_colors[3 * g + 2];
-    if (clamped_colors) {  // forward output of the clamped epilogue: no gradient where it cut
-      vr = clamped_colors[3 * g] > 0.f ? vr : 0.f;
-      vg = clamped_colors[3 * g + 1] > 0.f ? vg : 0.f;
-      vb = clamped_colors[3 * g + 2] > 0.f ? vb : 0.f;
+    if (clamped_colors) {  // forward output of the clamped epilogue: no gradient where it cut (-0.0)
+      vr = __float_as_uint(clamped_colors[3 * g]) == 0x80000000u ? 0.f : vr;
+      vg = __float_as_uint(clamped_colors[3 * g + 1]) == 0x80000000u ? 0.f : vg;
+      vb = __float_as_uint(clamped_colors[3 * g + 2]) == 0x80000000u ? 0.f : vb;
     }
     v_dc[3 * g] = B[0] * vr;
     v_dc[3 * g + 1] = B[0] * vg;

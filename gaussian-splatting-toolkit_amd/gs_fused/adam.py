@@ -53,6 +53,16 @@ class FusedAdam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                # state restored from a checkpoint (torch.optim.Adam's state_dict is interchangeable)
+                # or handed over by refinement may be non-fp32 / non-contiguous / on another
+                # device: re-materialise it rather than hand a wrong pointer to the kernel
+                for key_ in ("exp_avg", "exp_avg_sq"):
+                    t = st[key_]
+                    if t.shape != p.shape:
+                        raise RuntimeError(f"FusedAdam: {key_} has shape {tuple(t.shape)}, parameter {tuple(p.shape)}")
+                    if t.dtype != torch.float32 or t.device != p.device or not t.is_contiguous():
+                        st[key_] = t = t.to(device=p.device, dtype=torch.float32).contiguous()
+                    _check(t, key_, torch.float32)
                 st["step"] = int(st["step"]) + 1
                 key = (p.device, float(b1), float(b2), float(group["eps"]), st["step"])
                 batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"])))

@@ -197,6 +197,10 @@ class TrainConfig:
     init_gaussians: Optional[int] = None  # the model starts from this many (coarser) Gaussians; default: all
     refine: Optional[object] = None       # gs_fused.RefineConfig; default: the reference's values
     refine_seed: int = 20240807           # broadcast by construction: the same on every rank
+    # checkpoints in the toolkit's layout (harness/checkpoint.py; trainer.py:404-476)
+    checkpoint_dir: Optional[str] = None
+    save_every: int = 0                   # steps_per_save; 0 = never
+    resume_from: Optional[str] = None     # a .ckpt file or a directory (latest step)
     scene: str = "ball"                   # blob_scene kind
     scene_scale: tuple = (0.01, 0.06)     # range of the truth's Gaussian scales
 
@@ -274,6 +278,15 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             idx = np.linspace(0, cfg.num_views - 1, cfg.eval_views).astype(int)
             return float(np.mean([psnr(model.render(cams[i], bg, cfg.sh_degree)["rgb"], gt[i]) for i in idx]))
 
+    start_step = 0
+    if cfg.resume_from:
+        from .checkpoint import load_checkpoint
+
+        start_step = load_checkpoint(cfg.resume_from, model, optims)  # resizes the model to the saved N
+        n = model.num_points
+        xys_grad_norm = torch.zeros(n, device=device)
+        vis_counts = torch.zeros(n, device=device, dtype=torch.int32)
+        max_2dsize = torch.zeros(n, device=device)
     psnr0 = evaluate()
     losses = []
     # gradient exchange: started per parameter from autograd hooks (overlaps the rest of the
@@ -285,7 +298,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for step in range(cfg.iters):
+    for step in range(start_step, cfg.iters):
         v = view_for_rank(step, rank, world, cfg.num_views)
         for o in optims.values():
             o.zero_grad(set_to_none=True)
@@ -348,6 +361,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                     exchange.rebind({k: model.gauss[k] for k in PARAM_NAMES})
             # the statistics restart after every refinement_after past the warm-up (:491-493)
             stats_first = True
+        if cfg.save_every and cfg.checkpoint_dir and step > 0 and step % cfg.save_every == 0 and rank == 0:
+            from .checkpoint import save_checkpoint
+
+            save_checkpoint(cfg.checkpoint_dir, step, model, optims)
         if cfg.log_every and step % cfg.log_every == 0:
             losses.append(float(loss.detach()))
     if world > 1:
@@ -358,9 +375,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     elapsed = time.perf_counter() - t0
     psnr1 = evaluate()
     checksum = float(sum(p.detach().double().sum() for p in model.param_list()))
-    return {"iters": cfg.iters, "seconds": elapsed, "iters_per_s": cfg.iters / elapsed, "psnr_start": psnr0,
+    return {"iters": cfg.iters - start_step, "start_step": start_step, "seconds": elapsed,
+            "iters_per_s": (cfg.iters - start_step) / elapsed, "psnr_start": psnr0,
             "psnr_end": psnr1, "losses": losses, "param_checksum": checksum,
-            "views_per_s": world * cfg.iters / elapsed, "num_gaussians_start": n0,
+            "views_per_s": world * (cfg.iters - start_step) / elapsed, "num_gaussians_start": n0,
             "num_gaussians_end": model.num_points, "refinements": history,
             # (step, bytes) whenever the per-step exchange volume changed: SH warm-up, refinement
             "allreduce_bytes": exchanged_bytes}

@@ -309,8 +309,9 @@ int gsr_depth_l1_backward(long long num_pixels, const float *upstream,
  * are written straight into v_dc [n,3] and v_rest [n,K-1,3].  degree in [1,3]
  * (K = (degree+1)^2).  Optional epilogue of the models (vanilla_gs.py:826,
  * `torch.clamp(rgbs + 0.5, min=0.0)`): colors = sh + shift, cut at 0 when
- * clamp_zero != 0; the backward then takes those colours (clamped_colors, NULL if
- * not clamped) and passes no gradient where they are 0. */
+ * clamp_zero != 0 -- a channel that was cut is stored as -0.0, so that the backward,
+ * which takes those colours (clamped_colors, NULL if not clamped), blocks the gradient
+ * exactly where sh + shift < 0 and passes it where it is >= 0, like torch.clamp. */
 int gsr_sh_forward_split(unsigned num_points, unsigned degree,
                          unsigned degrees_to_use, const float *viewdirs,
                          const float *dc, const float *rest, float *colors,

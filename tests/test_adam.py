@@ -105,3 +105,37 @@ def test_fused_adam_contract():
         FusedAdam([c]).step()
     with pytest.raises(ValueError):
         FusedAdam([p], betas=(1.0, 0.999))
+
+
+@pytest.mark.gpu
+def test_fused_adam_rematerialises_nonconforming_state():
+    """State restored from a torch.optim.Adam checkpoint (or sliced by refinement) may be
+    fp64 / non-contiguous: FusedAdam converts it instead of reading wrong memory."""
+    import torch
+
+    from gs_fused import FusedAdam
+
+    torch.manual_seed(0)
+    p = torch.randn(1000, 3, device="cuda", requires_grad=True)
+    q = p.detach().clone().requires_grad_(True)
+    ref = torch.optim.Adam([q], lr=1e-2, eps=1e-15)
+    opt = FusedAdam([p], lr=1e-2, eps=1e-15)
+    for it in range(3):
+        g = torch.randn_like(p)
+        p.grad, q.grad = g.clone(), g.clone()
+        opt.step()
+        ref.step()
+        if it == 0:  # degrade the state: fp64 and a non-contiguous view
+            st = opt.state[p]
+            st["exp_avg"] = st["exp_avg"].double()
+            wide = torch.zeros(1000, 6, device="cuda")
+            wide[:, ::2] = st["exp_avg_sq"]
+            st["exp_avg_sq"] = wide[:, ::2]
+            assert not st["exp_avg_sq"].is_contiguous()
+    assert torch.allclose(p, q, rtol=2e-6, atol=1e-7)
+    st = opt.state[p]
+    assert st["exp_avg"].dtype == torch.float32 and st["exp_avg_sq"].is_contiguous()
+    st["exp_avg"] = st["exp_avg"][:10]
+    p.grad = torch.randn_like(p)
+    with pytest.raises(RuntimeError):
+        opt.step()

@@ -514,6 +514,32 @@ def test_split_sh_equals_cat(K, use, n):
         assert np.abs(got2 - c.grad.cpu().numpy()).max() < 1e-6
 
 
+def test_split_sh_clamp_passes_the_gradient_at_exactly_zero():
+    """torch.clamp(x, min=0) passes the cotangent where x >= 0, x == 0 included; the fused
+    epilogue must too (a channel that was cut is told apart from one that is exactly zero)."""
+    from gs_fused import spherical_harmonics_split
+    from rasterizer import spherical_harmonics
+
+    n = 64
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, device=DEV), dim=-1)
+    dc = torch.zeros(n, 3, device=DEV)
+    dc[::3] = -1.0   # sh + shift < 0: cut, no gradient
+    dc[1::3] = 1.0   # > 0
+    # rows 2::3 stay 0: sh + shift == 0 exactly (shift 0, all coefficients 0)
+    dc.requires_grad_(True)
+    rest = torch.zeros(n, 3, 3, device=DEV, requires_grad=True)
+    v = torch.randn(n, 3, device=DEV)
+    out = spherical_harmonics_split(1, dirs, dc, rest, shift=0.0, clamp_zero=True)
+    out.backward(v)
+    c = torch.cat((dc.detach()[:, None, :], rest.detach()), 1).requires_grad_(True)
+    ref = torch.clamp(spherical_harmonics(1, dirs, c) + 0.0, min=0.0)
+    ref.backward(v)
+    assert torch.equal(out == 0, ref == 0) and torch.allclose(out, ref)
+    assert torch.allclose(dc.grad, c.grad[:, 0], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(rest.grad, c.grad[:, 1:], rtol=1e-6, atol=1e-7)
+    assert dc.grad[2::3].abs().min().item() > 0 and dc.grad[::3].abs().max().item() == 0
+
+
 @pytest.mark.parametrize("n", [1, 257, 10_000])
 def test_activate_gaussians_equals_torch_ops(n):
     """gs_fused.activate_gaussians == exp / normalise / sigmoid / normalised view

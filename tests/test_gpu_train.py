@@ -55,3 +55,28 @@ def test_training_with_refinement_grows_the_model_and_keeps_learning():
     assert [s for s, _ in res2["refinements"]] == [s for s, _ in res["refinements"]]
     for (_, n1), (_, n2) in zip(res["refinements"], res2["refinements"]):
         assert abs(n1 - n2) <= 0.01 * n1, (res["refinements"], res2["refinements"])
+
+
+def test_resume_from_checkpoint_after_densification(tmp_path):
+    """A run that densified and saved can be resumed by a trainer that starts from the
+    initial number of Gaussians: the model and the FusedAdam state are resized on load
+    (vanilla_gs.py:236-258, trainer.py:404-443)."""
+    from gs_fused import RefineConfig
+    from harness import checkpoint as CK
+    from harness.train import TrainConfig, train
+
+    rcfg = RefineConfig(warmup_length=40, refine_every=20, reset_alpha_every=6, stop_screen_size_at=200,
+                        stop_split_at=260)
+    kw = dict(num_gaussians=20_000, init_gaussians=4_000, width=320, height=180, num_views=8, sh_degree=3,
+              sh_degree_interval=60, densify=True, refine=rcfg, checkpoint_dir=str(tmp_path), save_every=100)
+    first = train(TrainConfig(iters=101, **kw), torch.device("cuda", 0))
+    saved = torch.load(CK.latest_checkpoint(str(tmp_path)), map_location="cpu", weights_only=False)
+    n_saved = saved["pipeline"]["_model.gauss_params.means"].shape[0]
+    assert saved["step"] == 100 and n_saved == first["num_gaussians_end"] != 4_000
+    assert saved["optimizers"]["means"]["state"][0]["exp_avg"].shape[0] == n_saved
+    second = train(TrainConfig(iters=200, resume_from=str(tmp_path), **kw), torch.device("cuda", 0))
+    assert second["start_step"] == 101 and second["num_gaussians_start"] == 4_000
+    # it continues from the saved model: the PSNR the resumed trainer starts from is the one the
+    # first run ended with (same parameters, the forward is deterministic)
+    assert abs(second["psnr_start"] - first["psnr_end"]) < 1e-3, (first, second)
+    assert second["psnr_end"] > second["psnr_start"] - 0.5 and np.isfinite(second["param_checksum"])
