@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const float *__restrict__ v_output_alpha, float *__restrict__ v_xy,
     float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity,
     const float *__restrict__ extra, const float bg_extra, const float *__restrict__ v_out_extra,
-    float *__restrict__ v_extra) {
+    float *__restrict__ v_extra, const int deep_threshold, const unsigned base_grid) {
   static_assert(!RGBD || G == 4, "the 10-component butterfly exists for groups of 4");
   constexpr int NC = RGBD ? 10 : 9;
   __shared__ SplatA sA[kChunk];
@@ -215,9 +215,10 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   __shared__ int sId[kChunk];
   using BF = Butterfly<G>;
 
-  const int tile = gsr_xcd_remap(blockIdx.x, tiles_x, num_tiles / tiles_x);
+  int2 range = make_int2(0, 0);
+  const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
+  const int tile = job.tile, allowed = job.allowed;  // allowed: the sub-tiles this wave owns (raster_common.h)
   if (tile < 0) return;
-  const int2 range = tile_bins[tile];
   if (range.y <= range.x) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
-    const bool inside = col < img_w && row < img_h;
+    const bool inside = col < img_w && row < img_h && ((allowed >> p) & 1);
     T[p] = 1.f;
     K[p] = vr[p] = vg[p] = vb[p] = ve[p] = 0.f;
     binf[p] = -1;  // `inside && idx <= bin_final` folds into one compare
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     // back to front: lane l fetches sorted index hi - l; kept splats stay in that order
     const int sidx_l = hi - lane;
     const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics,
-                                  colors, opacities, sA, sB, sC, sId, RGBD ? extra : nullptr, staged);
+                                  colors, opacities, sA, sB, sC, sId, RGBD ? extra : nullptr, staged, allowed);
     __syncthreads();
 
     for (int t0 = 0; t0 < count; t0 += G) {
@@ -563,7 +564,7 @@ GSR_EXPORT int gsr_rasterize_backward(
     const float *conics, const float *colors, const float *opacities, const float *background,
     const float *final_Ts, const int32_t *final_idx, const float *v_output,
     const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
-    gsr_stream_t stream) {
+    int deep_tile_threshold, gsr_stream_t stream) {
   if (block_width != 16)
     return gsr_rasterize_backward_nd(img_height, img_width, block_width, 3, num_points,
                                      gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
@@ -586,14 +587,16 @@ GSR_EXPORT int gsr_rasterize_backward(
     const char *e = getenv("GSR_BWD_GROUP");
     return (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : GSR_BWD_GROUP;
   }();
+  const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
+  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
 #define GSR_LAUNCH_T16(G)                                                                          \
-  hipLaunchKernelGGL((raster_bwd_tile16_kernel<G, false>), dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)),      \
+  hipLaunchKernelGGL((raster_bwd_tile16_kernel<G, false>), dim3(deep ? 4 * base : base),            \
                      dim3(64), 0, s, tiles_x,                                                        \
                      num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,               \
                      reinterpret_cast<const int2 *>(tile_bins),                                     \
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,  \
                      final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,        \
-                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr)
+                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep, base)
   if (group == 8) GSR_LAUNCH_T16(8);
   else GSR_LAUNCH_T16(4);
 #undef GSR_LAUNCH_T16
@@ -606,7 +609,8 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
     const int32_t *tile_bins, const float *xys, const float *conics, const float *colors, const float *extra,
     const float *opacities, const float *background, float extra_background, const float *final_Ts,
     const int32_t *final_idx, const float *v_output, const float *v_output_extra, const float *v_output_alpha,
-    float *v_xy, float *v_conic, float *v_colors, float *v_extra, float *v_opacity, gsr_stream_t stream) {
+    float *v_xy, float *v_conic, float *v_colors, float *v_extra, float *v_opacity, int deep_tile_threshold,
+    gsr_stream_t stream) {
   GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward_rgbd: empty image");
   GSR_REQUIRE(num_points >= 0, "rasterize_backward_rgbd: num_points < 0");
   if (num_points == 0) return GSR_OK;
@@ -620,11 +624,13 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
   GSR_CHECK_HIP(hipMemsetAsync(v_extra, 0, sizeof(float) * (size_t)num_points, s));
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
-  hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, true>), dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64),
+  const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
+  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, true>), dim3(deep ? 4 * base : base), dim3(64),
                      0, s, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics,
                      colors, opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic,
-                     v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra);
+                     v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra, deep, base);
   GSR_CHECK_LAUNCH("rasterize_backward_rgbd");
   return GSR_OK;
 }

@@ -79,6 +79,43 @@ __device__ __forceinline__ int splat_reach_mask(float x, float y, float a, float
   return m;
 }
 
+// ---- deep tiles ---------------------------------------------------------------
+// One wave per tile makes a kernel as slow as its deepest tiles: a tile whose list is
+// several times the average keeps one wave busy long after the rest of the chip has
+// drained (clustered scenes: 10 % of the tiles with 10x the depth).  With
+// deep_threshold > 0 the launch carries three more blocks per tile slot; for a tile
+// whose list is longer than the threshold the four blocks each take ONE 8x8 sub-tile
+// (the regular block sub-tile 0), for every other tile the extra blocks exit at once.
+// A sub-tile wave runs the very same per-pixel instructions on its 64 pixels (the other
+// three sub-tiles are masked off wave-uniformly) and stages only the splats that reach
+// its sub-tile, so results are bit-identical to the one-wave-per-tile walk.
+// Block b of the extra range [base_grid, 4 base_grid) sits on XCD b % 8 like the regular
+// block of the same tile (the four waves share the splat records in one L2).
+struct TileJob {
+  int tile;     // < 0: nothing to do
+  int allowed;  // sub-tile mask this wave owns (15 = the whole tile)
+};
+__device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned base_grid, const int tiles_x,
+                                            const int tiles_y, const int2 *__restrict__ tile_bins,
+                                            const int deep_threshold, int2 &range) {
+  TileJob j{-1, 15};
+  if (b < base_grid) {
+    j.tile = gsr_xcd_remap(b, tiles_x, tiles_y);
+    if (j.tile < 0) return j;
+    range = tile_bins[j.tile];
+    if (deep_threshold > 0 && range.y - range.x > deep_threshold) j.allowed = 1;
+    return j;
+  }
+  const unsigned e = b - base_grid, x = e & 7u, q = e >> 3;
+  const int tile = gsr_xcd_remap((q / 3u) * 8u + x, tiles_x, tiles_y);
+  if (tile < 0) return j;
+  range = tile_bins[tile];
+  if (range.y - range.x <= deep_threshold) return j;
+  j.tile = tile;
+  j.allowed = 2 << (q % 3u);
+  return j;
+}
+
 // Stage up to 64 splats (one per `live` lane, sorted index `sidx`) into LDS,
 // dropping the ones that cannot reach the tile; returns how many were kept.
 // Kept splats stay in lane order.  Wave-synchronous (one wave per workgroup).
@@ -87,7 +124,8 @@ __device__ __forceinline__ int stage_chunk(
     const int *__restrict__ ids_sorted, const float2 *__restrict__ xys,
     const float *__restrict__ conics, const float *__restrict__ colors,
     const float *__restrict__ opacities, SplatA *sA, SplatB *sB, SplatC *sC, int *sId,
-    const float *__restrict__ extra = nullptr, unsigned long long *staged_counter = nullptr) {
+    const float *__restrict__ extra = nullptr, unsigned long long *staged_counter = nullptr,
+    const int allowed = 15) {
   // measurement hook (gsr_debug_count_staged): list entries read by this launch
   if (staged_counter) {
     const int n = __popcll(__ballot(live));
@@ -108,6 +146,7 @@ __device__ __forceinline__ int stage_chunk(
 #ifdef GSR_NO_CULL
     mask = 15;  // experiment: keep every list entry
 #endif
+    mask &= allowed;  // a wave that owns one sub-tile of a deep tile keeps only what reaches it
   }
   const unsigned long long kept = __ballot(mask != 0);
   if (mask != 0) {

@@ -53,12 +53,14 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ background, float *__restrict__ out_img,
     float *__restrict__ final_Ts, int *__restrict__ final_idx, const float *__restrict__ extra,
-    const float bg_extra, float *__restrict__ out_extra) {
+    const float bg_extra, float *__restrict__ out_extra, const int deep_threshold, const unsigned base_grid) {
   __shared__ SplatA sA[kChunk];
   __shared__ SplatB sB[kChunk];
   __shared__ SplatC sC[kChunk];
 
-  const int tile = gsr_xcd_remap(blockIdx.x, tiles_x, num_tiles / tiles_x);
+  int2 range = make_int2(0, 0);
+  const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
+  const int tile = job.tile, allowed = job.allowed;
   if (tile < 0) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   int last[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const bool inside = (qx + 8 * (p & 1)) < img_w && (qy + 8 * (p >> 1)) < img_h;
+    const bool inside = (qx + 8 * (p & 1)) < img_w && (qy + 8 * (p >> 1)) < img_h && ((allowed >> p) & 1);
     T[p] = inside ? 1.f : -1.f;
     cr[p] = cg[p] = cb[p] = ce[p] = 0.f;
     last[p] = 0;
@@ -86,13 +88,12 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     return m;
   };
 
-  const int2 range = tile_bins[tile];
   unsigned long long *const staged = g_fwd_staged;
   int live = live_subtiles();
   for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
     const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics,
-                                  colors, opacities, sA, sB, sC, nullptr, RGBD ? extra : nullptr, staged);
+                                  colors, opacities, sA, sB, sC, nullptr, RGBD ? extra : nullptr, staged, allowed);
     __syncthreads();
     for (int t = 0; t < count; ++t) {
       if ((t & 7) == 7) {
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
-    if (col < img_w && row < img_h) {
+    if (col < img_w && row < img_h && ((allowed >> p) & 1)) {
       const size_t pid = (size_t)row * img_w + col;
       const float Tp = fabsf(T[p]);
       final_Ts[pid] = Tp;
@@ -289,7 +290,7 @@ GSR_EXPORT int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_wi
                                      const float *xys, const float *conics, const float *colors,
                                      const float *opacities, const float *background,
                                      float *out_img, float *final_Ts, int32_t *final_idx,
-                                     gsr_stream_t stream) {
+                                     int deep_tile_threshold, gsr_stream_t stream) {
   int rc = check_common("rasterize_forward", tiles_x, tiles_y, block_width, img_width, img_height, 3);
   if (rc != GSR_OK) return rc;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
@@ -300,11 +301,13 @@ GSR_EXPORT int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_wi
                           gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
                           background, out_img, final_Ts, final_idx, (hipStream_t)stream);
   const int num_tiles = tiles_x * tiles_y;
-  hipLaunchKernelGGL(raster_fwd_tile16_kernel<false>, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0,
+  const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
+  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  hipLaunchKernelGGL(raster_fwd_tile16_kernel<false>, dim3(deep ? 4 * base : base), dim3(64), 0,
                      (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
-                     out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr);
+                     out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base);
   GSR_CHECK_LAUNCH("rasterize_forward(tile16)");
   return GSR_OK;
 }
@@ -315,18 +318,20 @@ GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img
                                           const float *extra, const float *opacities,
                                           const float *background, float extra_background, float *out_img,
                                           float *out_extra, float *final_Ts, int32_t *final_idx,
-                                          gsr_stream_t stream) {
+                                          int deep_tile_threshold, gsr_stream_t stream) {
   int rc = check_common("rasterize_forward_rgbd", tiles_x, tiles_y, 16, img_width, img_height, 3);
   if (rc != GSR_OK) return rc;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && extra && opacities && background &&
                   out_img && out_extra && final_Ts && final_idx,
               "rasterize_forward_rgbd: null pointer");
   const int num_tiles = tiles_x * tiles_y;
-  hipLaunchKernelGGL(raster_fwd_tile16_kernel<true>, dim3(gsr_xcd_grid(tiles_x, num_tiles / tiles_x)), dim3(64), 0,
+  const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
+  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  hipLaunchKernelGGL(raster_fwd_tile16_kernel<true>, dim3(deep ? 4 * base : base), dim3(64), 0,
                      (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
-                     out_img, final_Ts, final_idx, extra, extra_background, out_extra);
+                     out_img, final_Ts, final_idx, extra, extra_background, out_extra, deep, base);
   GSR_CHECK_LAUNCH("rasterize_forward_rgbd");
   return GSR_OK;
 }

@@ -201,7 +201,14 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
 /* ---- compositing ----------------------------------------------------------
  * replaces rasterize_forward_tensor (bindings.cu:269-328), kernel
  * forward.cu:278-395 (3 channels, fp32).  out_img[H,W,3] final_Ts[H,W]
- * final_idx[H,W](i32). */
+ * final_idx[H,W](i32).
+ * deep_tile_threshold (block_width 16 only; here, in gsr_rasterize_backward and in
+ * the _rgbd variants): 0 = one wave per tile.  > 0: a tile whose list holds more
+ * entries than this is composited by four waves, one per 8x8 sub-tile, so that a few
+ * very deep tiles (clustered scenes) do not hold a kernel up after the rest of the
+ * chip has drained.  Never changes a result (same per-pixel instruction sequence);
+ * costs three idle workgroups per tile at launch.  A good value: 1.5x the mean list
+ * length, not below 1024 (a split tile costs ~2x the instructions per list entry). */
 int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_width,
                           unsigned img_width, unsigned img_height,
                           const int32_t *gaussian_ids_sorted,
@@ -209,7 +216,7 @@ int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_width,
                           const float *conics, const float *colors,
                           const float *opacities, const float *background,
                           float *out_img, float *final_Ts, int32_t *final_idx,
-                          gsr_stream_t stream);
+                          int deep_tile_threshold, gsr_stream_t stream);
 
 /* replaces rasterize_backward_tensor (bindings.cu:476-528), kernel
  * backward.cu:133-303.  v_xy[n,2] v_conic[n,3] v_colors[n,3] v_opacity[n]
@@ -224,7 +231,8 @@ int gsr_rasterize_backward(unsigned img_height, unsigned img_width,
                            const float *final_Ts, const int32_t *final_idx,
                            const float *v_output, const float *v_output_alpha,
                            float *v_xy, float *v_conic, float *v_colors,
-                           float *v_opacity, gsr_stream_t stream);
+                           float *v_opacity, int deep_tile_threshold,
+                           gsr_stream_t stream);
 
 /* generic channel count; replace nd_rasterize_forward_tensor /
  * nd_rasterize_backward_tensor (bindings.cu:330-469), kernels
@@ -338,7 +346,7 @@ int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img_width,
                                const float *background, float extra_background,
                                float *out_img, float *out_extra,
                                float *final_Ts, int32_t *final_idx,
-                               gsr_stream_t stream);
+                               int deep_tile_threshold, gsr_stream_t stream);
 int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
                                 int num_points,
                                 const int32_t *gaussian_ids_sorted,
@@ -351,7 +359,8 @@ int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
                                 const float *v_output_extra,
                                 const float *v_output_alpha, float *v_xy,
                                 float *v_conic, float *v_colors, float *v_extra,
-                                float *v_opacity, gsr_stream_t stream);
+                                float *v_opacity, int deep_tile_threshold,
+                                gsr_stream_t stream);
 
 /* ---- per-Gaussian activations (caller-side glue) ----------
  * exp(scales), quats / |quats|, sigmoid(opacities) and the normalised view

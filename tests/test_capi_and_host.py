@@ -53,7 +53,7 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b"degree" in L.gsr_last_error()
     rc = L.gsr_rasterize_forward(ctypes.c_int(3), ctypes.c_int(1), ctypes.c_uint(16), ctypes.c_uint(32),
                                  ctypes.c_uint(16), None, None, None, None, None, None, None, None, None, None,
-                                 None)
+                                 ctypes.c_int(0), None)
     assert rc == -1 and b"tile bounds" in L.gsr_last_error()
     # zero-sized work is a no-op, not an error
     assert L.gsr_sh_forward(ctypes.c_uint(0), ctypes.c_uint(3), ctypes.c_uint(3), None, None, None, None) == 0

@@ -510,3 +510,54 @@ def test_count_reach_errors():
     out, _ = C.count_reach(z(0, 2, device=DEV), z(0, dtype=torch.int32, device=DEV), z(0, 3, device=DEV),
                         z(0, 1, device=DEV), (4, 4, 1))
     assert out.numel() == 0
+
+
+@pytest.mark.parametrize("rgbd", [False, True])
+def test_deep_tiles_split_over_four_waves_give_identical_results(rgbd, monkeypatch):
+    """A tile whose list is longer than the deep-tile threshold is composited by four waves,
+    one per 8x8 sub-tile (raster_common.h): forward outputs are bit-identical to the
+    one-wave-per-tile walk, gradients equal up to the order of the float atomics."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 60_000, 320, 208, 16
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=5, scale_lo=0.01, scale_hi=0.08, longtail=True)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    rng = np.random.default_rng(2)
+    colors = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    order, cum = C.depth_order(cu(depths), cu(radii), cu(tiles))
+    I = int(cum[-1].item())
+    ids, bins = C.bin_sorted(n, I, order, cum, cu(xys), cu(radii), tb, bw)
+    lens = (bins[:, 1] - bins[:, 0]).cpu().numpy()
+    assert lens.max() > 4 * np.median(lens)  # a long tail
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
+    v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
+    v_ext = torch.rand(H, W, device=DEV) * 2 - 1
+
+    def run(threshold):
+        monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles: threshold)
+        if rgbd:
+            f = C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors), cu(depths),
+                                         cu(sc["opacities"]), bg, 0.0)
+            b = C.rasterize_backward_rgbd(H, W, ids, bins, cu(xys), cu(conics), cu(colors), cu(depths),
+                                          cu(sc["opacities"]), bg, 0.0, f[2], f[3], v_img, v_ext, v_alpha)
+        else:
+            f = C.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors),
+                                    cu(sc["opacities"]), bg)
+            b = C.rasterize_backward(H, W, bw, ids, bins, cu(xys), cu(conics), cu(colors), cu(sc["opacities"]), bg,
+                                     f[1], f[2], v_img, v_alpha)
+        return f, b
+
+    f0, b0 = run(0)                                   # one wave per tile
+    thr = int(np.percentile(lens, 70))               # 30 % of the tiles split
+    f1, b1 = run(thr)
+    f2, b2 = run(1)                                   # every non-trivial tile split
+    for fa in (f1, f2):
+        for x, y in zip(f0, fa):
+            assert torch.equal(x, y)
+    for ba in (b1, b2):
+        for x, y in zip(b0, ba):
+            scale = x.abs().max().item()
+            assert (x - y).abs().max().item() <= 2e-5 * scale
