@@ -92,14 +92,20 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
   const float tz = V[8] * px + V[9] * py + V[10] * pz + V[11];
 
   if (tz > clip) {  // near-plane cull is `z <= clip` (helpers.cuh:212-219)
-    float w, x, y, z;
-    const M3 R = quat_to_rot(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2],
-                             quats[4 * i + 3], w, x, y, z);
-    const float s0 = glob_scale * scales[3 * i], s1 = glob_scale * scales[3 * i + 1],
-                s2 = glob_scale * scales[3 * i + 2];
-    const M3 M{R.a00 * s0, R.a01 * s1, R.a02 * s2, R.a10 * s0, R.a11 * s1,
-               R.a12 * s2, R.a20 * s0, R.a21 * s1, R.a22 * s2};
-    const M3 S = mul(M, transpose(M));
+    M3 S;
+    if (scales) {
+      float w, x, y, z;
+      const M3 R = quat_to_rot(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2],
+                               quats[4 * i + 3], w, x, y, z);
+      const float s0 = glob_scale * scales[3 * i], s1 = glob_scale * scales[3 * i + 1],
+                  s2 = glob_scale * scales[3 * i + 2];
+      const M3 M{R.a00 * s0, R.a01 * s1, R.a02 * s2, R.a10 * s0, R.a11 * s1,
+                 R.a12 * s2, R.a20 * s0, R.a21 * s1, R.a22 * s2};
+      S = mul(M, transpose(M));
+    } else {  // precomputed covariances: cov3d is an INPUT (upper triangle xx xy xz yy yz zz)
+      const float *c = cov3d + 6 * i;
+      S = M3{c[0], c[1], c[2], c[1], c[3], c[4], c[2], c[4], c[5]};
+    }
     o_cov[0] = S.a00;
     o_cov[1] = S.a01;
     o_cov[2] = S.a02;
@@ -149,8 +155,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     }
   }
 
+  if (scales) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) cov3d[6 * i + k] = o_cov[k];
+    for (int k = 0; k < 6; ++k) cov3d[6 * i + k] = o_cov[k];
+  }
   xys[2 * i] = o_x;
   xys[2 * i + 1] = o_y;
   depths[i] = o_depth;
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
     // cov3d = M M^T, M = R S  (backward.cu:427-453)
     const M3 vS{g3[0], 0.5f * g3[1], 0.5f * g3[2], 0.5f * g3[1], g3[3],
                 0.5f * g3[4], 0.5f * g3[2], 0.5f * g3[4], g3[5]};
+    if (scales) {  // (precomputed covariances: the chain ends at v_cov3d)
     float w, x, y, z;
     const M3 R = quat_to_rot(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2],
                              quats[4 * i + 3], w, x, y, z);
@@ -288,6 +297,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
                    z * (vR.a21 + vR.a12) + w * (vR.a02 - vR.a20));
     gq[3] = 2.f * (x * (vR.a20 + vR.a02) + y * (vR.a21 + vR.a12) -
                    2.f * z * (vR.a00 + vR.a11) + w * (vR.a10 - vR.a01));
+    }
   }
 
 #pragma unroll
@@ -296,10 +306,12 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
   for (int k = 0; k < 6; ++k) v_cov3d[6 * i + k] = g3[k];
 #pragma unroll
   for (int k = 0; k < 3; ++k) v_mean3d[3 * i + k] = gm[k];
+  if (scales) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) v_scale[3 * i + k] = gs[k];
+    for (int k = 0; k < 3; ++k) v_scale[3 * i + k] = gs[k];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = gq[k];
+    for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = gq[k];
+  }
 }
 
 __global__ __launch_bounds__(256) void cov2d_bounds_kernel(
@@ -328,9 +340,11 @@ GSR_EXPORT int gsr_project_forward(
   GSR_REQUIRE(block_width >= 2 && block_width <= 16, "project_forward: block_width must be in [2,16]");
   GSR_REQUIRE(img_height > 0 && img_width > 0, "project_forward: empty image");
   if (num_points == 0) return GSR_OK;
-  GSR_REQUIRE(means3d && scales && quats && viewmat && projmat && cov3d && xys && depths &&
+  GSR_REQUIRE(means3d && viewmat && projmat && cov3d && xys && depths &&
                   radii && conics && compensation && num_tiles_hit,
               "project_forward: null pointer");
+  GSR_REQUIRE((scales == nullptr) == (quats == nullptr),
+              "project_forward: pass both scales and quats, or neither (cov3d is then an input)");
   const int tiles_x = (int)gsr_cdiv(img_width, block_width);
   const int tiles_y = (int)gsr_cdiv(img_height, block_width);
   hipLaunchKernelGGL(project_fwd_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0,
@@ -355,10 +369,11 @@ GSR_EXPORT int gsr_project_backward(
   (void)cy;
   GSR_REQUIRE(num_points >= 0, "project_backward: num_points < 0");
   if (num_points == 0) return GSR_OK;
-  GSR_REQUIRE(means3d && scales && quats && viewmat && projmat && cov3d && radii && conics &&
-                  compensation && v_cov2d &&
-                  v_cov3d && v_mean3d && v_scale && v_quat,
+  GSR_REQUIRE(means3d && viewmat && projmat && cov3d && radii && conics && compensation && v_cov2d &&
+                  v_cov3d && v_mean3d,
               "project_backward: null pointer");
+  GSR_REQUIRE((scales == nullptr) == (quats == nullptr), "project_backward: pass both scales and quats, or neither");
+  GSR_REQUIRE(scales == nullptr || (v_scale && v_quat), "project_backward: null pointer");
   hipLaunchKernelGGL(project_bwd_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0,
                      (hipStream_t)stream, num_points, means3d, scales, glob_scale, quats,
                      viewmat, projmat, fx, fy, (int)img_width, (int)img_height, cov3d, radii,

@@ -56,23 +56,31 @@ def _cf(v) -> C.c_float:
 
 
 def project_gaussians_forward(
-    num_points: int, means3d: Tensor, scales: Tensor, glob_scale: float, quats: Tensor,
+    num_points: int, means3d: Tensor, scales: Optional[Tensor], glob_scale: float, quats: Optional[Tensor],
     viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
     img_height: int, img_width: int, block_width: int, clip_thresh: float,
+    cov3d_precomp: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     """-> (cov3d, xys, depths, radii, conics, compensation, num_tiles_hit);
-    replaces ``project_gaussians_forward_tensor`` (bindings.cu:107-160)."""
-    for t, nm in ((means3d, "means3d"), (scales, "scales"), (quats, "quats"),
-                  (viewmat, "viewmat"), (projmat, "projmat")):
+    replaces ``project_gaussians_forward_tensor`` (bindings.cu:107-160).
+    ``cov3d_precomp`` [N,6] (with ``scales`` = ``quats`` = None): covariances handed in
+    instead of being built from scales and rotations; returned as ``cov3d``."""
+    precomp = cov3d_precomp is not None
+    if precomp != (scales is None) or precomp != (quats is None):
+        raise RuntimeError("pass either scales and quats, or cov3d_precomp")
+    for t, nm in ((means3d, "means3d"), (viewmat, "viewmat"), (projmat, "projmat")) + (
+            ((cov3d_precomp, "cov3d_precomp"),) if precomp else ((scales, "scales"), (quats, "quats"))):
         _check(t, nm, _f32)
     n = int(num_points)
     if viewmat.numel() < 12 or projmat.numel() != 16:
         raise RuntimeError("viewmat must hold at least 3x4 and projmat 4x4 values")
-    if means3d.numel() != 3 * n or scales.numel() != 3 * n or quats.numel() != 4 * n:
+    if means3d.numel() != 3 * n or (not precomp and (scales.numel() != 3 * n or quats.numel() != 4 * n)) \
+            or (precomp and cov3d_precomp.numel() != 6 * n):
         raise RuntimeError("means3d/scales/quats do not match num_points")
     dev = means3d.device
+    _opt0 = lambda t: None if t is None else _ptr(t)
     with torch.cuda.device(dev):
-        cov3d = torch.empty((n, 6), dtype=_f32, device=dev)
+        cov3d = cov3d_precomp if precomp else torch.empty((n, 6), dtype=_f32, device=dev)
         xys = torch.empty((n, 2), dtype=_f32, device=dev)
         depths = torch.empty((n,), dtype=_f32, device=dev)
         radii = torch.empty((n,), dtype=_i32, device=dev)
@@ -80,8 +88,8 @@ def project_gaussians_forward(
         compensation = torch.empty((n,), dtype=_f32, device=dev)
         num_tiles_hit = torch.empty((n,), dtype=_i32, device=dev)
         _call(
-            "gsr_project_forward", C.c_int(n), _ptr(means3d), _ptr(scales), _cf(glob_scale),
-            _ptr(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
+            "gsr_project_forward", C.c_int(n), _ptr(means3d), _opt0(scales), _cf(glob_scale),
+            _opt0(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
             C.c_uint(img_height), C.c_uint(img_width), C.c_uint(block_width), _cf(clip_thresh),
             _ptr(cov3d), _ptr(xys), _ptr(depths), _ptr(radii), _ptr(conics), _ptr(compensation),
             _ptr(num_tiles_hit), _stream(dev),
@@ -99,9 +107,10 @@ def project_gaussians_backward(
     replaces ``project_gaussians_backward_tensor`` (bindings.cu:164-216)."""
     n = int(num_points)
     dev = means3d.device
-    for t, nm in ((means3d, "means3d"), (scales, "scales"), (quats, "quats"), (viewmat, "viewmat"),
+    precomp = scales is None and quats is None  # covariances were handed in: the chain ends at v_cov3d
+    for t, nm in ((means3d, "means3d"), (viewmat, "viewmat"),
                   (projmat, "projmat"), (cov3d, "cov3d"), (conics, "conics"),
-                  (compensation, "compensation")):
+                  (compensation, "compensation")) + (() if precomp else ((scales, "scales"), (quats, "quats"))):
         _check(t, nm, _f32)
     _check(radii, "radii", _i32)
     # cotangents may arrive non-contiguous / expanded from autograd; None = zero
@@ -115,14 +124,14 @@ def project_gaussians_backward(
         v_cov2d = torch.empty((n, 3), dtype=_f32, device=dev)
         v_cov3d = torch.empty((n, 6), dtype=_f32, device=dev)
         v_mean3d = torch.empty((n, 3), dtype=_f32, device=dev)
-        v_scale = torch.empty((n, 3), dtype=_f32, device=dev)
-        v_quat = torch.empty((n, 4), dtype=_f32, device=dev)
+        v_scale = None if precomp else torch.empty((n, 3), dtype=_f32, device=dev)
+        v_quat = None if precomp else torch.empty((n, 4), dtype=_f32, device=dev)
         _call(
-            "gsr_project_backward", C.c_int(n), _ptr(means3d), _ptr(scales), _cf(glob_scale),
-            _ptr(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
+            "gsr_project_backward", C.c_int(n), _ptr(means3d), _opt(scales), _cf(glob_scale),
+            _opt(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
             C.c_uint(img_height), C.c_uint(img_width), _ptr(cov3d), _ptr(radii), _ptr(conics),
             _ptr(compensation), _opt(v_xy), _opt(v_depth), _opt(v_conic), _opt(v_compensation),
-            _ptr(v_cov2d), _ptr(v_cov3d), _ptr(v_mean3d), _ptr(v_scale), _ptr(v_quat),
+            _ptr(v_cov2d), _ptr(v_cov3d), _ptr(v_mean3d), _opt(v_scale), _opt(v_quat),
             _stream(dev),
         )
     return v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat

@@ -52,7 +52,11 @@ const char *gsr_last_error(void);
  * replaces project_gaussians_forward_tensor (bindings.cu:107-160), kernel
  * forward.cu:13-90.  viewmat: >= 12 floats (top 3x4), projmat: 16 floats.
  * outputs: cov3d[n,6] xys[n,2] depths[n] radii[n](i32) conics[n,3]
- *          compensation[n] num_tiles_hit[n](i32) */
+ *          compensation[n] num_tiles_hit[n](i32)
+ * Precomputed covariances (the `cov3D_precomp` of Inria-style callers): with
+ * scales == NULL and quats == NULL, cov3d[n,6] (upper triangle xx xy xz yy yz zz,
+ * world space) is an INPUT and is not written; gsr_project_backward with the same
+ * two NULLs then stops at v_cov3d (v_scale / v_quat are not touched, may be NULL). */
 int gsr_project_forward(int num_points, const float *means3d,
                         const float *scales, float glob_scale,
                         const float *quats, const float *viewmat,

@@ -355,9 +355,74 @@ def test_inria_named_facade_matches_the_three_ops():
     with pytest.raises(Exception):
         GaussianRasterizer(settings)(pb["means3d"], means2D, pb["opacities"], scales=pb["scales"],
                                      rotations=pb["quats"])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception):  # scales/rotations AND cov3D_precomp
         GaussianRasterizer(settings)(pb["means3d"], means2D, pb["opacities"], shs=pb["sh_coeffs"],
+                                     scales=pb["scales"], rotations=pb["quats"],
                                      cov3D_precomp=torch.zeros(2500, 6, device=DEV))
+
+
+def test_inria_facade_against_the_oracle_with_precomputed_covariances_depth_and_alpha():
+    """The Inria-named surface checked against the ORACLE (not against this package's own
+    ops): colours from precomputed colours, covariances handed in as `cov3D_precomp` with
+    their own gradient, depth and alpha images from the same compositing pass."""
+    from rasterizer.inria import GaussianRasterizationSettings, GaussianRasterizer
+
+    W, H, n = 176, 112, 3000
+    cam = S.make_camera(W, H, yaw=-0.1, pitch=0.05)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=21, scale_lo=0.01, scale_hi=0.1)
+    bg = np.array(S.BACKGROUND, np.float32)
+    rng = np.random.default_rng(3)
+    colors = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    v_img = rng.uniform(-1, 1, (3, H, W)).astype(np.float32)
+    v_dep = rng.uniform(-1, 1, (1, H, W)).astype(np.float32)
+    v_alpha = rng.uniform(-1, 1, (1, H, W)).astype(np.float32)
+    # oracle: projection (gives cov3d too), lists, compositing of colours and of depths
+    r = O.render_forward(sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat, cam.fx, cam.fy,
+                         cam.cx, cam.cy, H, W, 16, colors, sc["opacities"], bg, ambig_eps=1e-5)
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    dcol = np.repeat(r["depths"][:, None], 3, 1).astype(np.float32)
+    dep_ref = O.rasterize_forward(tb, (16, 16, 1), (W, H, 1), r["gaussian_ids_sorted"], r["tile_bins"], r["xys"],
+                                  r["conics"], dcol, sc["opacities"], np.zeros(3, np.float32))[0][..., 0]
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=0.5 * W / cam.fx, tanfovy=0.5 * H / cam.fy, bg=cu(bg),
+        scale_modifier=1.0, viewmatrix=cu(cam.viewmat).t().contiguous(),
+        projmatrix=cu(cam.projmat).t().contiguous(), sh_degree=0, campos=cu(cam.campos))
+    means = cu(sc["means3d"], True)
+    cov = cu(r["cov3d"], True)
+    opac = cu(sc["opacities"], True)
+    col = cu(colors, True)
+    means2D = torch.zeros(n, 3, device=DEV, requires_grad=True)
+    img, radii, depth, alpha = GaussianRasterizer(settings)(
+        means3D=means, means2D=means2D, opacities=opac, colors_precomp=col, cov3D_precomp=cov,
+        return_depth=True, return_alpha=True)
+    assert img.shape == (3, H, W) and depth.shape == (1, H, W) and alpha.shape == (1, H, W)
+    assert np.array_equal(npy(radii), r["radii"])
+    ok = ~r["ambig"]
+    assert ok.mean() > 0.99
+    assert np.abs(npy(img).transpose(1, 2, 0) - r["out_img"])[ok].max() < 1e-4
+    assert np.abs(npy(alpha)[0] - (1 - r["final_Ts"]))[ok].max() < 1e-4
+    assert np.abs(npy(depth)[0] - dep_ref)[ok].max() < 1e-4 * max(1.0, float(r["depths"].max()))
+    torch.autograd.backward([img, depth, alpha], [cu(v_img), cu(v_dep), cu(v_alpha)])
+    # oracle backward: colour pass (with alpha cotangent) + depth pass, then the projection VJP
+    a = O.rasterize_backward(H, W, 16, r["gaussian_ids_sorted"], r["tile_bins"], r["xys"], r["conics"], colors,
+                             sc["opacities"], bg, r["final_Ts"], r["final_idx"], v_img.transpose(1, 2, 0), v_alpha[0])
+    vd3 = np.zeros((H, W, 3), np.float32)
+    vd3[..., 0] = v_dep[0]
+    dT, dI = O.rasterize_forward(tb, (16, 16, 1), (W, H, 1), r["gaussian_ids_sorted"], r["tile_bins"], r["xys"],
+                                 r["conics"], dcol, sc["opacities"], np.zeros(3, np.float32))[1:3]
+    b = O.rasterize_backward(H, W, 16, r["gaussian_ids_sorted"], r["tile_bins"], r["xys"], r["conics"], dcol,
+                             sc["opacities"], np.zeros(3, np.float32), dT, dI, vd3, np.zeros((H, W), np.float32))
+    vxy, vconic = a[0] + b[0], a[1] + b[1]
+    grad_close(npy(means2D.grad)[:, :2], vxy, name="means2D.grad")
+    grad_close(npy(col.grad), a[2], name="colors_precomp.grad")
+    grad_close(npy(opac.grad), a[3] + b[3], name="opacities.grad")
+    v_depth = b[2][:, 0]  # the depth image reads depths[:, None].repeat(1, 3): channel 0 carries the cotangent
+    _, v_cov3d, v_mean, _, _ = O.project_gaussians_backward(
+        n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat, cam.fx, cam.fy, cam.cx,
+        cam.cy, H, W, r["cov3d"], r["radii"], r["conics"], r["compensation"], vxy, v_depth, vconic,
+        np.zeros(n, np.float32))
+    grad_close(npy(means.grad), v_mean, name="means3D.grad")
+    grad_close(npy(cov.grad), v_cov3d, name="cov3D_precomp.grad")
 
 
 def test_binning_cache_tracks_opacity_and_conics():
