@@ -111,11 +111,13 @@ GSR_EXPORT int gsr_activate_backward(int num_points, const float *raw_quats, con
 namespace {
 __global__ __launch_bounds__(256) void densify_stats_kernel(const int n, const float2 *__restrict__ v_xys,
                                                             const int *__restrict__ radii, const float inv_size,
-                                                            const int first, float *__restrict__ xys_grad_norm,
+                                                            const int first_host, const int *__restrict__ first_dev,
+                                                            float *__restrict__ xys_grad_norm,
                                                             int *__restrict__ vis_counts,
                                                             float *__restrict__ max_2dsize) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int first = first_dev ? *first_dev : first_host;
   const int r = radii[i];
   float norm = 0.f;
   if (v_xys && (first || r > 0)) {
@@ -143,8 +145,22 @@ GSR_EXPORT int gsr_densify_stats(int num_points, const float *v_xys, const int32
   GSR_REQUIRE(radii && xys_grad_norm && vis_counts && max_2dsize, "densify_stats: null pointer");
   GSR_REQUIRE(v_xys == nullptr || (reinterpret_cast<uintptr_t>(v_xys) & 7u) == 0, "densify_stats: v_xys must be 8-byte aligned");
   hipLaunchKernelGGL(densify_stats_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream,
-                     num_points, reinterpret_cast<const float2 *>(v_xys), radii, inv_size, first, xys_grad_norm,
-                     vis_counts, max_2dsize);
+                     num_points, reinterpret_cast<const float2 *>(v_xys), radii, inv_size, first, (const int *)nullptr,
+                     xys_grad_norm, vis_counts, max_2dsize);
   GSR_CHECK_LAUNCH("densify_stats");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_densify_stats_dev(int num_points, const float *v_xys, const int32_t *radii, float inv_size,
+                                     const int32_t *first, float *xys_grad_norm, int32_t *vis_counts,
+                                     float *max_2dsize, gsr_stream_t stream) {
+  GSR_REQUIRE(num_points >= 0, "densify_stats_dev: num_points < 0");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(radii && first && xys_grad_norm && vis_counts && max_2dsize, "densify_stats_dev: null pointer");
+  GSR_REQUIRE(v_xys == nullptr || (reinterpret_cast<uintptr_t>(v_xys) & 7u) == 0, "densify_stats_dev: v_xys must be 8-byte aligned");
+  hipLaunchKernelGGL(densify_stats_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream,
+                     num_points, reinterpret_cast<const float2 *>(v_xys), radii, inv_size, 0, first, xys_grad_norm,
+                     vis_counts, max_2dsize);
+  GSR_CHECK_LAUNCH("densify_stats_dev");
   return GSR_OK;
 }

@@ -40,6 +40,13 @@ void gsr_set_error(const char *fmt, ...);
 
 static inline unsigned gsr_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }
 
+// Zero `bytes` bytes (a multiple of 4) at a 4-byte aligned device address with a KERNEL
+// rather than hipMemsetAsync: a kernel node is captured into a HIP graph like every other
+// launch of this library (gs_fused.ViewGraph replays whole views), whereas memset nodes
+// recorded during stream capture were observed to leave the gradient accumulators
+// un-zeroed on replay (ROCm 7.2: garbage gradients depending on the pool layout).
+int gsr_zero_async(void *ptr, size_t bytes, hipStream_t s);
+
 // ---- device helpers --------------------------------------------------------
 #define GSR_WAVE 64
 

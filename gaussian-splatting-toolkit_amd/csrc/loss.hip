@@ -253,7 +253,7 @@ GSR_EXPORT int gsr_l1_ssim_forward(unsigned img_height, unsigned img_width, floa
   GSR_REQUIRE(img_height > kHalo && img_width > kHalo, "l1_ssim_forward: image must be larger than 10x10");
   GSR_REQUIRE(pred && gt && maps && sums && loss_out, "l1_ssim_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, GSR_LOSS_WORKSPACE_DOUBLES * sizeof(double), s));
+  if (int zrc = gsr_zero_async(sums, GSR_LOSS_WORKSPACE_DOUBLES * sizeof(double), s)) return zrc;
   const dim3 grd(gsr_cdiv(img_width, kTW), gsr_cdiv(img_height, kTH), 3);
   hipLaunchKernelGGL(l1_ssim_fwd_kernel, grd, dim3(256), 0, s, (int)img_height, (int)img_width, ssim_lambda,
                      clamp_pred, pred, gt, maps, sums);
@@ -342,7 +342,7 @@ GSR_EXPORT int gsr_depth_l1_forward(long long num_pixels, const float *depth, co
   GSR_REQUIRE(num_pixels > 0, "depth_l1_forward: empty image");
   GSR_REQUIRE(depth && alpha && gt && depth_max && sums && loss_out, "depth_l1_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  GSR_CHECK_HIP(hipMemsetAsync(sums, 0, GSR_LOSS_SUM_SLOTS * sizeof(double), s));
+  if (int zrc = gsr_zero_async(sums, GSR_LOSS_SUM_SLOTS * sizeof(double), s)) return zrc;
   const unsigned blocks = (unsigned)std::min<long long>((num_pixels + 1023) / 1024, 4096);
   hipLaunchKernelGGL(depth_l1_fwd_kernel, dim3(blocks), dim3(256), 0, s, num_pixels, depth, alpha, gt, depth_max,
                      sums);

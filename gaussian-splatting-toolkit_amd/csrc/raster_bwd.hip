@@ -523,13 +523,13 @@ int zero_grads(int n, unsigned channels, float *v_xy, float *v_conic, float *v_c
   // Python binding lays them out back to back), four otherwise
   if (v_conic == v_xy + 2 * (size_t)n && v_colors == v_conic + 3 * (size_t)n &&
       v_opacity == v_colors + (size_t)channels * n) {
-    GSR_CHECK_HIP(hipMemsetAsync(v_xy, 0, sizeof(float) * (6 + channels) * (size_t)n, s));
+    if (int zrc = gsr_zero_async(v_xy, sizeof(float) * (6 + channels) * (size_t)n, s)) return zrc;
     return GSR_OK;
   }
-  GSR_CHECK_HIP(hipMemsetAsync(v_xy, 0, sizeof(float) * 2 * (size_t)n, s));
-  GSR_CHECK_HIP(hipMemsetAsync(v_conic, 0, sizeof(float) * 3 * (size_t)n, s));
-  GSR_CHECK_HIP(hipMemsetAsync(v_colors, 0, sizeof(float) * channels * (size_t)n, s));
-  GSR_CHECK_HIP(hipMemsetAsync(v_opacity, 0, sizeof(float) * (size_t)n, s));
+  if (int zrc = gsr_zero_async(v_xy, sizeof(float) * 2 * (size_t)n, s)) return zrc;
+  if (int zrc = gsr_zero_async(v_conic, sizeof(float) * 3 * (size_t)n, s)) return zrc;
+  if (int zrc = gsr_zero_async(v_colors, sizeof(float) * channels * (size_t)n, s)) return zrc;
+  if (int zrc = gsr_zero_async(v_opacity, sizeof(float) * (size_t)n, s)) return zrc;
   return GSR_OK;
 }
 
@@ -621,7 +621,7 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
   hipStream_t s = (hipStream_t)stream;
   int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
   if (rc != GSR_OK) return rc;
-  GSR_CHECK_HIP(hipMemsetAsync(v_extra, 0, sizeof(float) * (size_t)num_points, s));
+  if (int zrc = gsr_zero_async(v_extra, sizeof(float) * (size_t)num_points, s)) return zrc;
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);

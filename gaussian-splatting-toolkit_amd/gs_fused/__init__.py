@@ -8,3 +8,4 @@ from .sh import spherical_harmonics_split  # noqa: F401
 from .activations import activate_gaussians, densify_stats_  # noqa: F401
 from .rgbd import rasterize_gaussians_rgbd  # noqa: F401
 from .refine import RefineConfig, adam_moments, refine_gaussians, refinement_branch, swap_parameters  # noqa: F401
+from .render import DensifyStats, ListCapacity, ViewSpec, render_gaussians  # noqa: F401

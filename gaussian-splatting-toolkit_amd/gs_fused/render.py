@@ -1,0 +1,314 @@
+"""One render op: what ``GaussianSplattingModel.get_outputs`` does between the raw
+parameters and the images, as a single autograd node.
+
+The toolkit's models (gs_toolkit/models/vanilla_gs.py:765-857, depth_gs.py:225-363) run,
+per view: exp / normalise / sigmoid, the view directions, ``torch.cat`` of the SH
+features, ``project_gaussians``, ``spherical_harmonics``, ``clamp(+0.5)``,
+``rasterize_gaussians`` (and a second one for depth) -- ~25 torch ops and four custom
+autograd nodes, each with its own saved-tensor bookkeeping.  ``render_gaussians`` chains
+the same native calls (include/gsraster.h) inside ONE ``torch.autograd.Function``:
+
+  forward : gsr_activate_forward -> gsr_project_forward -> gsr_sh_forward_split (+0.5,
+            clamp) -> count_reach / depth_order / bin_sorted_dev -> gsr_rasterize_forward
+            (or _rgbd: RGB + depth from one compositing pass)
+  backward: gsr_rasterize_backward(_rgbd) -> gsr_sh_backward_split -> gsr_project_backward
+            -> gsr_activate_backward, and the densification statistics of ``after_train``
+            (vanilla_gs.py:344-372) straight from the screen-space gradient.
+
+Nothing in it reads device memory back: the tile lists are sized by ``capacity`` (the
+caller's job: `ListCapacity` below keeps a running estimate and checks the real count one
+view later), which makes the whole view -- forward, loss, backward -- capturable in a HIP
+graph (`ViewGraph`).  Same values as the separate ops (tests/test_gpu_render.py): images
+bit-identical, gradients equal up to the order of the float atomics.
+fp32 CUDA tensors; 16x16 tiles; SH degree 1-3 storage (K = 4, 9, 16).
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+import rasterizer.cuda as _C
+from rasterizer.cuda import _call, _ptr, _stream
+
+_f32, _i32 = torch.float32, torch.int32
+BLOCK = 16
+
+
+@dataclass(frozen=True)
+class ViewSpec:
+    """The per-view scalars (baked into a captured graph: one graph per distinct spec)."""
+    height: int
+    width: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    sh_degree_to_use: int
+    render_depth: bool = False
+    clip_thresh: float = 0.01
+    glob_scale: float = 1.0
+
+    @property
+    def tile_bounds(self):
+        return ((self.width + BLOCK - 1) // BLOCK, (self.height + BLOCK - 1) // BLOCK, 1)
+
+
+class DensifyStats:
+    """``xys_grad_norm`` / ``vis_counts`` / ``max_2dsize`` of after_train (vanilla_gs.py:344-372),
+    updated by the backward of `render_gaussians` itself (one launch, no retain_grad)."""
+
+    def __init__(self, n: int, device, max_dim: int):
+        self.xys_grad_norm = torch.zeros(n, device=device)
+        self.vis_counts = torch.zeros(n, device=device, dtype=_i32)
+        self.max_2dsize = torch.zeros(n, device=device)
+        self.max_dim = int(max_dim)
+        # 1 = the next update is the first after a refinement (vanilla_gs.py:354-356); kept on the
+        # DEVICE so that a captured graph replays correctly across refinement boundaries
+        self.first = torch.ones(1, device=device, dtype=_i32)
+        self.enabled = True
+
+    def as_tuple(self):
+        return self.xys_grad_norm, self.vis_counts, self.max_2dsize
+
+    def restart(self):
+        self.first.fill_(1)
+
+
+class _Render(Function):
+    @staticmethod
+    def forward(ctx, means, log_scales, raw_quats, logits, features_dc, features_rest, viewmat, projmat, campos,
+                background, spec: ViewSpec, capacity: int, count_out: Tensor, stats: Optional[DensifyStats]):
+        n = means.shape[0]
+        dev = means.device
+        H, W = spec.height, spec.width
+        tb = spec.tile_bounds
+        degree = {4: 1, 9: 2, 16: 3}[features_rest.shape[1] + 1]
+        with torch.cuda.device(dev):
+            scales = torch.empty_like(log_scales)
+            quats = torch.empty_like(raw_quats)
+            opac = torch.empty_like(logits)
+            dirs = torch.empty((n, 3), dtype=_f32, device=dev)
+            _call("gsr_activate_forward", C.c_int(n), _ptr(means), _ptr(log_scales), _ptr(raw_quats), _ptr(logits),
+                  _ptr(campos), _ptr(scales), _ptr(quats), _ptr(opac), _ptr(dirs), _stream(dev))
+            cov3d, xys, depths, radii, conics, comp, tiles = _C.project_gaussians_forward(
+                n, means, scales, spec.glob_scale, quats, viewmat, projmat, spec.fx, spec.fy, spec.cx, spec.cy, H, W,
+                BLOCK, spec.clip_thresh)
+            colors = torch.empty((n, 3), dtype=_f32, device=dev)
+            _call("gsr_sh_forward_split", C.c_uint(n), C.c_uint(degree), C.c_uint(spec.sh_degree_to_use), _ptr(dirs),
+                  _ptr(features_dc), _ptr(features_rest), _ptr(colors), C.c_float(0.5), C.c_int(1), _stream(dev))
+            counts, recs = _C.count_reach(xys, radii, conics, opac, tb)
+            order, cum = _C.depth_order(depths, radii, counts)
+            ids, bins = _C.bin_sorted(n, capacity, order, cum, xys, radii, tb, BLOCK, recs, device_sized=True,
+                                      count_out=count_out)
+            if spec.render_depth:
+                img, dep, Ts, idx = _C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, xys, conics, colors, depths,
+                                                              opac, background, 0.0)
+            else:
+                img, Ts, idx = _C.rasterize_forward(tb, (BLOCK, BLOCK, 1), (W, H, 1), ids, bins, xys, conics, colors,
+                                                    opac, background)
+                dep = None
+        ctx.spec, ctx.stats, ctx.degree = spec, stats, degree
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(means, raw_quats, features_dc, features_rest, viewmat, projmat, background, scales, quats,
+                              opac, dirs, cov3d, xys, depths, radii, conics, comp, colors, ids, bins, Ts, idx)
+        ctx.mark_non_differentiable(radii)
+        alpha = 1 - Ts
+        if dep is None:
+            return img, alpha, radii
+        return img, alpha, radii, dep
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha, _v_radii, v_dep=None):
+        (means, raw_quats, features_dc, features_rest, viewmat, projmat, background, scales, quats, opac, dirs, cov3d,
+         xys, depths, radii, conics, comp, colors, ids, bins, Ts, idx) = ctx.saved_tensors
+        spec, stats = ctx.spec, ctx.stats
+        n = means.shape[0]
+        dev = means.device
+        H, W = spec.height, spec.width
+        with torch.cuda.device(dev):
+            if v_img is None:
+                v_img = torch.zeros(H, W, 3, device=dev)
+            v_a = None if v_alpha is None else v_alpha.contiguous()
+            if spec.render_depth:
+                if v_dep is None:
+                    v_dep = torch.zeros(H, W, device=dev)
+                v_xy, v_conic, v_colors, v_depths, v_opac = _C.rasterize_backward_rgbd(
+                    H, W, ids, bins, xys, conics, colors, depths, opac, background, 0.0, Ts, idx, v_img, v_dep, v_a)
+            else:
+                v_xy, v_conic, v_colors, v_opac = _C.rasterize_backward(
+                    H, W, BLOCK, ids, bins, xys, conics, colors, opac, background, Ts, idx, v_img, v_a)
+                v_depths = None
+            if stats is not None and stats.enabled:
+                _call("gsr_densify_stats_dev", C.c_int(n), _ptr(v_xy), _ptr(radii), C.c_float(1.0 / stats.max_dim),
+                      _ptr(stats.first), _ptr(stats.xys_grad_norm), _ptr(stats.vis_counts), _ptr(stats.max_2dsize),
+                      _stream(dev))
+                stats.first.zero_()
+            v_dc = torch.empty_like(features_dc)
+            v_rest = torch.empty_like(features_rest)
+            _call("gsr_sh_backward_split", C.c_uint(n), C.c_uint(ctx.degree), C.c_uint(spec.sh_degree_to_use),
+                  _ptr(dirs), _ptr(v_colors), _ptr(colors), _ptr(v_dc), _ptr(v_rest), _stream(dev))
+            _, _, v_means, v_scales, v_quats = _C.project_gaussians_backward(
+                n, means, scales, spec.glob_scale, quats, viewmat, projmat, spec.fx, spec.fy, spec.cx, spec.cy, H, W,
+                cov3d, radii, conics, comp, v_xy, v_depths, v_conic, None)
+            g_s = torch.empty_like(scales)
+            g_q = torch.empty_like(quats)
+            g_o = torch.empty_like(opac)
+            _call("gsr_activate_backward", C.c_int(n), _ptr(raw_quats), _ptr(scales), _ptr(quats), _ptr(opac),
+                  _ptr(v_scales), _ptr(v_quats), _ptr(v_opac.view_as(opac)), _ptr(g_s), _ptr(g_q), _ptr(g_o),
+                  _stream(dev))
+        return (v_means, g_s, g_q, g_o, v_dc, v_rest) + (None,) * 8
+
+
+def render_gaussians(means: Tensor, log_scales: Tensor, raw_quats: Tensor, opacity_logits: Tensor,
+                     features_dc: Tensor, features_rest: Tensor, viewmat: Tensor, projmat: Tensor, campos: Tensor,
+                     background: Tensor, spec: ViewSpec, capacity: int, count_out: Optional[Tensor] = None,
+                     stats: Optional[DensifyStats] = None) -> Dict[str, Optional[Tensor]]:
+    """The raw parameters of a Gaussian model -> ``{"rgb" [H,W,3] (not clamped at 1), "alpha"
+    [H,W], "depth" [H,W] or None (accumulated, not divided by alpha), "radii" [N] i32,
+    "count" int32[1]}``.
+
+    viewmat: the top 3x4 (or 4x4) world->camera matrix, projmat 4x4 ``P @ V``, campos [3],
+    all on the device.  ``capacity``: entries the tile lists are sized for; ``count`` receives
+    the entries the view really needs -- if it exceeds the capacity the lists were cut and
+    the result is incomplete: render again with a larger capacity (`ListCapacity`).
+    ``count_out`` may be a caller-owned int32[1] (device, or pinned host memory)."""
+    n = means.shape[0]
+    if features_dc.shape != (n, 3) or features_rest.dim() != 3 or features_rest.shape[1] + 1 not in (4, 9, 16):
+        raise ValueError("features_dc [N,3] and features_rest [N,K-1,3] with K in (4, 9, 16) expected")
+    if log_scales.shape != (n, 3) or raw_quats.shape != (n, 4) or opacity_logits.numel() != n:
+        raise ValueError("expected scales [N,3], quats [N,4], opacities [N,1]")
+    if capacity < 1:
+        raise ValueError("capacity must be positive")
+    if count_out is None:
+        count_out = torch.empty(1, dtype=_i32, device=means.device)
+    vm = viewmat[:3, :] if viewmat.shape[0] == 4 else viewmat
+    out = _Render.apply(means.contiguous(), log_scales.contiguous(), raw_quats.contiguous(),
+                        opacity_logits.contiguous(), features_dc.contiguous(), features_rest.contiguous(),
+                        vm.contiguous(), projmat.contiguous(), campos.contiguous(), background.contiguous(), spec,
+                        int(capacity), count_out, stats)
+    return {"rgb": out[0], "alpha": out[1], "radii": out[2], "depth": out[3] if spec.render_depth else None,
+            "count": count_out}
+
+
+@dataclass
+class ListCapacity:
+    """Keeps the tile lists large enough without waiting for the GPU: ``capacity`` for the
+    next view, and a check of a PREVIOUS view's real count (read from pinned memory
+    once its event has fired).  ``grow`` is the head-room over the largest count seen."""
+    capacity: int = 1 << 20
+    grow: float = 1.5
+    _pending: list = field(default_factory=list)
+
+    def slot(self, device) -> Tensor:
+        """A pinned int32[1] for `render_gaussians(count_out=...)`; call `submitted()` after
+        the render has been enqueued."""
+        return torch.zeros(1, dtype=_i32).pin_memory()
+
+    def submitted(self, slot: Tensor, capacity_used: int, device) -> None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self._pending.append((ev, slot, capacity_used))
+
+    def overflowed(self, wait: bool = False) -> bool:
+        """Did any finished view need more entries than it was given?  Grows `capacity`."""
+        bad = False
+        keep = []
+        for ev, slot, cap in self._pending:
+            if wait:
+                ev.synchronize()
+            if not ev.query():
+                keep.append((ev, slot, cap))
+                continue
+            need = int(slot[0])
+            if need > cap:
+                bad = True
+            want = int(self.grow * need) + 65536
+            if want > self.capacity:
+                self.capacity = (want + (1 << 20) - 1) & ~((1 << 20) - 1)
+        self._pending = keep
+        return bad
+
+
+class ViewGraph:
+    """One HIP graph per view: render -> loss -> backward of a Gaussian model captured once
+    (``torch.cuda.CUDAGraph`` = hipGraph on ROCm) and replayed for every view with the same
+    `ViewSpec`, number of Gaussians and list capacity.  What varies per view -- the camera
+    matrices and position, the target image(s) -- is copied into static buffers before
+    the replay; the parameter gradients land in static ``.grad`` tensors that the optimizer
+    then reads as usual.  The graph holds ~45 kernel nodes that are otherwise ~45 launches
+    from Python through ctypes / autograd.
+
+    ``loss_fn(out, targets) -> scalar`` with ``out`` the dict of `render_gaussians` and
+    ``targets`` the tuple of static target tensors.  After a replay, ``count_host[0]`` (pinned)
+    holds the list entries the view needed: `fits()` tells whether they fitted the capacity
+    the graph was captured with -- if not, the result of that view is incomplete and the
+    owner re-captures with a larger capacity (`ListCapacity`)."""
+
+    def __init__(self, params: Dict[str, Tensor], spec: ViewSpec, capacity: int, loss_fn, background: Tensor,
+                 target_shapes, stats: Optional[DensifyStats] = None):
+        self.params, self.spec, self.capacity, self.loss_fn, self.stats = params, spec, int(capacity), loss_fn, stats
+        dev = params["means"].device
+        self.device = dev
+        self.background = background
+        self.viewmat = torch.zeros(3, 4, device=dev)
+        self.projmat = torch.zeros(4, 4, device=dev)
+        self.campos = torch.zeros(3, device=dev)
+        self.targets = tuple(torch.zeros(s, device=dev) for s in target_shapes)
+        self.count_dev = torch.zeros(1, dtype=_i32, device=dev)
+        self.count_host = torch.zeros(1, dtype=_i32).pin_memory()
+        self.graph = None
+        self.out = None
+        self.loss = None
+
+    def _set_inputs(self, viewmat, projmat, campos, targets):
+        self.viewmat.copy_(viewmat[:3, :])
+        self.projmat.copy_(projmat)
+        self.campos.copy_(campos)
+        for dst, src in zip(self.targets, targets):
+            dst.copy_(src)
+
+    def _step(self):
+        p = self.params
+        out = render_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"],
+                               p["features_rest"], self.viewmat, self.projmat, self.campos, self.background, self.spec,
+                               self.capacity, count_out=self.count_dev, stats=self.stats)
+        loss = self.loss_fn(out, self.targets)
+        loss.backward()
+        _C.publish_int32(self.count_dev, self.count_host)
+        return out, loss
+
+    def capture(self, viewmat, projmat, campos, targets) -> None:
+        """Warm up eagerly on a side stream (allocator, lazy initialisation), then capture."""
+        self._set_inputs(viewmat, projmat, campos, targets)
+        first_flag = None if self.stats is None else self.stats.first.clone()
+        saved = None if self.stats is None else [t.clone() for t in self.stats.as_tuple()]
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                for t in self.params.values():
+                    t.grad = None
+                self._step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        for t in self.params.values():
+            t.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out, self.loss = self._step()
+        if self.stats is not None:  # the warm-up and the capture must not count as views
+            self.stats.first.copy_(first_flag)
+            for dst, src in zip(self.stats.as_tuple(), saved):
+                dst.copy_(src)
+
+    def replay(self, viewmat, projmat, campos, targets):
+        """-> (loss, out): static tensors, overwritten by the next replay."""
+        self._set_inputs(viewmat, projmat, campos, targets)
+        self.graph.replay()
+        return self.loss, self.out
+
+    def fits(self) -> bool:
+        """After a synchronisation point: did the last replayed view fit the capacity?"""
+        return int(self.count_host[0]) <= self.capacity

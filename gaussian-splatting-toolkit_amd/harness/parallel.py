@@ -168,6 +168,14 @@ class GradientExchange:
         self._bytes += buf.numel() * buf.element_size()
         self.pending.append((work, buf, g, rows if stage is not None else None, op))
 
+    def start_all(self) -> None:
+        """Start the collectives for every parameter now (gradients written by a replayed HIP
+        graph: no autograd hooks fire)."""
+        if self.enabled:
+            for name, p in self.named.items():
+                if p.grad is not None:
+                    self._start(name, p)
+
     def finish(self) -> int:
         """Wait for the collectives started during this backward; parameters that received
         no gradient on this rank are exchanged as zeros.  Returns the bytes exchanged."""

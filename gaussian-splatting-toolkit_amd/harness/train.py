@@ -197,6 +197,11 @@ class TrainConfig:
     init_gaussians: Optional[int] = None  # the model starts from this many (coarser) Gaussians; default: all
     refine: Optional[object] = None       # gs_fused.RefineConfig; default: the reference's values
     refine_seed: int = 20240807           # broadcast by construction: the same on every rank
+    # gs_fused.render_gaussians: the whole view as ONE autograd node (activations, projection, SH,
+    # binning, compositing; densification statistics from its backward) instead of the op-by-op
+    # call sequence of the models; use_graph: render -> loss -> backward replayed as one HIP graph
+    fused_render: bool = False
+    use_graph: bool = False
     # checkpoints in the toolkit's layout (harness/checkpoint.py; trainer.py:404-476)
     checkpoint_dir: Optional[str] = None
     save_every: int = 0                   # steps_per_save; 0 = never
@@ -298,18 +303,75 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
+    use_fused = (cfg.fused_render or cfg.use_graph) and device.type == "cuda" and cfg.split_sh and cfg.fused_loss \
+        and cfg.sh_degree in (1, 2, 3)
+    fstats = caps = vgraph = vkey = None
+    overflow_views = 0
+    if use_fused:
+        from gs_fused import DensifyStats, ListCapacity, ViewSpec, render_gaussians
+        from gs_fused.render import ViewGraph
+
+        fstats = DensifyStats(model.num_points, device, max_dim)
+        caps = ListCapacity()
+        graph_loss = lambda out, targets: loss_fn(out["rgb"], targets[0])
+        with torch.no_grad():  # size the lists once, synchronously (vanilla: every view, utils.py:124)
+            while True:
+                g_ = model.gauss
+                probe = render_gaussians(g_["means"], g_["scales"], g_["quats"], g_["opacities"], g_["features_dc"],
+                                         g_["features_rest"], cams[0].viewmat, cams[0].projmat, cams[0].campos, bg,
+                                         ViewSpec(cfg.height, cfg.width, cams[0].fx, cams[0].fy, cams[0].cx,
+                                                  cams[0].cy, cfg.sh_degree), caps.capacity)
+                need = int(probe["count"].item())
+                if need <= caps.capacity:
+                    caps.capacity = max(caps.capacity, ((int(1.5 * need) + 65536 + (1 << 20) - 1) >> 20) << 20)
+                    break
+                caps.capacity = ((int(1.5 * need) + (1 << 20)) >> 20) << 20
     for step in range(start_step, cfg.iters):
         v = view_for_rank(step, rank, world, cfg.num_views)
-        for o in optims.values():
-            o.zero_grad(set_to_none=True)
         deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
         exchange.active_rows["features_rest"] = (deg + 1) ** 2 - 1
-        out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp)
-        rgb = out["rgb"]
-        loss = loss_fn(rgb, gt[v])
-        loss.backward()
+        if use_fused:
+            cam = cams[v]
+            spec = ViewSpec(cfg.height, cfg.width, cam.fx, cam.fy, cam.cx, cam.cy, deg)
+            fstats.enabled = not (cfg.densify and step >= rcfg.stop_split_at)
+            g_ = model.gauss
+            if cfg.use_graph:
+                key = (spec, model.num_points, caps.capacity, fstats.enabled)
+                if vkey != key:  # new SH degree, N changed by refinement, or larger lists: capture again
+                    vgraph = ViewGraph({k: g_[k] for k in PARAM_NAMES}, spec, caps.capacity, graph_loss, bg,
+                                       [(cfg.height, cfg.width, 3)], stats=fstats)
+                    vgraph.capture(cam.viewmat, cam.projmat, cam.campos, (gt[v],))
+                    vkey = key
+                else:
+                    # the count of the previous replay is in pinned memory by now
+                    if not vgraph.fits():
+                        overflow_views += 1
+                        caps.capacity = ((int(1.5 * int(vgraph.count_host[0])) + (1 << 20)) >> 20) << 20
+                loss, out = vgraph.replay(cam.viewmat, cam.projmat, cam.campos, (gt[v],))
+                if world > 1:
+                    exchange.start_all()
+            else:
+                for o in optims.values():
+                    o.zero_grad(set_to_none=True)
+                slot = caps.slot(device)
+                used = caps.capacity
+                out = render_gaussians(g_["means"], g_["scales"], g_["quats"], g_["opacities"], g_["features_dc"],
+                                       g_["features_rest"], cam.viewmat, cam.projmat, cam.campos, bg, spec, used,
+                                       count_out=slot, stats=fstats)
+                loss = loss_fn(out["rgb"], gt[v])
+                loss.backward()
+                caps.submitted(slot, used, device)
+                if caps.overflowed():
+                    overflow_views += 1
+        else:
+            for o in optims.values():
+                o.zero_grad(set_to_none=True)
+            out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp)
+            rgb = out["rgb"]
+            loss = loss_fn(rgb, gt[v])
+            loss.backward()
         # densification statistics (vanilla_gs.py:344-372; not updated past stop_split_at, :347)
-        if cfg.densify and step >= rcfg.stop_split_at:
+        if use_fused or (cfg.densify and step >= rcfg.stop_split_at):
             pass
         elif fused_stats:
             densify_stats_(out["xys"].grad, out["radii"], max_dim, xys_grad_norm, vis_counts, max_2dsize,
@@ -339,6 +401,8 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         if cfg.densify and step % rcfg.refine_every == 0 and step > rcfg.warmup_length:
             branch, reset = _refinement_branch(rcfg, step, cfg.num_views)
             if branch != "none" or reset:
+                if use_fused:
+                    xys_grad_norm, vis_counts, max_2dsize = fstats.as_tuple()
                 if world > 1 and branch == "densify":
                     allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize)
                 old = {k: model.gauss[k] for k in PARAM_NAMES}
@@ -357,10 +421,14 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                         xys_grad_norm = torch.empty(n, device=device)
                         vis_counts = torch.empty(n, device=device, dtype=torch.int32)
                         max_2dsize = torch.empty(n, device=device)
+                        if use_fused:
+                            fstats = DensifyStats(n, device, max_dim)
                     history.append((step, model.num_points))
                     exchange.rebind({k: model.gauss[k] for k in PARAM_NAMES})
             # the statistics restart after every refinement_after past the warm-up (:491-493)
             stats_first = True
+            if use_fused:
+                fstats.restart()
         if cfg.save_every and cfg.checkpoint_dir and step > 0 and step % cfg.save_every == 0 and rank == 0:
             from .checkpoint import save_checkpoint
 
@@ -381,7 +449,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             "views_per_s": world * (cfg.iters - start_step) / elapsed, "num_gaussians_start": n0,
             "num_gaussians_end": model.num_points, "refinements": history,
             # (step, bytes) whenever the per-step exchange volume changed: SH warm-up, refinement
-            "allreduce_bytes": exchanged_bytes}
+            "allreduce_bytes": exchanged_bytes,
+            "render": ("hip graph per view" if cfg.use_graph else "one fused op") if use_fused else "separate ops",
+            "list_overflow_views": overflow_views}
 
 
 # the refinement backend (module-level so that CPU tests can substitute stand-ins)

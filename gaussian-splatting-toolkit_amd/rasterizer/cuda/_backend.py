@@ -53,6 +53,7 @@ SYMBOLS = (
     "gsr_activate_forward",
     "gsr_activate_backward",
     "gsr_densify_stats",
+    "gsr_densify_stats_dev",
     "gsr_refine_workspace_bytes",
     "gsr_refine_plan",
     "gsr_refine_apply",

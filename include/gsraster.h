@@ -399,6 +399,13 @@ int gsr_densify_stats(int num_points, const float *v_xys, const int32_t *radii,
                       float inv_size, int first, float *xys_grad_norm,
                       int32_t *vis_counts, float *max_2dsize,
                       gsr_stream_t stream);
+/* the same with `first` read from device memory (one int32): the call can then sit in
+ * a captured HIP graph that is replayed across refinement boundaries */
+int gsr_densify_stats_dev(int num_points, const float *v_xys,
+                          const int32_t *radii, float inv_size,
+                          const int32_t *first, float *xys_grad_norm,
+                          int32_t *vis_counts, float *max_2dsize,
+                          gsr_stream_t stream);
 
 /* ---- refinement: densify / split / duplicate / cull --------
  * GaussianSplattingModel.refinement_after (gs_toolkit/models/vanilla_gs.py:381-497)

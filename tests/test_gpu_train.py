@@ -80,3 +80,26 @@ def test_resume_from_checkpoint_after_densification(tmp_path):
     # first run ended with (same parameters, the forward is deterministic)
     assert abs(second["psnr_start"] - first["psnr_end"]) < 1e-3, (first, second)
     assert second["psnr_end"] > second["psnr_start"] - 0.5 and np.isfinite(second["param_checksum"])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_training_through_the_fused_render_op_and_hip_graph(graph):
+    """The same training run through gs_fused.render_gaussians (one autograd node per view) and
+    through one HIP graph per view (render -> loss -> backward replayed): refinement still acts
+    (re-capture when N or the SH degree changes) and the run learns like the op-by-op one."""
+    from gs_fused import RefineConfig
+    from harness.train import TrainConfig, train
+
+    rcfg = RefineConfig(warmup_length=40, refine_every=20, reset_alpha_every=6, stop_screen_size_at=200,
+                        stop_split_at=260)
+    kw = dict(num_gaussians=20_000, init_gaussians=4_000, width=320, height=180, num_views=8, iters=200, sh_degree=3,
+              sh_degree_interval=60, densify=True, refine=rcfg)
+    ref = train(TrainConfig(**kw), torch.device("cuda", 0))
+    res = train(TrainConfig(fused_render=True, use_graph=graph, **kw), torch.device("cuda", 0))
+    assert res["render"] == ("hip graph per view" if graph else "one fused op")
+    assert res["list_overflow_views"] == 0
+    assert [s for s, _ in res["refinements"]] == [s for s, _ in ref["refinements"]]
+    for (_, n1), (_, n2) in zip(ref["refinements"], res["refinements"]):
+        assert abs(n1 - n2) <= 0.02 * n1, (ref["refinements"], res["refinements"])
+    assert abs(res["psnr_end"] - ref["psnr_end"]) < 0.5, (ref["psnr_end"], res["psnr_end"])
+    assert res["psnr_end"] > res["psnr_start"] + 2.0

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--sh-interval", type=int, default=None, help="SH degree warm-up interval (reference: 1000)")
     ap.add_argument("--grad-thresh", type=float, default=None, help="densify_grad_thresh (reference: 0.0002)")
     ap.add_argument("--log-every", type=int, default=0)
+    ap.add_argument("--fused-render", action="store_true", help="gs_fused.render_gaussians: one autograd node per view")
+    ap.add_argument("--graph", action="store_true", help="render -> loss -> backward replayed as one HIP graph per view")
     ap.add_argument("--scene", default="ball", choices=["ball", "shell"])
     ap.add_argument("--scene-scale", type=float, nargs=2, default=[0.01, 0.06])
     ap.add_argument("--torch-activations", action="store_true", help="A/B: torch ops for exp/normalise/sigmoid/viewdirs")
@@ -66,6 +68,7 @@ def main():
                       torch_fused_adam=args.torch_fused_adam, split_sh=not args.cat_sh,
                       fused_activations=not args.torch_activations, densify=args.densify,
                       init_gaussians=args.init_gaussians, refine=rcfg, log_every=args.log_every,
+                      fused_render=args.fused_render, use_graph=args.graph,
                       scene=args.scene, scene_scale=tuple(args.scene_scale))
     res = train(cfg, dev, rank, world)
     if world > 1:
