@@ -50,6 +50,7 @@ KERNELS = (
     ("rasterize_forward_rgbd", "raster_fwd"),
     ("rasterize_backward", "raster_bwd"),
     ("rasterize_backward_rgbd", "raster_bwd"),
+    ("rasterize_backward_det", "raster_bwd"),
     ("compute_sh_backward", "sh_bwd"),
     ("project_gaussians_backward", "project_bwd"),
 )
@@ -221,6 +222,9 @@ def main():
     ap.add_argument("--sh-degree-to-use", type=int, default=None,
                     help="evaluate only the first bands (the models' SH warm-up, vanilla_gs.py:811-820); the "
                          "gradient exchange then leaves the inactive bands out")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="compositing backward with a fixed summation order (gsr_rasterize_backward_det) instead of "
+                         "float atomics")
     ap.add_argument("--scene", default="uniform", choices=["uniform", "longtail"],
                     help="longtail: 10 %% of the tiles hold ~10x the list depth (clustered Gaussians)")
     args = ap.parse_args()
@@ -262,6 +266,10 @@ def main():
     from harness.pipeline import CameraTensors, render_view
 
     timers = KernelTimers()
+    if args.deterministic:
+        from rasterizer import rasterize as _Rd
+
+        _Rd.set_deterministic(True)
 
     # ---- workload: SURVEY.md 8(d), seed 42; one scene, one camera per rank
     W, H, N, deg = args.width, args.height, args.gaussians, args.sh_degree
@@ -446,7 +454,8 @@ def main():
                 "workload": f"{N} random Gaussians (SURVEY 8d, seed 42, scales log-U[{args.scale_lo},{args.scale_hi}]), "
                             f"SH degree {deg}, {W}x{H}, block 16, fwd+bwd through the rasterizer autograd API"
                             + ((" + depth image from the same compositing pass (gs_fused)" if args.fused_depth
-                               else " + differentiable depth pass") if args.render_depth else ""),
+                               else " + differentiable depth pass") if args.render_depth else "")
+                            + (", deterministic backward" if args.deterministic else ""),
                 "intersections_per_gaussian": round(num_intersects / N, 2),
                 "gaussians": N, "visible": n_visible, "intersections": num_intersects,
                 "list_entries": list_entries,

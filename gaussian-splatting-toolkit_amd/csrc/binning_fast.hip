@@ -36,8 +36,8 @@ int gsr_tile_band_rows(int tiles_x, int tiles_y, int *rows_per_band);
 bool gsr_tile_scatter_supported(int tiles_x, int tiles_y);
 size_t gsr_tile_scatter_workspace_bytes(int I, int tiles_per_band, int bands);
 int gsr_tile_scatter(int I, const int *cum, int n, const unsigned *keys, const int *gids, int tiles_x, int tiles_y,
-                     int *ids_sorted, int *tile_bins, int *count_out, void *workspace, size_t workspace_bytes,
-                     hipStream_t s);
+                     int *ids_sorted, int *tile_bins, int *count_out, int *slot_of_entry, void *workspace,
+                     size_t workspace_bytes, hipStream_t s);
 
 namespace {
 
@@ -444,8 +444,8 @@ namespace {
 int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const int32_t *order,
                     const int32_t *cum_sorted, const float *xys, const int32_t *radii,
                     const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
-                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *count_out, void *workspace,
-                    size_t workspace_bytes, gsr_stream_t stream) {
+                    int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *count_out, int32_t *slot_of_entry,
+                    void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0 && num_intersects >= 0, "bin_sorted: negative size");
   GSR_REQUIRE(block_width >= 2 && block_width <= 16, "bin_sorted: block_width must be in [2,16]");
   GSR_REQUIRE(tiles_x > 0 && tiles_y > 0, "bin_sorted: empty tile grid");
@@ -457,6 +457,7 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   const char mode = tile_sort_mode(tiles_x, tiles_y, reach_records != nullptr);
   GSR_REQUIRE(!device_sized || mode == 's',
               "bin_sorted_dev: needs the single-pass tile scatter (<= 16384 tiles, or reach records)");
+  GSR_REQUIRE(slot_of_entry == nullptr || mode == 's', "bin_sorted: slot_of_entry needs the single-pass tile scatter");
   int rpb = tiles_y, bands = 1;
   if (reach_records) {
     bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
@@ -491,7 +492,7 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   GSR_CHECK_LAUNCH("bin_sorted(emit)");
   if (mode == 's')
     return gsr_tile_scatter(num_intersects, cum_sorted, num_points, tile_in, ids_in, tiles_x, tiles_y,
-                            gaussian_ids_sorted, tile_bins, count_out, temp, temp_bytes, s);
+                            gaussian_ids_sorted, tile_bins, count_out, slot_of_entry, temp, temp_bytes, s);
   // (bands == 1 here: the stream is in depth order over the whole grid)
   if (mode == 'm') {
     int rc = gsr_sort_mid_pairs(num_intersects, tile_in, ids_in, tile_out, gaussian_ids_sorted,
@@ -512,20 +513,21 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
 GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                               const int32_t *cum_sorted, const float *xys, const int32_t *radii,
                               const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
-                              int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *workspace,
-                              size_t workspace_bytes, gsr_stream_t stream) {
+                              int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *slot_of_entry,
+                              void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
   return bin_sorted_impl(false, num_points, num_intersects, order, cum_sorted, xys, radii, reach_records, tiles_x,
-                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, nullptr, workspace, workspace_bytes,
-                         stream);
+                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, nullptr, slot_of_entry, workspace,
+                         workspace_bytes, stream);
 }
 
 GSR_EXPORT int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
                                   const int32_t *cum_sorted, const float *xys, const int32_t *radii,
                                   const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
                                   int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *count_out,
-                                  void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
+                                  int32_t *slot_of_entry, void *workspace, size_t workspace_bytes,
+                                  gsr_stream_t stream) {
   GSR_REQUIRE(capacity > 0 && num_points > 0, "bin_sorted_dev: capacity and num_points must be positive");
   return bin_sorted_impl(true, num_points, capacity, order, cum_sorted, xys, radii, reach_records, tiles_x,
-                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, count_out, workspace, workspace_bytes,
-                         stream);
+                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, count_out, slot_of_entry, workspace,
+                         workspace_bytes, stream);
 }

@@ -195,6 +195,47 @@ __device__ __forceinline__ int wave_max(int v) {
 // RGBD (G == 4 only): a fourth colour channel (one scalar per Gaussian, composited into its
 // own image over background bg_extra by the forward) with cotangent v_out_extra [H,W];
 // its gradient goes to v_extra [N].
+constexpr int kPartialStride = 12;  // floats per list entry in deterministic mode (10 used)
+
+// ---- deterministic mode, second pass -------------------------------------------------
+// One lane per Gaussian (depth position i, Gaussian order[i]): sums the partial rows of its
+// list entries in stream order -- entry e of band b, e in [cum[b n + i - 1], cum[b n + i]),
+// lives in row slot_of[e] -- so the result does not depend on which tile's wave finished
+// first.  Rows a tile never reached (it stopped early / the splat was culled at staging)
+// carry flag 0.
+template <bool RGBD>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(
+    const int n, const int num_bands, const int capacity, const int *__restrict__ order,
+    const int *__restrict__ cum, const int *__restrict__ slot_of, const float *__restrict__ partials,
+    const unsigned char *__restrict__ pflags, float *__restrict__ v_xy, float *__restrict__ v_conic,
+    float *__restrict__ v_colors, float *__restrict__ v_opacity, float *__restrict__ v_extra) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < num_bands; ++b) {
+    const long long ci = (long long)b * n + i;
+    int e0 = ci > 0 ? cum[ci - 1] : 0, e1 = cum[ci];
+    e0 = min(e0, capacity);
+    e1 = min(e1, capacity);
+    for (int e = e0; e < e1; ++e) {
+      const int s = slot_of[e];
+      if (!pflags[s]) continue;
+      const float4 *row = reinterpret_cast<const float4 *>(partials + (size_t)s * kPartialStride);
+      const float4 r0 = row[0], r1 = row[1], r2 = row[2];
+      acc[0] += r0.x, acc[1] += r0.y, acc[2] += r0.z, acc[3] += r0.w;
+      acc[4] += r1.x, acc[5] += r1.y, acc[6] += r1.z, acc[7] += r1.w;
+      acc[8] += r2.x;
+      if (RGBD) acc[9] += r2.y;
+    }
+  }
+  const int g = order[i];
+  v_xy[2 * g] = acc[0], v_xy[2 * g + 1] = acc[1];
+  v_conic[3 * g] = acc[2], v_conic[3 * g + 1] = acc[3], v_conic[3 * g + 2] = acc[4];
+  v_colors[3 * g] = acc[5], v_colors[3 * g + 1] = acc[6], v_colors[3 * g + 2] = acc[7];
+  v_opacity[g] = acc[8];
+  if (RGBD) v_extra[g] = acc[9];
+}
+
 template <int G, bool RGBD>
 __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
@@ -206,7 +247,8 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const float *__restrict__ v_output_alpha, float *__restrict__ v_xy,
     float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity,
     const float *__restrict__ extra, const float bg_extra, const float *__restrict__ v_out_extra,
-    float *__restrict__ v_extra, const int deep_threshold, const unsigned base_grid) {
+    float *__restrict__ v_extra, const int deep_threshold, const unsigned base_grid,
+    float *__restrict__ partials, unsigned char *__restrict__ pflags) {
   static_assert(!RGBD || G == 4, "the 10-component butterfly exists for groups of 4");
   constexpr int NC = RGBD ? 10 : 9;
   __shared__ SplatA sA[kChunk];
@@ -364,11 +406,26 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
         const float k2 = no * sel_b * A.b;
         const float grad = main_v * k1 + other * k2;
         const int g = sId[t];
+        if (partials) {
+          // deterministic mode: the (tile, splat) partial goes to the row of its list entry;
+          // rows are summed per Gaussian in a fixed order by reduce_partials_kernel
+          const int sx = sC[t].sidx;
+          float *row = partials + (size_t)sx * kPartialStride;
+          if (owns_main) row[comp] = grad;
+          if (owns_extra) {
+            row[8] = extra_v;
+            pflags[sx] = 1;
+          }
+          if constexpr (RGBD) {
+            if ((lane & 15) == 1) row[9] = extra2_v;
+          }
+        } else {
         if (owns_main && grad != 0.f)
           unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, grad);
         if (owns_extra && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
         if constexpr (RGBD) {
           if ((lane & 15) == 1 && extra2_v != 0.f) unsafeAtomicAdd(v_extra + g, extra2_v);
+        }
         }
       }
     }
@@ -596,7 +653,8 @@ GSR_EXPORT int gsr_rasterize_backward(
                      reinterpret_cast<const int2 *>(tile_bins),                                     \
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,  \
                      final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,        \
-                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep, base)
+                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep, base, \
+                     (float *)nullptr, (unsigned char *)nullptr)
   if (group == 8) GSR_LAUNCH_T16(8);
   else GSR_LAUNCH_T16(4);
 #undef GSR_LAUNCH_T16
@@ -630,8 +688,68 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
                      0, s, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics,
                      colors, opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic,
-                     v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra, deep, base);
+                     v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra, deep, base, (float *)nullptr,
+                     (unsigned char *)nullptr);
   GSR_CHECK_LAUNCH("rasterize_backward_rgbd");
+  return GSR_OK;
+}
+
+// ---- deterministic backward ----------------------------------------------------------
+GSR_EXPORT size_t gsr_rasterize_backward_det_workspace_bytes(int list_capacity) {
+  if (list_capacity <= 0) return 0;
+  return (((size_t)list_capacity * kPartialStride * sizeof(float) + 255) & ~(size_t)255) +
+         (((size_t)list_capacity + 255) & ~(size_t)255);
+}
+
+GSR_EXPORT int gsr_rasterize_backward_det(
+    unsigned img_height, unsigned img_width, int num_points, int list_capacity, const int32_t *gaussian_ids_sorted,
+    const int32_t *tile_bins, const float *xys, const float *conics, const float *colors, const float *extra,
+    const float *opacities, const float *background, float extra_background, const float *final_Ts,
+    const int32_t *final_idx, const float *v_output, const float *v_output_extra, const float *v_output_alpha,
+    const int32_t *order, const int32_t *cum_sorted, int num_bands, const int32_t *slot_of_entry, void *workspace,
+    size_t workspace_bytes, float *v_xy, float *v_conic, float *v_colors, float *v_extra, float *v_opacity,
+    gsr_stream_t stream) {
+  GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward_det: empty image");
+  GSR_REQUIRE(num_points >= 0 && list_capacity >= 0, "rasterize_backward_det: negative size");
+  if (num_points == 0) return GSR_OK;
+  const bool rgbd = extra != nullptr;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background && final_Ts &&
+                  final_idx && v_output && order && cum_sorted && slot_of_entry && v_xy && v_conic && v_colors &&
+                  v_opacity && (!rgbd || (v_output_extra && v_extra)),
+              "rasterize_backward_det: null pointer");
+  GSR_REQUIRE(num_bands >= 1, "rasterize_backward_det: num_bands < 1");
+  GSR_REQUIRE(workspace && workspace_bytes >= gsr_rasterize_backward_det_workspace_bytes(list_capacity) &&
+                  (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "rasterize_backward_det: workspace too small or not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  float *partials = static_cast<float *>(workspace);
+  unsigned char *pflags = reinterpret_cast<unsigned char *>(workspace) +
+                          (((size_t)list_capacity * kPartialStride * sizeof(float) + 255) & ~(size_t)255);
+  if (int zrc = gsr_zero_async(pflags, ((size_t)list_capacity + 3) & ~(size_t)3, s)) return zrc;
+  const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
+  const int num_tiles = tiles_x * tiles_y;
+  const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
+  // (one wave per tile: a split tile would need one partial row per sub-tile wave)
+  if (rgbd) {
+    hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, true>), dim3(base), dim3(64), 0, s, tiles_x, num_tiles,
+                       (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
+                       reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, final_Ts, final_idx,
+                       v_output, v_output_alpha, v_xy, v_conic, v_colors, v_opacity, extra, extra_background,
+                       v_output_extra, v_extra, 0, base, partials, pflags);
+    hipLaunchKernelGGL(reduce_partials_kernel<true>, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, num_points,
+                       num_bands, list_capacity, order, cum_sorted, slot_of_entry, (const float *)partials,
+                       (const unsigned char *)pflags, v_xy, v_conic, v_colors, v_opacity, v_extra);
+  } else {
+    hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, false>), dim3(base), dim3(64), 0, s, tiles_x, num_tiles,
+                       (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
+                       reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, final_Ts, final_idx,
+                       v_output, v_output_alpha, v_xy, v_conic, v_colors, v_opacity, (const float *)nullptr, 0.f,
+                       (const float *)nullptr, (float *)nullptr, 0, base, partials, pflags);
+    hipLaunchKernelGGL(reduce_partials_kernel<false>, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, num_points,
+                       num_bands, list_capacity, order, cum_sorted, slot_of_entry, (const float *)partials,
+                       (const unsigned char *)pflags, v_xy, v_conic, v_colors, v_opacity, (float *)nullptr);
+  }
+  GSR_CHECK_LAUNCH("rasterize_backward_det");
   return GSR_OK;
 }
 

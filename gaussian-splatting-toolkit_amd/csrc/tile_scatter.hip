@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const Ban
                                                       const unsigned *__restrict__ table,
                                                       const unsigned *__restrict__ gsum,
                                                       const unsigned *__restrict__ tile_base,
-                                                      int *__restrict__ ids_out) {
+                                                      int *__restrict__ ids_out, int *__restrict__ slot_out) {
   extern __shared__ unsigned off[];
   const int lane = threadIdx.x & 63, b = blockIdx.y;
   // Workgroup x runs on XCD x % 8.  Give each XCD a contiguous range of chunks:
@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const Ban
   int key_bits = 1;  // bits that distinguish tile ids
   while ((1 << key_bits) < T) ++key_bits;
   // One 64-lane step: slot = ds_add_rtn, conflicts re-ranked by lane (see the header).
-  auto place = [&](const unsigned key, const int gid, const bool live) {
+  // slot_out (nullable): the final slot of stream element `eidx`, i.e. the inverse of the
+  // scatter (deterministic backward: raster_bwd.hip reduces per Gaussian in stream order)
+  auto place = [&](const unsigned key, const int gid, const bool live, const int eidx) {
     unsigned old = 0, cur = 1;
     if (live) {
       old = atomicAdd(&off[key], 1u);  // key: band-local tile id
@@ -314,7 +316,10 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const Ban
       if (mine) pos = cur - (unsigned)__popcll(same) + (unsigned)__popcll(same & lt);
       cm &= ~same;
     }
-    if (live) ids_out[pos] = gid;
+    if (live) {
+      ids_out[pos] = gid;
+      if (slot_out) slot_out[eidx] = (int)pos;
+    }
   };
   // Full batches of kUnroll x 64 elements, software-pipelined: the next batch is
   // loaded before the current one is placed.  The loop body is straight-line
@@ -360,12 +365,12 @@ __global__ __launch_bounds__(256) void scatter_kernel(const int I_cap, const Ban
       ngid[u] = gids[base + u * 64];
     }
 #pragma unroll
-    for (int u = 0; u < kUnroll; ++u) place(key[u], gid[u], true);
+    for (int u = 0; u < kUnroll; ++u) place(key[u], gid[u], true, (int)beg + b * (kUnroll * 64) + u * 64 + lane);
   }
   for (int e0 = (int)beg + nfull * (kUnroll * 64); e0 < end; e0 += 64) {
     const int e = e0 + lane;
     const bool live = e < end;
-    place(live ? keys[e] - key0 : 0u, live ? gids[e] : 0, live);
+    place(live ? keys[e] - key0 : 0u, live ? gids[e] : 0, live, e);
   }
 }
 
@@ -408,10 +413,10 @@ size_t gsr_tile_scatter_workspace_bytes(int I, int tiles_per_band, int bands) {
 // inclusive scan over the per-band counts of the n Gaussians in (band, depth) order, band
 // b's segment of the stream is [cum[b n - 1], cum[(b + 1) n - 1]), cut at `I` (what the
 // buffers were sized for); count_out (device-accessible int, may be null) receives the
-// uncut total cum[bands n - 1].
+// uncut total cum[bands n - 1]; slot_of_entry (may be null) the slot each stream element went to.
 int gsr_tile_scatter(int I, const int *cum, int n, const unsigned *keys, const int *gids, int tiles_x, int tiles_y,
-                     int *ids_sorted, int *tile_bins, int *count_out, void *workspace, size_t workspace_bytes,
-                     hipStream_t s) {
+                     int *ids_sorted, int *tile_bins, int *count_out, int *slot_of_entry, void *workspace,
+                     size_t workspace_bytes, hipStream_t s) {
   using namespace gsr_ts;
   int rpb = 0;
   const int bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
@@ -442,7 +447,7 @@ int gsr_tile_scatter(int I, const int *cum, int n, const unsigned *keys, const i
   hipLaunchKernelGGL(bases_kernel, dim3(1), dim3(1024), 0, s, bands, T, tpb, num_tiles, totals, tile_bins);
   hipLaunchKernelGGL(scatter_kernel, dim3(8 * gsr_cdiv(p.chunks, 8), bands), dim3(256), lds, s, I, B, p.chunk, T,
                      p.chunks, p.groups, p.chunks_per_group, keys, gids, (const unsigned *)table,
-                     (const unsigned *)gsum, (const unsigned *)totals, ids_sorted);
+                     (const unsigned *)gsum, (const unsigned *)totals, ids_sorted, slot_of_entry);
   GSR_CHECK_LAUNCH("tile_scatter");
   return GSR_OK;
 }

@@ -63,6 +63,10 @@ class _RasterizeRGBD(Function):
             idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
             ids = torch.zeros(0, dtype=torch.int32, device=dev)
             bins = torch.zeros(0, 2, dtype=torch.int32, device=dev)
+        from rasterizer import rasterize as _R
+
+        ctx.det = _R._bin_cache["value"][3] if (_R.is_deterministic() and num_intersects >= 1 and
+                                                _R._bin_cache["value"] is not None) else None
         ctx.set_materialize_grads(False)
         ctx.meta = (img_height, img_width, num_intersects, float(extra_background))
         ctx.save_for_backward(ids, bins, xys, conics, colors, extra, opacity, background, Ts, idx)
@@ -79,8 +83,14 @@ class _RasterizeRGBD(Function):
             return (z(xys), None, None, z(conics), None, z(colors), z(extra), z(opacity)) + (None,) * 4
         v_img = torch.zeros(H, W, 3, device=dev) if v_img is None else v_img
         v_ext = torch.zeros(H, W, device=dev) if v_ext is None else v_ext
-        v_xy, v_conic, v_colors, v_extra, v_opacity = _C.rasterize_backward_rgbd(
-            H, W, ids, bins, xys, conics, colors, extra, opacity, background, ebg, Ts, idx, v_img, v_ext, v_alpha)
+        if ctx.det is not None:  # fixed summation order (rasterizer.rasterize.set_deterministic)
+            v_xy, v_conic, v_colors, v_extra, v_opacity = _C.rasterize_backward_det(
+                H, W, ids, bins, xys, conics, colors, opacity, background, Ts, idx, v_img, v_alpha, *ctx.det,
+                extra=extra, extra_background=ebg, v_output_extra=v_ext)
+        else:
+            v_xy, v_conic, v_colors, v_extra, v_opacity = _C.rasterize_backward_rgbd(
+                H, W, ids, bins, xys, conics, colors, extra, opacity, background, ebg, Ts, idx, v_img, v_ext,
+                v_alpha)
         return (v_xy, None, None, v_conic, None, v_colors, v_extra.view(extra.shape),
                 v_opacity.reshape(opacity.shape)) + (None,) * 4
 

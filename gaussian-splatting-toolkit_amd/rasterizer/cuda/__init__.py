@@ -311,7 +311,7 @@ MAX_SCATTER_TILES = 16384  # tile grids the device-sized path supports without r
 def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Tensor, xys: Tensor,
                radii: Tensor, tile_bounds: Tuple[int, int, int], block_width: int,
                reach_records: Optional[Tensor] = None, device_sized: bool = False,
-               count_out: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+               count_out: Optional[Tensor] = None, want_slots: bool = False):
     """Second half (``gsr_bin_sorted``): -> (gaussian_ids_sorted i32[I],
     tile_bins i32[T,2]), identical to what ``bin_and_sort_gaussians`` returns.
     With the records (and counts) of :func:`count_reach`: the same lists without
@@ -320,7 +320,8 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     the device from ``cum_sorted[-1]`` and the lists are cut at the capacity
     (``gsr_bin_sorted_dev``) -- the caller checks ``cum_sorted[-1] <= capacity``
     later, off the critical path; ``count_out`` (int32[1], pinned host memory or
-    device) receives that count."""
+    device) receives that count.  ``want_slots``: also return ``slot_of_entry`` i32[I]
+    (the inverse of the scatter, for :func:`rasterize_backward_det`)."""
     _check(order, "order", _i32)
     _check(cum_sorted, "cum_sorted", _i32)
     _check(xys, "xys", _f32)
@@ -338,14 +339,17 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
         nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I), C.c_int(tile_bounds[0]),
                                                            C.c_int(tile_bounds[1])))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        slots = torch.empty((I,), dtype=_i32, device=dev) if want_slots else None
         head = (C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted), _ptr(xys), _ptr(radii),
                 _ptr(reach_records) if reach_records is not None else None, C.c_int(tile_bounds[0]),
                 C.c_int(tile_bounds[1]), C.c_uint(block_width), _ptr(ids), _ptr(tile_bins))
-        tail = (_ptr(ws), C.c_size_t(nbytes), _stream(dev))
+        tail = (_ptr(slots) if want_slots else None, _ptr(ws), C.c_size_t(nbytes), _stream(dev))
         if device_sized:
             _call("gsr_bin_sorted_dev", *head, _ptr(count_out) if count_out is not None else None, *tail)
         else:
             _call("gsr_bin_sorted", *head, *tail)
+    if want_slots:
+        return ids, tile_bins, slots
     return ids, tile_bins
 
 
@@ -470,6 +474,48 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
               C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(),
                                           ((img_width + 15) // 16) * ((img_height + 15) // 16))), _stream(dev))
     return v_xy, v_conic, v_colors, v_extra, v_opacity
+
+
+def rasterize_backward_det(img_height, img_width, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
+                           background, final_Ts, final_idx, v_output, v_output_alpha, order, cum_sorted, slot_of_entry,
+                           extra=None, extra_background: float = 0.0, v_output_extra=None):
+    """``gsr_rasterize_backward_det``: the compositing backward with a fixed summation order
+    (bit-identical gradients from run to run) -> (v_xy, v_conic, v_colors, v_opacity [N,1]) or,
+    with ``extra`` / ``v_output_extra``, (v_xy, v_conic, v_colors, v_extra [N], v_opacity)."""
+    _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
+    for t, nm in ((order, "order"), (cum_sorted, "cum_sorted"), (slot_of_entry, "slot_of_entry")):
+        _check(t, nm, _i32)
+    v_output = _check(v_output.contiguous(), "v_output", _f32)
+    if v_output_alpha is not None:
+        v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
+    rgbd = extra is not None
+    if rgbd:
+        _check(extra, "extra", _f32)
+        v_output_extra = _check(v_output_extra.contiguous(), "v_output_extra", _f32)
+    n = xys.size(0)
+    L = gaussian_ids_sorted.numel()
+    if slot_of_entry.numel() != L or order.numel() != n or cum_sorted.numel() % max(n, 1):
+        raise RuntimeError("rasterize_backward_det: order / cum_sorted / slot_of_entry do not match the lists")
+    bands = cum_sorted.numel() // n if n else 1
+    dev = xys.device
+    _o = lambda t: None if t is None else _ptr(t)
+    with torch.cuda.device(dev):
+        v_xy = torch.empty((n, 2), dtype=_f32, device=dev)
+        v_conic = torch.empty((n, 3), dtype=_f32, device=dev)
+        v_colors = torch.empty((n, 3), dtype=_f32, device=dev)
+        v_opacity = torch.empty((n, 1), dtype=_f32, device=dev)
+        v_extra = torch.empty((n,), dtype=_f32, device=dev) if rgbd else None
+        nbytes = int(_lib().gsr_rasterize_backward_det_workspace_bytes(C.c_int(L)))
+        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=dev)
+        _call("gsr_rasterize_backward_det", C.c_uint(img_height), C.c_uint(img_width), C.c_int(n), C.c_int(L),
+              _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors), _o(extra),
+              _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(final_Ts), _ptr(final_idx),
+              _ptr(v_output), _o(v_output_extra), _o(v_output_alpha), _ptr(order), _ptr(cum_sorted), C.c_int(bands),
+              _ptr(slot_of_entry), _ptr(ws), C.c_size_t(nbytes), _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
+              _o(v_extra), _ptr(v_opacity), _stream(dev))
+    if rgbd:
+        return v_xy, v_conic, v_colors, v_extra, v_opacity
+    return v_xy, v_conic, v_colors, v_opacity
 
 
 def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,

@@ -58,6 +58,8 @@ SYMBOLS = (
     "gsr_refine_plan",
     "gsr_refine_apply",
     "gsr_adam_step",
+    "gsr_rasterize_backward_det_workspace_bytes",
+    "gsr_rasterize_backward_det",
     "gsr_debug_count_staged",
 )
 
@@ -87,6 +89,7 @@ def _load():
     lib.gsr_depth_order_workspace_bytes.restype = C.c_size_t
     lib.gsr_bin_sorted_workspace_bytes.restype = C.c_size_t
     lib.gsr_refine_workspace_bytes.restype = C.c_size_t
+    lib.gsr_rasterize_backward_det_workspace_bytes.restype = C.c_size_t
     return lib
 
 

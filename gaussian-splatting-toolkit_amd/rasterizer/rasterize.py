@@ -27,6 +27,20 @@ import rasterizer.cuda as _C
 
 _bin_cache = {"key": None, "value": None, "keepalive": None, "reach": None}
 
+# Deterministic backward (include/gsraster.h, gsr_rasterize_backward_det): per-(tile, entry)
+# partials summed per Gaussian in a fixed order instead of float atomics -- bit-identical
+# gradients from run to run, ~1.4x the backward time.  GSR_DETERMINISTIC=1 or set_deterministic().
+_deterministic = {"on": os.environ.get("GSR_DETERMINISTIC", "0") not in ("", "0")}
+
+
+def set_deterministic(flag: bool) -> None:
+    _deterministic["on"] = bool(flag)
+    _bin_cache["key"] = None  # cached lists may lack the inverse map
+
+
+def is_deterministic() -> bool:
+    return _deterministic["on"]
+
 
 def _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width):
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (xys, depths, radii, num_tiles_hit)) + (
@@ -220,9 +234,9 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     # conics and opacity.
     exact = block_width == 16
 
-    def remember(num_intersects, ids, bins):
+    def remember(num_intersects, ids, bins, aux=None):
         _bin_cache["key"] = key
-        _bin_cache["value"] = (num_intersects, ids, bins)
+        _bin_cache["value"] = (num_intersects, ids, bins, aux)
         _bin_cache["keepalive"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
         _bin_cache["reach"] = (conics.detach(), opacity.detach(), conics._version, opacity._version,
                                _producer_signature(conics), _producer_signature(opacity))
@@ -231,7 +245,7 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
         same = _same_reach_inputs(conics, opacity) if exact else True
         cached = _bin_cache["value"]
         if same is True:
-            return cached + (None,)
+            return cached[:3] + (None,)
         if same == "verify" and cached[0] >= 1:
             # use the cached lists now; compare the values on the device and look at the
             # answer once the compositing is queued (no host wait in front of the GPU work)
@@ -243,7 +257,7 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
 
             def verify():
                 if not check.resolve():
-                    return cached + (False,)
+                    return cached[:3] + (False,)
                 n, ids, bins, fin = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds,
                                                  block_width, exact, remember)
                 if fin is not None:
@@ -265,16 +279,25 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
         tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds)
     order, cum_sorted = _C.depth_order(depths, radii, tiles)
 
+    # deterministic backward: keep the inverse of the scatter and the depth order (block_width 16
+    # with the exact lists, i.e. the single-pass scatter path)
+    det = _deterministic["on"] and exact and os.environ.get("GSR_TILE_SORT", "s")[:1] not in ("r", "m")
+
     def build(count, device_sized=False):
-        return _C.bin_sorted(num_points, count, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
-                             device_sized=device_sized)
+        out = _C.bin_sorted(num_points, count, order, cum_sorted, xys, radii, tile_bounds, block_width, records,
+                            device_sized=device_sized, want_slots=det)
+        if det:
+            build.aux = (order, cum_sorted, out[2])
+        return out[0], out[1]
+
+    build.aux = None
 
     capacity = _speculative_capacity(xys.device, num_points, tile_bounds, exact)
     if capacity is None:
         num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
         _note_count(xys.device, num_points, tile_bounds, num_intersects)
         ids, bins = build(num_intersects) if num_intersects >= 1 else (None, None)
-        remember(num_intersects, ids, bins)
+        remember(num_intersects, ids, bins, build.aux)
         return num_intersects, ids, bins, None
 
     # Size the lists from the previous view instead of waiting for the count to reach the
@@ -293,7 +316,7 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
         rebuilt = num_intersects > capacity  # the guess was too small: build the lists again
         if rebuilt:
             ids, bins = build(num_intersects)
-        remember(num_intersects, ids, bins)
+        remember(num_intersects, ids, bins, build.aux)
         return num_intersects, ids, bins, rebuilt
 
     return None, ids, bins, finish
@@ -336,6 +359,9 @@ class _RasterizeGaussians(Function):
         ctx.set_materialize_grads(False)
         ctx.img_width = img_width
         ctx.img_height = img_height
+        # deterministic backward: (order, cum_sorted, slot_of_entry) of the lists just used
+        ctx.det = _bin_cache["value"][3] if (_deterministic["on"] and num_intersects >= 1 and
+                                             colors.shape[-1] == 3 and _bin_cache["value"] is not None) else None
         ctx.num_intersects = num_intersects
         ctx.block_width = block_width
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity,
@@ -361,11 +387,16 @@ class _RasterizeGaussians(Function):
             v_colors = torch.zeros_like(colors)
             v_opacity = torch.zeros_like(opacity)
         else:
-            rasterize_fn = _C.rasterize_backward if colors.shape[-1] == 3 else _C.nd_rasterize_backward
-            v_xy, v_conic, v_colors, v_opacity = rasterize_fn(
-                ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
-                conics, colors, opacity, background, final_Ts, final_idx, v_out_img, v_out_alpha,
-            )
+            if ctx.det is not None:
+                v_xy, v_conic, v_colors, v_opacity = _C.rasterize_backward_det(
+                    ctx.img_height, ctx.img_width, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity,
+                    background, final_Ts, final_idx, v_out_img, v_out_alpha, *ctx.det)
+            else:
+                rasterize_fn = _C.rasterize_backward if colors.shape[-1] == 3 else _C.nd_rasterize_backward
+                v_xy, v_conic, v_colors, v_opacity = rasterize_fn(
+                    ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
+                    conics, colors, opacity, background, final_Ts, final_idx, v_out_img, v_out_alpha,
+                )
             v_opacity = v_opacity.reshape(opacity.shape)
 
         # xys, depths, radii, conics, num_tiles_hit, colors, opacity, then 5 non-differentiable

@@ -147,6 +147,10 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  * the counts to gsr_depth_order (in place of num_tiles_hit) and the records to
  * gsr_bin_sorted builds the lists without the dead pairs: images and gradients
  * are unchanged, `gaussian_ids_sorted` is a subsequence of the reference's.
+ * slot_of_entry (nullable, int32 as long as the lists): for the e-th list entry in
+ * (band, depth position, tile) order -- the entries of the Gaussian at depth position
+ * i in band b are e in [cum_sorted[b n + i - 1], cum_sorted[b n + i]) -- the index it got
+ * in gaussian_ids_sorted: the inverse map gsr_rasterize_backward_det reduces along.
  * With reach_records == NULL gsr_bin_sorted reproduces the reference's lists
  * bit for bit.
  *
@@ -174,7 +178,8 @@ int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                    const int32_t *radii, const void *reach_records, int tiles_x,
                    int tiles_y, unsigned block_width,
                    int32_t *gaussian_ids_sorted, int32_t *tile_bins,
-                   void *workspace, size_t workspace_bytes, gsr_stream_t stream);
+                   int32_t *slot_of_entry, void *workspace,
+                   size_t workspace_bytes, gsr_stream_t stream);
 
 /* One int32 from device memory to any device-accessible address, e.g. pinned
  * host memory mapped into the device's address space: a one-thread kernel in
@@ -199,8 +204,9 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
                        const int32_t *radii, const void *reach_records,
                        int tiles_x, int tiles_y, unsigned block_width,
                        int32_t *gaussian_ids_sorted, int32_t *tile_bins,
-                       int32_t *count_out, void *workspace,
-                       size_t workspace_bytes, gsr_stream_t stream);
+                       int32_t *count_out, int32_t *slot_of_entry,
+                       void *workspace, size_t workspace_bytes,
+                       gsr_stream_t stream);
 
 /* ---- compositing ----------------------------------------------------------
  * replaces rasterize_forward_tensor (bindings.cu:269-328), kernel
@@ -500,6 +506,31 @@ typedef struct {
 int gsr_adam_step(int num_tensors, const gsr_adam_tensor *tensors,
                   double beta1, double beta2, double eps, long long step,
                   gsr_stream_t stream);
+
+/* ---- deterministic compositing backward ------------------------------------------
+ * gsr_rasterize_backward(_rgbd) sum the per-tile contributions to a Gaussian's gradient
+ * with float atomics: the result depends on the order in which the tiles' waves retire
+ * (differences of a few ulp from run to run).  This variant (16x16 tiles) writes each
+ * (tile, list entry) contribution to its own row of a workspace and then sums the rows of
+ * every Gaussian in a fixed order, so two runs on the same inputs give bit-identical
+ * gradients ("deterministic backward").  It needs what the binning knew:
+ * order / cum_sorted of gsr_depth_order (num_bands = gsr_tile_bands) and slot_of_entry of
+ * gsr_bin_sorted(_dev); list_capacity = the length gaussian_ids_sorted / slot_of_entry were
+ * sized for.  extra / v_output_extra / v_extra NULL: three channels; otherwise the RGB +
+ * extra-channel pass of gsr_rasterize_backward_rgbd.  Every output element is written.
+ * About 1.4x the time of the atomic version and 48 B of workspace per list entry. */
+size_t gsr_rasterize_backward_det_workspace_bytes(int list_capacity);
+int gsr_rasterize_backward_det(
+    unsigned img_height, unsigned img_width, int num_points, int list_capacity,
+    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+    const float *xys, const float *conics, const float *colors,
+    const float *extra, const float *opacities, const float *background,
+    float extra_background, const float *final_Ts, const int32_t *final_idx,
+    const float *v_output, const float *v_output_extra,
+    const float *v_output_alpha, const int32_t *order,
+    const int32_t *cum_sorted, int num_bands, const int32_t *slot_of_entry,
+    void *workspace, size_t workspace_bytes, float *v_xy, float *v_conic,
+    float *v_colors, float *v_extra, float *v_opacity, gsr_stream_t stream);
 
 /* ---- measurement hook ---------------------------------------------------------
  * counters: two device uint64 (or NULL = off, the default).  While set, the 16x16

@@ -561,3 +561,57 @@ def test_deep_tiles_split_over_four_waves_give_identical_results(rgbd, monkeypat
         for x, y in zip(b0, ba):
             scale = x.abs().max().item()
             assert (x - y).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("W,H,n", [(320, 208, 40_000), (3840, 2160, 30_000)])
+def test_deterministic_backward_is_bit_reproducible_and_equals_the_atomic_one(W, H, n):
+    """gsr_rasterize_backward_det: per-(tile, entry) partials summed per Gaussian in a fixed
+    order.  Two runs give bit-identical gradients (the atomic version differs by a few ulp from
+    run to run), equal to the atomic result up to that summation order; RGB and RGB + depth; one
+    band and four bands (4K)."""
+    import rasterizer.cuda as C
+
+    bw = 16
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=8, scale_lo=0.01, scale_hi=0.08 if W < 2000 else 0.05)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    g = dict(xys=cu(xys), depths=cu(depths), radii=cu(radii), conics=cu(conics), opac=cu(sc["opacities"]))
+    cnt, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
+    order, cum = C.depth_order(g["depths"], g["radii"], cnt)
+    I = int(cum[-1].item())
+    ids, bins, slots = C.bin_sorted(n, I + 4096, order, cum, g["xys"], g["radii"], tb, bw, recs, device_sized=True,
+                                    want_slots=True)
+    # the inverse map: entry e went to slot slots[e]; it is a permutation of [0, I)
+    assert torch.equal(torch.sort(slots[:I]).values, torch.arange(I, device=DEV, dtype=torch.int32))
+    # ... and entry e of Gaussian order[i] really holds that Gaussian
+    owner = torch.repeat_interleave(order.repeat(C.tile_bands(tb)).long(),
+                                    torch.diff(cum.long(), prepend=torch.zeros(1, device=DEV, dtype=torch.long)))
+    assert torch.equal(ids[slots[:I].long()].long(), owner)
+    rng = np.random.default_rng(1)
+    colors = cu(rng.uniform(0, 1, (n, 3)).astype(np.float32))
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
+    v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
+    v_ext = torch.rand(H, W, device=DEV) * 2 - 1
+    img, Ts, idx = C.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), ids, bins, g["xys"], g["conics"], colors, g["opac"], bg)
+    args = (H, W, ids, bins, g["xys"], g["conics"], colors, g["opac"], bg, Ts, idx, v_img, v_alpha, order, cum, slots)
+    d1 = C.rasterize_backward_det(*args)
+    d2 = C.rasterize_backward_det(*args)
+    a = C.rasterize_backward(H, W, bw, ids, bins, g["xys"], g["conics"], colors, g["opac"], bg, Ts, idx, v_img, v_alpha)
+    for x, y, z in zip(d1, d2, a):
+        assert torch.equal(x, y)                                                    # reproducible bit for bit
+        assert (x - z).abs().max().item() <= 2e-5 * z.abs().max().item() + 1e-12    # same sums
+    # RGB + extra channel
+    f = C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, g["xys"], g["conics"], colors, g["depths"], g["opac"], bg, 0.0)
+    e1 = C.rasterize_backward_det(H, W, ids, bins, g["xys"], g["conics"], colors, g["opac"], bg, f[2], f[3], v_img,
+                                  v_alpha, order, cum, slots, extra=g["depths"], extra_background=0.0,
+                                  v_output_extra=v_ext)
+    e2 = C.rasterize_backward_det(H, W, ids, bins, g["xys"], g["conics"], colors, g["opac"], bg, f[2], f[3], v_img,
+                                  v_alpha, order, cum, slots, extra=g["depths"], extra_background=0.0,
+                                  v_output_extra=v_ext)
+    b = C.rasterize_backward_rgbd(H, W, ids, bins, g["xys"], g["conics"], colors, g["depths"], g["opac"], bg, 0.0,
+                                  f[2], f[3], v_img, v_ext, v_alpha)
+    for x, y, z in zip(e1, e2, b):
+        assert torch.equal(x, y)
+        assert (x - z.view_as(x)).abs().max().item() <= 2e-5 * z.abs().max().item() + 1e-12

@@ -103,3 +103,27 @@ def test_training_through_the_fused_render_op_and_hip_graph(graph):
         assert abs(n1 - n2) <= 0.02 * n1, (ref["refinements"], res["refinements"])
     assert abs(res["psnr_end"] - ref["psnr_end"]) < 0.5, (ref["psnr_end"], res["psnr_end"])
     assert res["psnr_end"] > res["psnr_start"] + 2.0
+
+
+def test_deterministic_mode_makes_training_bitwise_reproducible():
+    """rasterizer.rasterize.set_deterministic(True): the compositing backward sums in a fixed
+    order, so two training runs (refinement included: the split samples are counter-based)
+    end with bit-identical parameters -- the float atomics were the only source of
+    run-to-run differences."""
+    from gs_fused import RefineConfig
+    from harness.train import TrainConfig, train
+    from rasterizer import rasterize as R
+
+    rcfg = RefineConfig(warmup_length=40, refine_every=20, reset_alpha_every=6, stop_screen_size_at=200,
+                        stop_split_at=260)
+    cfg = TrainConfig(num_gaussians=20_000, init_gaussians=4_000, width=320, height=180, num_views=8, iters=150,
+                      sh_degree=3, sh_degree_interval=40, densify=True, refine=rcfg)
+    R.set_deterministic(True)
+    try:
+        a = train(cfg, torch.device("cuda", 0))
+        b = train(cfg, torch.device("cuda", 0))
+    finally:
+        R.set_deterministic(False)
+    assert a["refinements"] == b["refinements"] and len(a["refinements"]) >= 3
+    assert a["param_checksum"] == b["param_checksum"]
+    assert a["psnr_end"] == b["psnr_end"]
