@@ -7,7 +7,7 @@
 #    MI355X_MICROARCH.md HBM section)
 # PMC passes never combine with other trace domains (only --kernel-trace).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
