@@ -22,6 +22,7 @@
 
 #include "gsr_common.h"
 #include "raster_common.h"
+#include "tile_rows.h"
 
 // sort_mid.hip
 size_t gsr_sort_mid_workspace_bytes(int n);
@@ -38,6 +39,13 @@ size_t gsr_tile_scatter_workspace_bytes(int I, int tiles_per_band, int bands);
 int gsr_tile_scatter(int I, const int *cum, int n, const unsigned *keys, const int *gids, int tiles_x, int tiles_y,
                      int *ids_sorted, int *tile_bins, int *count_out, int *slot_of_entry, void *workspace,
                      size_t workspace_bytes, hipStream_t s);
+
+// tile_partition2.hip
+bool gsr_tile_partition2_supported(int tiles_x, int tiles_y);
+size_t gsr_tile_partition2_workspace_bytes(int n, int capacity, int tiles_x, int tiles_y);
+int gsr_tile_partition2(int n, int capacity, const int *order, const void *recs, int tiles_x, int tiles_y,
+                        int *ids_sorted, int *tile_bins, int *count_out, void *workspace, size_t workspace_bytes,
+                        hipStream_t s);
 
 namespace {
 
@@ -64,75 +72,6 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(const int n, const floa
   // visible splats have depth > 0 (bit pattern orders like the value); culled
   // ones emit nothing, park them at the front
   keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0u;
-}
-
-// ---- tile lists: which tiles of its bounding box does a splat go into? -----
-// Per Gaussian record (32 B) written by the count pass in index order and
-// gathered by the emission pass in depth order (one 32-B sector per Gaussian
-// instead of four scattered loads).
-struct alignas(16) SplatRec {
-  float x, y, a, b, c;
-  float smax;     // see raster_common.h make_reach(): +inf = keep every box tile, < 0 = none
-  unsigned box0;  // minx | miny << 16
-  unsigned box1;  // box width | box height << 16   (0 | 0 when culled)
-};
-static_assert(sizeof(SplatRec) == 32, "SplatRec layout");
-
-// derived per Gaussian, kept in LDS for the row loop
-struct RowParams {
-  float D;      // a c - b^2
-  float umax;   // half x-extent of {sigma <= smax}
-  float vmax;   // half y-extent
-  float vstar;  // y offset of the rightmost point is -vstar, of the leftmost +vstar
-};
-
-__device__ __forceinline__ RowParams make_row_params(const SplatRec &r) {
-  RowParams p{1.f, 0.f, 0.f, 0.f};
-  if (r.smax >= 0.f && r.smax != INFINITY) {
-    p.D = r.a * r.c - r.b * r.b;  // > 0 (make_reach sets smax = inf otherwise)
-    const float t = 2.f * r.smax / p.D;
-    p.umax = sqrtf(t * r.c);
-    p.vmax = sqrtf(t * r.a);
-    p.vstar = r.b * p.umax / r.c;
-  }
-  return p;
-}
-
-// Tiles [t0, t1) of tile row `ty` (inside the box) in which the splat can reach
-// alpha >= 1/255, i.e. whose pixel-centre rectangle [16tx, 16tx+15] x [16ty, 16ty+15]
-// meets the ellipse {sigma <= smax}.  The ellipse cut by the row's band is convex,
-// so its x-projection is one interval [xl, xr]; xr is attained at the band's point
-// closest (in y) to the ellipse's rightmost point, xl likewise.  Conservative:
-// `smax` carries a 1 % margin in alpha (make_reach) and the interval is widened
-// by 1e-3 of the ellipse's extent + 0.05 px against rounding in the square roots.
-// The compositing kernels re-test per sub-tile / pixel, so keeping a dead pair is
-// harmless; dropping a live one is what the margins exclude
-// (tests/test_gpu_kernels.py::test_exact_lists_drop_only_dead_pairs).
-__device__ __forceinline__ void row_range(const SplatRec &r, const RowParams &p, int ty, int &t0, int &t1) {
-  const int minx = (int)(r.box0 & 0xffffu), bwid = (int)(r.box1 & 0xffffu);
-  t0 = minx;
-  t1 = minx + bwid;
-  if (r.smax == INFINITY) return;
-  if (r.smax < 0.f) {
-    t1 = t0;
-    return;
-  }
-  const float v0 = 16.f * (float)ty - r.y, v1 = v0 + 15.f;
-  const float mv = 1e-3f * p.vmax + 0.05f, mu = 1e-3f * p.umax + 0.05f;
-  if (v0 > p.vmax + mv || v1 < -p.vmax - mv) {
-    t1 = t0;
-    return;
-  }
-  const float two_as = 2.f * r.a * r.smax;
-  const float vr = fminf(fmaxf(-p.vstar, v0), v1), vl = fminf(fmaxf(p.vstar, v0), v1);
-  const float inv_a = 1.f / r.a;
-  const float xr = (-r.b * vr + sqrtf(fmaxf(two_as - p.D * vr * vr, 0.f))) * inv_a + mu;
-  const float xl = (-r.b * vl - sqrtf(fmaxf(two_as - p.D * vl * vl, 0.f))) * inv_a - mu;
-  // 16 tx <= x + xr   and   16 tx + 15 >= x + xl
-  const float f0 = fminf(fmaxf(ceilf((r.x + xl - 15.f) * 0.0625f), (float)t0), (float)t1);
-  const float f1 = fminf(fmaxf(floorf((r.x + xr) * 0.0625f) + 1.f, (float)t0), (float)t1);
-  t0 = (int)f0;
-  t1 = (int)f1 > t0 ? (int)f1 : t0;
 }
 
 // One wave handles 64 Gaussians and walks their (Gaussian, tile row) items
@@ -394,7 +333,7 @@ GSR_EXPORT int gsr_publish_int32(const int32_t *src, int32_t *dst, gsr_stream_t 
 GSR_EXPORT size_t gsr_reach_record_bytes(void) { return sizeof(SplatRec); }
 
 GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *radii, const float *conics,
-                               const float *opacities, int tiles_x, int tiles_y, int32_t *counts,
+                               const float *opacities, int tiles_x, int tiles_y, int num_bands, int32_t *counts,
                                void *reach_records, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0, "count_reach: num_points < 0");
   if (num_points == 0) return GSR_OK;
@@ -404,6 +343,8 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
   int rpb = tiles_y;
   int bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
   if (bands < 1) bands = 1, rpb = tiles_y;  // grids the scatter does not serve: one count per Gaussian
+  GSR_REQUIRE(num_bands == 1 || num_bands == bands, "count_reach: num_bands must be 1 or gsr_tile_bands()");
+  if (num_bands == 1) bands = 1, rpb = tiles_y;
   auto kernel = bands > 1 ? tile_rows_kernel<true> : tile_rows_kernel<false>;
   hipLaunchKernelGGL(kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream, 0,
                      num_points, (const int *)nullptr, (const int *)nullptr, xys, radii, conics, opacities,
@@ -419,23 +360,34 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
 //   'm': sort_mid.hip + edge detection
 // GSR_TILE_SORT=r|m|s overrides (A/B measurements).  Grids of more than one
 // band need the per-band counts of gsr_count_reach, i.e. reach records.
-char tile_sort_mode(int tiles_x, int tiles_y, bool have_records) {
+//   't': two-level partition (tile_partition2.hip): grids above 16384 tiles given ONE count per
+//        Gaussian (num_bands == 1) and the reach records
+char tile_sort_mode(int tiles_x, int tiles_y, bool have_records, int num_bands) {
   static const char forced = [] {
     const char *e = getenv("GSR_TILE_SORT");
     return e ? e[0] : '\0';
   }();
   if (forced == 'r' || forced == 'm') return forced;
   const int bands = gsr_tile_band_rows(tiles_x, tiles_y, nullptr);
-  return (bands == 1 || (bands > 1 && have_records)) ? 's' : 'r';
+  if (forced == 't' && have_records && num_bands == 1 && gsr_tile_partition2_supported(tiles_x, tiles_y)) return 't';
+  if (bands == 1) return 's';
+  if (!have_records) return 'r';
+  if (num_bands == 1) return gsr_tile_partition2_supported(tiles_x, tiles_y) ? 't' : 'r';
+  return bands > 1 ? 's' : 'r';
 }
 
-GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_intersects, int tiles_x, int tiles_y) {
+GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_points, int num_intersects, int tiles_x, int tiles_y) {
   if (num_intersects <= 0) return 0;
   int rpb = 0;
   const int bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
   const size_t scatter = bands > 0 ? gsr_tile_scatter_workspace_bytes(num_intersects, rpb * tiles_x, bands) : 0;
-  return 3 * align_up(4 * (size_t)num_intersects) +
-         align_up(std::max({tile_sort_temp(num_intersects), gsr_sort_mid_workspace_bytes(num_intersects), scatter}));
+  const size_t two_level = gsr_tile_partition2_supported(tiles_x, tiles_y)
+                               ? gsr_tile_partition2_workspace_bytes(num_points, num_intersects, tiles_x, tiles_y)
+                               : 0;
+  return std::max(two_level,
+                  3 * align_up(4 * (size_t)num_intersects) +
+                      align_up(std::max({tile_sort_temp(num_intersects), gsr_sort_mid_workspace_bytes(num_intersects),
+                                         scatter})));
 }
 
 namespace {
@@ -443,7 +395,7 @@ namespace {
 // `num_intersects` is the capacity the caller sized its buffers for
 int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const int32_t *order,
                     const int32_t *cum_sorted, const float *xys, const int32_t *radii,
-                    const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
+                    const void *reach_records, int tiles_x, int tiles_y, unsigned block_width, int num_bands,
                     int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *count_out, int32_t *slot_of_entry,
                     void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0 && num_intersects >= 0, "bin_sorted: negative size");
@@ -454,15 +406,16 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   GSR_REQUIRE(tiles_x <= 65535 && tiles_y <= 65535, "bin_sorted: tile grid too large");
   hipStream_t s = (hipStream_t)stream;
   const int num_tiles = tiles_x * tiles_y;
-  const char mode = tile_sort_mode(tiles_x, tiles_y, reach_records != nullptr);
-  GSR_REQUIRE(!device_sized || mode == 's',
-              "bin_sorted_dev: needs the single-pass tile scatter (<= 16384 tiles, or reach records)");
+  const char mode = tile_sort_mode(tiles_x, tiles_y, reach_records != nullptr, num_bands);
+  GSR_REQUIRE(!device_sized || mode == 's' || mode == 't',
+              "bin_sorted_dev: needs the tile scatter / two-level partition (<= 16384 tiles, or reach records)");
   GSR_REQUIRE(slot_of_entry == nullptr || mode == 's', "bin_sorted: slot_of_entry needs the single-pass tile scatter");
   int rpb = tiles_y, bands = 1;
-  if (reach_records) {
+  if (reach_records && num_bands > 1) {
     bands = gsr_tile_band_rows(tiles_x, tiles_y, &rpb);
     if (bands < 1) bands = 1, rpb = tiles_y;
   }
+  GSR_REQUIRE(num_bands == bands, "bin_sorted: num_bands must be 1 or gsr_tile_bands() (with reach records)");
   const bool nothing = num_points == 0 || num_intersects == 0;
   if (nothing || mode != 's') {  // the scatter path writes every entry of tile_bins itself
     hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
@@ -471,11 +424,14 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   }
   if (num_points == 0 || num_intersects == 0) return GSR_OK;
   GSR_REQUIRE(order && cum_sorted && xys && radii && gaussian_ids_sorted && workspace, "bin_sorted: null pointer");
-  const size_t need = gsr_bin_sorted_workspace_bytes(num_intersects, tiles_x, tiles_y);
+  const size_t need = gsr_bin_sorted_workspace_bytes(num_points, num_intersects, tiles_x, tiles_y);
   if (workspace_bytes < need) {
     gsr_set_error("bin_sorted: workspace %zu < %zu bytes", workspace_bytes, need);
     return GSR_ENOMEM;
   }
+  if (mode == 't')  // large grid, one count per Gaussian: row-partitioned emission + per-row column partition
+    return gsr_tile_partition2(num_points, num_intersects, order, reach_records, tiles_x, tiles_y,
+                               gaussian_ids_sorted, tile_bins, count_out, workspace, workspace_bytes, s);
   char *ws = static_cast<char *>(workspace);
   const size_t ib = align_up(4 * (size_t)num_intersects);
   unsigned *tile_in = reinterpret_cast<unsigned *>(ws);
@@ -513,21 +469,21 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
 GSR_EXPORT int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                               const int32_t *cum_sorted, const float *xys, const int32_t *radii,
                               const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
-                              int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *slot_of_entry,
-                              void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
+                              int num_bands, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                              int32_t *slot_of_entry, void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
   return bin_sorted_impl(false, num_points, num_intersects, order, cum_sorted, xys, radii, reach_records, tiles_x,
-                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, nullptr, slot_of_entry, workspace,
-                         workspace_bytes, stream);
+                         tiles_y, block_width, num_bands, gaussian_ids_sorted, tile_bins, nullptr, slot_of_entry,
+                         workspace, workspace_bytes, stream);
 }
 
 GSR_EXPORT int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
                                   const int32_t *cum_sorted, const float *xys, const int32_t *radii,
                                   const void *reach_records, int tiles_x, int tiles_y, unsigned block_width,
-                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins, int32_t *count_out,
-                                  int32_t *slot_of_entry, void *workspace, size_t workspace_bytes,
-                                  gsr_stream_t stream) {
+                                  int num_bands, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                                  int32_t *count_out, int32_t *slot_of_entry, void *workspace,
+                                  size_t workspace_bytes, gsr_stream_t stream) {
   GSR_REQUIRE(capacity > 0 && num_points > 0, "bin_sorted_dev: capacity and num_points must be positive");
   return bin_sorted_impl(true, num_points, capacity, order, cum_sorted, xys, radii, reach_records, tiles_x,
-                         tiles_y, block_width, gaussian_ids_sorted, tile_bins, count_out, slot_of_entry, workspace,
-                         workspace_bytes, stream);
+                         tiles_y, block_width, num_bands, gaussian_ids_sorted, tile_bins, count_out, slot_of_entry,
+                         workspace, workspace_bytes, stream);
 }

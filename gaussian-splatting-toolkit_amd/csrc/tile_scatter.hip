@@ -378,6 +378,14 @@ inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace gsr_ts
 
+// exclusive prefix over per-tile counts (in place) + tile_bins, for tile_partition2.hip
+int gsr_tile_bases(int num_tiles, unsigned *totals, int *tile_bins, hipStream_t s) {
+  hipLaunchKernelGGL(gsr_ts::bases_kernel, dim3(1), dim3(1024), 0, s, 1, num_tiles, num_tiles, num_tiles, totals,
+                     tile_bins);
+  GSR_CHECK_LAUNCH("tile_bases");
+  return GSR_OK;
+}
+
 // ---- internal interface used by binning_fast.hip ---------------------------
 // Number of tile-row bands for a tile grid, and the tile rows per band.  One band up to
 // 16384 tiles; above, bands of whole tile rows holding <= 8192 tiles.  0 = unsupported

@@ -284,11 +284,12 @@ def publish_int32(src: Tensor, dst: Tensor) -> None:
 
 
 def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
-                tile_bounds: Tuple[int, int, int]) -> Tuple[Tensor, Tensor]:
+                tile_bounds: Tuple[int, int, int], bands: int = 1) -> Tuple[Tensor, Tensor]:
     """``gsr_count_reach``: per Gaussian, the number of 16x16 tiles of its bounding
-    box in which it can reach alpha >= 1/255 -> (counts i32[B*N], band-major, summing to
-    <= num_tiles_hit per Gaussian, B = :func:`tile_bands`; opaque per-Gaussian records for
-    :func:`bin_sorted`)."""
+    box in which it can reach alpha >= 1/255 -> (counts i32[bands*N], band-major, summing to
+    <= num_tiles_hit per Gaussian; opaque per-Gaussian records for :func:`bin_sorted`).
+    ``bands``: 1 (default: one count per Gaussian; large grids then take the two-level
+    partition) or :func:`tile_bands` (tile-row bands: needed for ``want_slots``)."""
     _check(xys, "xys", _f32)
     _check(radii, "radii", _i32)
     _check(conics, "conics", _f32)
@@ -298,10 +299,11 @@ def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
         raise RuntimeError("count_reach: xys [N,2], conics [N,3], opacities [N,1] expected")
     dev = xys.device
     with torch.cuda.device(dev):
-        counts = torch.empty((tile_bands(tile_bounds) * n,), dtype=_i32, device=dev)
+        counts = torch.empty((int(bands) * n,), dtype=_i32, device=dev)
         recs = torch.empty((n, int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
         _call("gsr_count_reach", C.c_int(n), _ptr(xys), _ptr(radii), _ptr(conics), _ptr(opacities),
-              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(counts), _ptr(recs), _stream(dev))
+              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_int(int(bands)), _ptr(counts), _ptr(recs),
+              _stream(dev))
     return counts, recs
 
 
@@ -336,13 +338,14 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     with torch.cuda.device(dev):
         ids = torch.empty((I,), dtype=_i32, device=dev)
         tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
-        nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(I), C.c_int(tile_bounds[0]),
-                                                           C.c_int(tile_bounds[1])))
+        nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(int(num_points)), C.c_int(I),
+                                                           C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
+        bands = cum_sorted.numel() // max(int(num_points), 1) if int(num_points) else 1
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         slots = torch.empty((I,), dtype=_i32, device=dev) if want_slots else None
         head = (C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted), _ptr(xys), _ptr(radii),
                 _ptr(reach_records) if reach_records is not None else None, C.c_int(tile_bounds[0]),
-                C.c_int(tile_bounds[1]), C.c_uint(block_width), _ptr(ids), _ptr(tile_bins))
+                C.c_int(tile_bounds[1]), C.c_uint(block_width), C.c_int(bands), _ptr(ids), _ptr(tile_bins))
         tail = (_ptr(slots) if want_slots else None, _ptr(ws), C.c_size_t(nbytes), _stream(dev))
         if device_sized:
             _call("gsr_bin_sorted_dev", *head, _ptr(count_out) if count_out is not None else None, *tail)
@@ -376,12 +379,22 @@ def deep_tile_threshold(list_entries: int, num_tiles: int) -> int:
     (10 % of the tiles ~10x deeper): forward 357 -> 320 us, backward 664 -> 625 us; factors
     0.8-1.5 within 3 % of each other, 0.3 (nearly every tile split) 1.7x slower; no effect
     on the uniform scene (nothing above the threshold; the idle workgroups cost < 1 %)."""
-    import os
-
-    factor = float(os.environ.get("GSR_DEEP_FACTOR", "1.2"))
+    factor, floor = _deep_knobs()
     if factor <= 0 or num_tiles <= 0:
         return 0
-    return max(int(os.environ.get("GSR_DEEP_MIN", "1024")), int(factor * list_entries / num_tiles))
+    return max(floor, int(factor * list_entries / num_tiles))
+
+
+_deep_cache = {}
+
+
+def _deep_knobs():
+    # (read once: two environment look-ups per compositing call are measurable on small scenes)
+    if not _deep_cache:
+        import os
+
+        _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "1024")))
+    return _deep_cache["v"]
 
 
 def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,

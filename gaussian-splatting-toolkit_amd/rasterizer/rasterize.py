@@ -274,14 +274,16 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
     # compute_cumulative_intersects + bin_and_sort_gaussians (bit for bit
     # when not `exact`: tests/test_gpu_kernels.py::
     # test_fused_binning_equals_reference_pipeline)
+    # deterministic backward: keep the inverse of the scatter and the depth order (block_width 16
+    # with the exact lists, i.e. the single-pass scatter path -- on grids above 16384 tiles that
+    # is the banded one; otherwise such grids take the two-level partition, bands = 1)
+    det = _deterministic["on"] and exact and os.environ.get("GSR_TILE_SORT", "s")[:1] not in ("r", "m")
     tiles, records = num_tiles_hit, None
     if exact:
-        tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds)
+        banded = det or os.environ.get("GSR_TILE_SORT", "")[:1] == "b"
+        tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds,
+                                        bands=_C.tile_bands(tile_bounds) if banded else 1)
     order, cum_sorted = _C.depth_order(depths, radii, tiles)
-
-    # deterministic backward: keep the inverse of the scatter and the depth order (block_width 16
-    # with the exact lists, i.e. the single-pass scatter path)
-    det = _deterministic["on"] and exact and os.environ.get("GSR_TILE_SORT", "s")[:1] not in ("r", "m")
 
     def build(count, device_sized=False):
         out = _C.bin_sorted(num_points, count, order, cum_sorted, xys, radii, tile_bounds, block_width, records,

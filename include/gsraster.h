@@ -154,29 +154,35 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  * With reach_records == NULL gsr_bin_sorted reproduces the reference's lists
  * bit for bit.
  *
- * Tile-row bands.  Tile grids above 16384 tiles (4K at 16 px: 240 x 135) are
- * binned in gsr_tile_bands(tiles_x, tiles_y) bands of whole tile rows (1 for
- * smaller grids): gsr_count_reach then writes counts[bands, n] (band-major),
- * gsr_depth_order scans them in (band, depth) order into cum_sorted[bands * n]
- * (cum_sorted[bands * n - 1] = number of list entries), and gsr_bin_sorted(_dev)
- * -- which needs the reach records for such grids -- partitions band by band. */
+ * Large tile grids (above 16384 tiles; 4K at 16 px: 240 x 135) need the reach
+ * records and are built in one of two ways, chosen by `num_bands` of
+ * gsr_count_reach / gsr_depth_order / gsr_bin_sorted(_dev):
+ *   num_bands = 1 (default of the Python package): TWO-LEVEL PARTITION -- the entries
+ *     are emitted straight into per-tile-row segments and each row is then split by
+ *     tile column, every store coalesced (csrc/tile_partition2.hip);
+ *   num_bands = gsr_tile_bands(tiles_x, tiles_y) (4 at 4K): TILE-ROW BANDS -- the
+ *     single-pass scatter band by band: gsr_count_reach writes counts[bands, n]
+ *     (band-major), gsr_depth_order scans them in (band, depth) order into
+ *     cum_sorted[bands * n]; slower on large lists, but hands out slot_of_entry
+ *     (deterministic backward).
+ * Grids up to 16384 tiles: num_bands = 1, the single-pass scatter. */
 size_t gsr_reach_record_bytes(void);
 int gsr_tile_bands(int tiles_x, int tiles_y);
 int gsr_count_reach(int num_points, const float *xys, const int32_t *radii,
                     const float *conics, const float *opacities, int tiles_x,
-                    int tiles_y, int32_t *counts, void *reach_records,
-                    gsr_stream_t stream);
+                    int tiles_y, int num_bands, int32_t *counts,
+                    void *reach_records, gsr_stream_t stream);
 size_t gsr_depth_order_workspace_bytes(int num_points, int num_bands);
 int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
                     const int32_t *num_tiles_hit, int num_bands,
                     int32_t *order, int32_t *cum_sorted, void *workspace,
                     size_t workspace_bytes, gsr_stream_t stream);
-size_t gsr_bin_sorted_workspace_bytes(int num_intersects, int tiles_x,
-                                      int tiles_y);
+size_t gsr_bin_sorted_workspace_bytes(int num_points, int num_intersects,
+                                      int tiles_x, int tiles_y);
 int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                    const int32_t *cum_sorted, const float *xys,
                    const int32_t *radii, const void *reach_records, int tiles_x,
-                   int tiles_y, unsigned block_width,
+                   int tiles_y, unsigned block_width, int num_bands,
                    int32_t *gaussian_ids_sorted, int32_t *tile_bins,
                    int32_t *slot_of_entry, void *workspace,
                    size_t workspace_bytes, gsr_stream_t stream);
@@ -203,8 +209,9 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
                        const int32_t *cum_sorted, const float *xys,
                        const int32_t *radii, const void *reach_records,
                        int tiles_x, int tiles_y, unsigned block_width,
-                       int32_t *gaussian_ids_sorted, int32_t *tile_bins,
-                       int32_t *count_out, int32_t *slot_of_entry,
+                       int num_bands, int32_t *gaussian_ids_sorted,
+                       int32_t *tile_bins, int32_t *count_out,
+                       int32_t *slot_of_entry,
                        void *workspace, size_t workspace_bytes,
                        gsr_stream_t stream);
 

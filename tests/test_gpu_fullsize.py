@@ -318,14 +318,21 @@ def test_config5_full_size_binning_properties_and_equals_reference_pipeline(c5):
     tb = ((W + 15) // 16, (H + 15) // 16, 1)
     bands = C.tile_bands(tb)
     assert bands == 4
-    cnt_bands, recs = C.count_reach(c5["xys"], c5["radii"], c5["conics"], c5["opac"], tb)
-    cnt = cnt_bands.view(bands, n).sum(0)
-    assert bool((cnt <= c5["tiles"]).all())
-    order, cum = C.depth_order(c5["depths"], c5["radii"], cnt_bands)
+    # the default large-grid path: one count per Gaussian, two-level partition
+    cnt, recs = C.count_reach(c5["xys"], c5["radii"], c5["conics"], c5["opac"], tb)
+    assert cnt.shape == (n,) and bool((cnt <= c5["tiles"]).all())
+    order, cum = C.depth_order(c5["depths"], c5["radii"], cnt)
     I2 = int(cum[-1].item())
     I = int(c5["tiles"].to(torch.int64).sum().item())
     assert 0.3 * I < I2 < 0.7 * I, (I, I2)
     ids, bins = C.bin_sorted(n, I2, order, cum, c5["xys"], c5["radii"], tb, 16, recs)
+    # ... equals the tile-row-band path (single-pass scatter band by band)
+    cnt_b, recs_b = C.count_reach(c5["xys"], c5["radii"], c5["conics"], c5["opac"], tb, bands=bands)
+    assert torch.equal(cnt_b.view(bands, n).sum(0).to(torch.int32), cnt)
+    order_b, cum_b = C.depth_order(c5["depths"], c5["radii"], cnt_b)
+    ids_b, bins_b = C.bin_sorted(n, I2, order_b, cum_b, c5["xys"], c5["radii"], tb, 16, recs_b)
+    assert torch.equal(ids_b, ids) and torch.equal(bins_b, bins)
+    del ids_b, bins_b, cnt_b, recs_b, order_b, cum_b
     # the ranges tile [0, I2) in tile order
     lens = (bins[:, 1] - bins[:, 0]).to(torch.int64)
     assert int(lens.sum().item()) == I2 and bool((lens >= 0).all())

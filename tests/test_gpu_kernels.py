@@ -422,9 +422,16 @@ def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
     I = int(cum[-1].item())
     ids_ref, bins_ref = C.bin_sorted(n, I, order, cum, g["xys"], g["radii"], tb, bw)
     # exact lists
-    cnt_bands, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
-    bands = C.tile_bands(tb)
-    assert bands == (1 if tb[0] * tb[1] <= 16384 else -(-tb[1] // (8192 // tb[0])))
+    # grids above 16384 tiles: two-level partition (one count per Gaussian) AND tile-row bands
+    nb = C.tile_bands(tb)
+    assert nb == (1 if tb[0] * tb[1] <= 16384 else -(-tb[1] // (8192 // tb[0])))
+    if nb > 1:
+        cnt1, recs1 = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)  # bands = 1
+        o1, c1 = C.depth_order(g["depths"], g["radii"], cnt1)
+        I1 = int(c1[-1].item())
+        two_level = C.bin_sorted(n, I1, o1, c1, g["xys"], g["radii"], tb, bw, recs1)
+    cnt_bands, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb, bands=nb)
+    bands = nb
     assert cnt_bands.shape == (bands * n,) and (cnt_bands >= 0).all()
     cnt = cnt_bands.view(bands, n).sum(0).to(torch.int32)
     assert (cnt <= g["tiles"]).all()
@@ -435,6 +442,17 @@ def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
     I2 = int(cum2[-1].item())
     assert 0 < I2 < I
     ids_ex, bins_ex = C.bin_sorted(n, I2, order2, cum2, g["xys"], g["radii"], tb, bw, recs)
+    if nb > 1:  # both large-grid paths build the very same lists
+        assert I1 == I2 and torch.equal(two_level[0], ids_ex) and torch.equal(two_level[1], bins_ex)
+        cap = torch.zeros(1, dtype=torch.int32).pin_memory()
+        ids_c, bins_c = C.bin_sorted(n, I1 + 5000, o1, c1, g["xys"], g["radii"], tb, bw, recs1, device_sized=True,
+                                     count_out=cap)
+        torch.cuda.synchronize()
+        assert int(cap[0]) == I1 and torch.equal(ids_c[:I1], ids_ex) and torch.equal(bins_c, bins_ex)
+        ids_s, bins_s = C.bin_sorted(n, I1 // 3, o1, c1, g["xys"], g["radii"], tb, bw, recs1, device_sized=True,
+                                     count_out=cap)
+        torch.cuda.synchronize()
+        assert int(cap[0]) == I1 and int(bins_s.max()) <= I1 // 3  # cut memory-safely
     # device-sized variant: capacity instead of the exact length, count handed back through
     # device-accessible (pinned host) memory; a capacity that is too small cuts the lists
     if True:
@@ -577,7 +595,7 @@ def test_deterministic_backward_is_bit_reproducible_and_equals_the_atomic_one(W,
     cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
     tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
     g = dict(xys=cu(xys), depths=cu(depths), radii=cu(radii), conics=cu(conics), opac=cu(sc["opacities"]))
-    cnt, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
+    cnt, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb, bands=C.tile_bands(tb))
     order, cum = C.depth_order(g["depths"], g["radii"], cnt)
     I = int(cum[-1].item())
     ids, bins, slots = C.bin_sorted(n, I + 4096, order, cum, g["xys"], g["radii"], tb, bw, recs, device_sized=True,

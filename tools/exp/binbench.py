@@ -49,7 +49,8 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / iters * 1e3, out
 
-    t_cnt, (cnt, recs) = timed(lambda: C.count_reach(xys, radii, conics, opac, tb))
+    nb = C.tile_bands(tb) if os.environ.get("BANDED") else 1
+    t_cnt, (cnt, recs) = timed(lambda: C.count_reach(xys, radii, conics, opac, tb, bands=nb))
     t_ord, (order, cum) = timed(lambda: C.depth_order(depths, radii, cnt))
     I = int(cum[-1].item())
     t_bin, _ = timed(lambda: C.bin_sorted(n, I, order, cum, xys, radii, tb, 16, recs))
