@@ -8,14 +8,16 @@
 // entries, with 8x write amplification.  Here no entry is ever written alone:
 //
 //   level A, by tile ROW, fused into the emission (no intermediate depth-ordered stream):
-//     P1 rowcount   one wave per 64 Gaussians in depth order: entries per tile row ->
-//                   tableC[wave][row]
+//     P1 rowcount   one workgroup per SLAB of 256 Gaussians in depth order: entries per tile
+//                   row -> tableC[slab][row]
 //     P2 rowscan    exclusive prefix of every row's column of that table (two small
 //                   kernels), row starts, per-row chunk starts, the total count
-//     P3 emit       the same walk again; the wave sorts its (Gaussian, row) items by row in
-//                   LDS and writes each row's entries -- (tile column, Gaussian id) -- as
-//                   ONE contiguous run at row_start + prefix, lanes owning consecutive
-//                   addresses.  Within a row the stream stays in depth order.
+//     P3 emit       the same walk again; the workgroup sorts its (Gaussian, row) items by row
+//                   in LDS (1024 at a time) and writes each row's entries -- (tile column,
+//                   Gaussian id) -- as ONE contiguous run at row_start + prefix, threads
+//                   owning consecutive addresses.  Within a row the stream stays in depth
+//                   order.  (First version: one wave per 64 Gaussians, 256 items at a time --
+//                   runs of ~9 entries, i.e. partial-line writes again, and 13 waves per CU.)
 //   level B, by tile COLUMN inside each row (<= 1024 tiles: counters and tables are tiny):
 //     P4 colhist    per 4096-entry chunk of a row's segment: histogram over the columns
 //     P5 colscan    per (row, column): prefix down the row's chunks, tile totals
@@ -36,87 +38,104 @@ int gsr_tile_bases(int num_tiles, unsigned *totals, int *tile_bins, hipStream_t 
 
 namespace gsr_p2 {
 
-constexpr int kGroup = 256;    // waves per scan group
-constexpr int kItems = 256;    // (Gaussian, row) items sorted per batch in P3
-constexpr int kMaskBlocks = 128;  // batches of up to 32768 entries use the start masks (larger: binary search)
+constexpr int kSlab = 256;     // Gaussians per workgroup of P1 / P3
+constexpr int kGroup = 64;     // slabs per scan group
+constexpr int kItems = 1024;   // (Gaussian, row) items sorted per batch in P3
+constexpr int kMaskBlocks = 256;  // batches of up to 16384 entries use the start masks (larger: binary search)
 constexpr int kChunk = 4096;   // entries per level-B chunk
 constexpr int kMaxDim = 1024;  // tile rows / columns supported
 
 struct Dims {
-  int n, waves, groups, tiles_x, tiles_y, txp;  // txp: padded tiles_x (row stride of tableB)
+  int n, slabs, groups, tiles_x, tiles_y, txp;  // txp: padded tiles_x (row stride of tableB)
 };
 
-// the wave's 64 Gaussians (depth order) and the prefix of their box heights: shared by P1 / P3
-struct WaveItems {
-  int pref[64];  // inclusive prefix of the box heights (rows) over the lanes
-  int gid[64];
-  SplatRec rec[64];
-  RowParams par[64];
+// the slab's 256 Gaussians (depth order) and the prefix of their box heights: shared by P1 / P3
+struct SlabItems {
+  int pref[kSlab];  // inclusive prefix of the box heights (rows) over the threads
+  int gid[kSlab];
+  SplatRec rec[kSlab];
+  RowParams par[kSlab];
 };
 
-__device__ __forceinline__ int load_wave(WaveItems &W, const int lane, const int i, const int n,
+// exclusive prefix of v over the 256 threads of the workgroup (and the total); two barriers
+__device__ __forceinline__ int block_excl(const int v, int *__restrict__ wsum, int &total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int k = 0; k < w; ++k) base += wsum[k];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + incl - v;
+}
+
+__device__ __forceinline__ int load_slab(SlabItems &W, int *__restrict__ wsum, const int i, const int n,
                                          const int *__restrict__ order, const SplatRec *__restrict__ recs) {
+  const int tid = threadIdx.x;
   SplatRec rec{0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0u, 0u};
   int g = 0;
   if (i < n) {
     g = order[i];
     rec = recs[g];
   }
-  int incl = (int)(rec.box1 >> 16);
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o);
-    if (lane >= o) incl += t;
-  }
-  W.pref[lane] = incl;
-  W.gid[lane] = g;
-  W.rec[lane] = rec;
-  W.par[lane] = make_row_params(rec);
-  return __shfl(incl, 63);
+  const int h = (int)(rec.box1 >> 16);
+  int total;
+  W.pref[tid] = block_excl(h, wsum, total) + h;
+  W.gid[tid] = g;
+  W.rec[tid] = rec;
+  W.par[tid] = make_row_params(rec);
+  __syncthreads();
+  return total;
 }
 
-// item q of the wave -> owner lane k, tile row, tile range [t0, t1)
-__device__ __forceinline__ void item_of(const WaveItems &W, const int q, const int total, int &k, int &ty, int &t0,
+// item q of the slab -> owner thread k, tile row, tile range [t0, t1)
+__device__ __forceinline__ void item_of(const SlabItems &W, const int q, const int total, int &k, int &ty, int &t0,
                                         int &t1) {
   k = 0;
 #pragma unroll
-  for (int step = 32; step > 0; step >>= 1)
+  for (int step = kSlab / 2; step > 0; step >>= 1)
     if (W.pref[k + step - 1] <= q) k += step;
-  k = k < 63 ? k : 63;
+  k = k < kSlab - 1 ? k : kSlab - 1;
   const SplatRec r = W.rec[k];
   ty = (int)(r.box0 >> 16) + q - (k ? W.pref[k - 1] : 0);
   t0 = t1 = 0;
   if (q < total) row_range(r, W.par[k], ty, t0, t1);
 }
 
-// ---- P1: entries per (wave, tile row) ----------------------------------------------------
-__global__ __launch_bounds__(64) void rowcount_kernel(const Dims D, const int *__restrict__ order,
-                                                      const SplatRec *__restrict__ recs, int *__restrict__ tableC) {
-  __shared__ WaveItems W;
+// ---- P1: entries per (slab, tile row) ----------------------------------------------------
+__global__ __launch_bounds__(kSlab) void rowcount_kernel(const Dims D, const int *__restrict__ order,
+                                                         const SplatRec *__restrict__ recs, int *__restrict__ tableC) {
+  __shared__ SlabItems W;
+  __shared__ int wsum[4];
   extern __shared__ int rowcnt[];  // [tiles_y]
-  const int lane = threadIdx.x, wave = blockIdx.x;
-  const int total = load_wave(W, lane, wave * 64 + lane, D.n, order, recs);
-  for (int r = lane; r < D.tiles_y; r += 64) rowcnt[r] = 0;
-  __syncthreads();
-  for (int q0 = 0; q0 < total; q0 += 64) {
+  const int tid = threadIdx.x, slab = blockIdx.x;
+  for (int r = tid; r < D.tiles_y; r += kSlab) rowcnt[r] = 0;
+  const int total = load_slab(W, wsum, slab * kSlab + tid, D.n, order, recs);
+  for (int q = tid; q < total; q += kSlab) {
     int k, ty, t0, t1;
-    item_of(W, q0 + lane, total, k, ty, t0, t1);
+    item_of(W, q, total, k, ty, t0, t1);
     if (t1 > t0) atomicAdd(&rowcnt[ty], t1 - t0);
   }
   __syncthreads();
-  int *out = tableC + (size_t)wave * D.tiles_y;
-  for (int r = lane; r < D.tiles_y; r += 64) out[r] = rowcnt[r];
+  int *out = tableC + (size_t)slab * D.tiles_y;
+  for (int r = tid; r < D.tiles_y; r += kSlab) out[r] = rowcnt[r];
 }
 
-// ---- P2a: per (group of 1024 waves, block of 64 rows): exclusive prefix down the waves -----
+// ---- P2a: per (group of 64 slabs, block of 64 rows): exclusive prefix down the slabs -------
 // Lane l of every wave owns row r0 + l (coalesced 256-byte reads along a table row); the four
-// waves of the workgroup take a quarter of the group's waves each.
+// waves of the workgroup take a quarter of the group's slabs each.
 __global__ __launch_bounds__(256) void rowscan1_kernel(const Dims D, const int *__restrict__ tableC,
                                                        int *__restrict__ tableA, int *__restrict__ gtot) {
   __shared__ int part[4][64];
   const int grp = blockIdx.x, row = blockIdx.y * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   const int w_beg = grp * kGroup + q * (kGroup / 4);
-  const int w_end = min(w_beg + kGroup / 4, D.waves);
+  const int w_end = min(w_beg + kGroup / 4, D.slabs);
   const bool live = row < D.tiles_y;
   int sum = 0;
   if (live)
@@ -132,7 +151,7 @@ __global__ __launch_bounds__(256) void rowscan1_kernel(const Dims D, const int *
       tableA[at] = run;
       run += v;
     }
-    if (q == 3) gtot[(size_t)row * D.groups + grp] = run;  // run = the group's total for this row
+    if (q == 3) gtot[(size_t)grp * D.tiles_y + row] = run;  // run = the group's total for this row
   }
 }
 
@@ -145,10 +164,22 @@ __global__ __launch_bounds__(1024) void rowscan2_kernel(const Dims D, const int 
   // thread r: exclusive prefix over the groups of row r (in place) and the row's total
   int rt = 0;
   if (tid < D.tiles_y) {
-    int *g = gtot + (size_t)tid * D.groups;
-    for (int k = 0; k < D.groups; ++k) {
-      const int v = g[k];
-      g[k] = rt;
+    int *g = gtot + tid;  // [group][row]: the threads of a wave read consecutive rows
+    const size_t st = (size_t)D.tiles_y;
+    int k = 0;
+    for (; k + 8 <= D.groups; k += 8) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = g[(k + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        g[(k + u) * st] = rt;
+        rt += v[u];
+      }
+    }
+    for (; k < D.groups; ++k) {
+      const int v = g[k * st];
+      g[k * st] = rt;
       rt += v;
     }
   }
@@ -184,163 +215,180 @@ __global__ __launch_bounds__(1024) void rowscan2_kernel(const Dims D, const int 
 }
 
 // ---- P3: emission, row-partitioned --------------------------------------------------------
-// One wave; its (Gaussian, row) items are taken kItems at a time (in (Gaussian, row) order),
-// sorted stably by row in LDS, and every row's entries of the batch are written as one run.
-__global__ __launch_bounds__(64) void emit_kernel(const Dims D, const int capacity, const int *__restrict__ order,
-                                                  const SplatRec *__restrict__ recs, const int *__restrict__ tableA,
-                                                  const int *__restrict__ gbase, const int *__restrict__ row_start,
-                                                  unsigned short *__restrict__ tx_out, int *__restrict__ gid_out) {
-  __shared__ WaveItems W;
+// One workgroup per slab; its (Gaussian, row) items are taken kItems at a time (in (Gaussian,
+// row) order), sorted stably by row in LDS, and every row's entries of the batch are written as
+// one run.  The sort ranks like P7 below: every wave ranks its own contiguous quarter of the
+// batch with wave-private row counters, one prefix over (row, wave) later every item has its slot.
+__global__ __launch_bounds__(kSlab) void emit_kernel(const Dims D, const int capacity, const int *__restrict__ order,
+                                                     const SplatRec *__restrict__ recs, const int *__restrict__ tableA,
+                                                     const int *__restrict__ gbase, const int *__restrict__ row_start,
+                                                     unsigned short *__restrict__ tx_out, int *__restrict__ gid_out) {
+  constexpr int kR = kItems / kSlab;     // items per thread and batch
+  __shared__ SlabItems W;
   __shared__ unsigned it_a[kItems];      // row | t0 << 16
-  __shared__ unsigned it_b[kItems];      // count | owner lane << 16
+  __shared__ unsigned it_b[kItems];      // count | owner thread << 16
   __shared__ unsigned short sorted[kItems];
   __shared__ int sout[kItems + 1];       // entry offset (within the batch) of sorted item s
   // start masks: bit e & 63 of word e >> 6 is set where a sorted item's first entry sits; the item
   // that owns entry e is (#starts at or before e) - 1: two popcounts instead of a binary search
   __shared__ unsigned long long smask[kMaskBlocks];
   __shared__ int blkfirst[kMaskBlocks];  // starts before the block
-  extern __shared__ int rows_lds[];      // 4 arrays of tiles_y ints
-  int *bcnt = rows_lds, *bcur = bcnt + D.tiles_y, *bent = bcur + D.tiles_y, *gcur = bent + D.tiles_y;
-  const int lane = threadIdx.x, wave = blockIdx.x;
+  __shared__ int wsum[4];
+  extern __shared__ int rows_lds[];      // 7 arrays of tiles_y ints
+  const int ny = D.tiles_y;
+  int *wcnt = rows_lds;                  // [4][ny] per-wave item counts of a row, then the waves' first slots
+  int *bent = wcnt + 4 * ny;             // first entry of the row within the batch
+  int *bentc = bent + ny;                // entries of the row in the batch
+  int *gcur = bentc + ny;                // the row's global cursor
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, slab = blockIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const int total = load_wave(W, lane, wave * 64 + lane, D.n, order, recs);
-  const int grp = wave / kGroup;
-  for (int r = lane; r < D.tiles_y; r += 64)
-    gcur[r] = row_start[r] + gbase[(size_t)r * D.groups + grp] + tableA[(size_t)wave * D.tiles_y + r];
-  __syncthreads();
+  const int grp = slab / kGroup;
+  for (int r = tid; r < ny; r += kSlab)
+    gcur[r] = row_start[r] + gbase[(size_t)grp * ny + r] + tableA[(size_t)slab * ny + r];
+  const int total = load_slab(W, wsum, slab * kSlab + tid, D.n, order, recs);
   int row_bits = 1;
-  while ((1 << row_bits) < D.tiles_y) ++row_bits;
+  while ((1 << row_bits) < ny) ++row_bits;
+  const int rp = (ny + kSlab - 1) / kSlab;  // rows per thread in the row scans (contiguous)
 
   for (int qa = 0; qa < total; qa += kItems) {
     const int nb = total - qa < kItems ? total - qa : kItems;
-    for (int r = lane; r < D.tiles_y; r += 64) bcnt[r] = 0, bent[r] = 0;
+    for (int r = tid; r < 4 * ny; r += kSlab) wcnt[r] = 0;
+    for (int r = tid; r < ny; r += kSlab) bentc[r] = 0;
     __syncthreads();
-    // 1. the batch's items, in item order
-    for (int i0 = 0; i0 < nb; i0 += 64) {
-      const int idx = i0 + lane;
+    // 1. the batch's items; wave w ranks items [w kItems/4, (w+1) kItems/4) by row, in item order
+    int rank[kR], myrow[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) {
+      const int idx = w * (kItems / 4) + r * 64 + lane;
       int k = 0, ty = 0, t0 = 0, t1 = 0;
       if (idx < nb) item_of(W, qa + idx, total, k, ty, t0, t1);
       const int cnt = t1 - t0;
       if (idx < nb) {
         it_a[idx] = (unsigned)ty | ((unsigned)t0 << 16);
         it_b[idx] = (unsigned)cnt | ((unsigned)k << 16);
-        if (cnt > 0) {
-          atomicAdd(&bcnt[ty], 1);
-          atomicAdd(&bent[ty], cnt);
-        }
       }
-    }
-    __syncthreads();
-    // 2. exclusive scans over the rows: items (-> bcur) and entries (-> bent, kept exclusive)
-    {
-      int carry_i = 0, carry_e = 0;
-      for (int r0 = 0; r0 < D.tiles_y; r0 += 64) {
-        const int r = r0 + lane;
-        const int ci = r < D.tiles_y ? bcnt[r] : 0, ce = r < D.tiles_y ? bent[r] : 0;
-        int ii = ci, ie = ce;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int a = __shfl_up(ii, o), b = __shfl_up(ie, o);
-          if (lane >= o) ii += a, ie += b;
-        }
-        if (r < D.tiles_y) {
-          bcur[r] = carry_i + ii - ci;
-          bent[r] = carry_e + ie - ce;  // exclusive: first entry of row r within the batch
-        }
-        carry_i += __shfl(ii, 63);
-        carry_e += __shfl(ie, 63);
-      }
-    }
-    __syncthreads();
-    // 3. stable placement by row: slot = cursor[row]++ in item order; lanes of one step that
-    //    share a row are ranked by lane (= item order) through wave-wide key matching
-    for (int i0 = 0; i0 < nb; i0 += 64) {
-      const int idx = i0 + lane;
-      const bool live = idx < nb && (it_b[idx < nb ? idx : 0] & 0xffffu) != 0;
-      const unsigned row = live ? (it_a[idx] & 0xffffu) : 0u;
+      const bool live = idx < nb && cnt > 0;
       unsigned long long peers = __ballot(live);
       for (int bit = 0; bit < row_bits; ++bit) {
-        const bool b = (row >> bit) & 1u;
+        const bool b = (ty >> bit) & 1;
         const unsigned long long set = __ballot(b);
         peers &= b ? set : ~set;
       }
-      if (live) {
-        const int rank = __popcll(peers & lt);
-        sorted[bcur[row] + rank] = (unsigned short)idx;
-      }
-      __syncthreads();
-      if (live && (peers & lt) == 0) bcur[row] += __popcll(peers);  // the group's first lane advances the cursor
-      __syncthreads();
-    }
-    // 4. entry offsets of the sorted items (items with no entries were not placed)
-    int nplaced = 0;
-    {
-      int carry = 0;
-      // number of placed items = bcur of the last row after placement = sum of bcnt
-      for (int r0 = 0; r0 < D.tiles_y; r0 += 64) {
-        const int r = r0 + lane;
-        int c = r < D.tiles_y ? bcnt[r] : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        nplaced += c;
-      }
-      for (int s0 = 0; s0 < nplaced; s0 += 64) {
-        const int s = s0 + lane;
-        const int c = s < nplaced ? (int)(it_b[sorted[s]] & 0xffffu) : 0;
-        int ic = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int a = __shfl_up(ic, o);
-          if (lane >= o) ic += a;
-        }
-        if (s < nplaced) sout[s] = carry + ic - c;
-        carry += __shfl(ic, 63);
-      }
-      if (lane == 0) sout[nplaced] = carry;
+      const int below = __popcll(peers & lt);
+      const int prev = live ? wcnt[w * ny + ty] : 0;  // every peer reads before the group's first lane writes
+      rank[r] = prev + below;
+      if (live && below == 0) wcnt[w * ny + ty] = prev + __popcll(peers);
+      if (live) atomicAdd(&bentc[ty], cnt);
+      myrow[r] = live ? ty : -1;
     }
     __syncthreads();
-    const int E = sout[nplaced];
+    // 2. prefix over (row, wave) of the item counts -> first slots; over the rows of the entries
+    int nplaced, E;
+    {
+      int ci = 0, ce = 0;
+      for (int j = 0; j < rp; ++j) {
+        const int r = tid * rp + j;
+        if (r < ny) {
+          ci += wcnt[r] + wcnt[ny + r] + wcnt[2 * ny + r] + wcnt[3 * ny + r];
+          ce += bentc[r];
+        }
+      }
+      int run_i = block_excl(ci, wsum, nplaced);
+      int run_e = block_excl(ce, wsum, E);
+      for (int j = 0; j < rp; ++j) {
+        const int r = tid * rp + j;
+        if (r < ny) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = wcnt[q * ny + r];
+            wcnt[q * ny + r] = run_i;
+            run_i += c;
+          }
+          bent[r] = run_e;
+          run_e += bentc[r];
+        }
+      }
+    }
+    __syncthreads();
+    // 3. placement
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+      if (myrow[r] >= 0) sorted[wcnt[w * ny + myrow[r]] + rank[r]] = (unsigned short)(w * (kItems / 4) + r * 64 + lane);
+    __syncthreads();
+    // 4. entry offsets of the sorted items (thread t: sorted items t kR .. t kR + kR - 1)
+    {
+      int c[kR], sum = 0;
+#pragma unroll
+      for (int j = 0; j < kR; ++j) {
+        const int sidx = tid * kR + j;
+        c[j] = sidx < nplaced ? (int)(it_b[sorted[sidx]] & 0xffffu) : 0;
+        sum += c[j];
+      }
+      int tot;
+      int run = block_excl(sum, wsum, tot);
+#pragma unroll
+      for (int j = 0; j < kR; ++j) {
+        const int sidx = tid * kR + j;
+        if (sidx < nplaced) sout[sidx] = run;
+        run += c[j];
+      }
+      if (tid == 0) sout[nplaced] = E;
+    }
     // 5. output-driven, coalesced: entry j of the batch belongs to sorted item s(j)
     const int nblk = (E + 63) >> 6;
     const bool use_masks = nblk <= kMaskBlocks;
     if (use_masks) {
-      for (int b = lane; b < nblk; b += 64) smask[b] = 0ull;
+      if (tid < nblk) smask[tid] = 0ull;
       __syncthreads();
-      for (int s0 = 0; s0 < nplaced; s0 += 64) {
-        const int s = s0 + lane;
-        if (s < nplaced) atomicOr(&smask[sout[s] >> 6], 1ull << (sout[s] & 63));
-      }
+      for (int sidx = tid; sidx < nplaced; sidx += kSlab) atomicOr(&smask[sout[sidx] >> 6], 1ull << (sout[sidx] & 63));
       __syncthreads();
-      int carry = 0;
-      for (int b0 = 0; b0 < nblk; b0 += 64) {
-        const int b = b0 + lane;
-        const int c = b < nblk ? __popcll(smask[b]) : 0;
-        int ic = c;
+      const int c = tid < nblk ? __popcll(smask[tid]) : 0;
+      int tot;
+      const int ex = block_excl(c, wsum, tot);
+      if (tid < nblk) blkfirst[tid] = ex;
+      __syncthreads();
+      // four independent entries per thread and step: the LDS look-up chain (mask -> item -> row
+      // cursors) is latency, not bandwidth
+      for (int j0 = 0; j0 < E; j0 += 4 * kSlab) {
+        int jj[4], lo[4];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int a = __shfl_up(ic, o);
-          if (lane >= o) ic += a;
+        for (int u = 0; u < 4; ++u) {
+          jj[u] = j0 + u * kSlab + tid;
+          const int jc = jj[u] < E ? jj[u] : E - 1;
+          lo[u] = blkfirst[jc >> 6] + __popcll(smask[jc >> 6] & ((2ull << (jc & 63)) - 1ull)) - 1;
         }
-        if (b < nblk) blkfirst[b] = carry + ic - c;
-        carry += __shfl(ic, 63);
-      }
-      __syncthreads();
-    }
-    for (int j0 = 0; j0 < E; j0 += 64) {
-      const int j = j0 + lane;
-      if (j < E) {
-        int lo;
-        if (use_masks) {
-          const unsigned long long m = smask[j0 >> 6];
-          lo = blkfirst[j0 >> 6] + __popcll(m & ((2ull << lane) - 1ull)) - 1;
-        } else {
-          lo = 0;
-          int hi = nplaced;  // last s with sout[s] <= j
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (sout[mid] <= j) lo = mid;
-            else hi = mid;
+        unsigned a[4], b[4];
+        int so[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int si = sorted[lo[u]];
+          a[u] = it_a[si];
+          b[u] = it_b[si];
+          so[u] = sout[lo[u]];
+        }
+        long long pos[4];
+        int gidv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int row = (int)(a[u] & 0xffffu);
+          pos[u] = (long long)gcur[row] + (jj[u] - bent[row]);
+          gidv[u] = W.gid[b[u] >> 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (jj[u] < E && pos[u] < capacity) {
+            tx_out[pos[u]] = (unsigned short)((int)(a[u] >> 16) + (jj[u] - so[u]));
+            gid_out[pos[u]] = gidv[u];
           }
+      }
+    } else {
+      __syncthreads();
+      for (int j = tid; j < E; j += kSlab) {
+        int lo = 0, hi = nplaced;  // last s with sout[s] <= j
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (sout[mid] <= j) lo = mid;
+          else hi = mid;
         }
         const unsigned a = it_a[sorted[lo]], b = it_b[sorted[lo]];
         const int row = (int)(a & 0xffffu), t0 = (int)(a >> 16), k = (int)(b >> 16);
@@ -352,20 +400,15 @@ __global__ __launch_bounds__(64) void emit_kernel(const Dims D, const int capaci
       }
     }
     __syncthreads();
-    // 6. advance the rows' global cursors by what the batch wrote (bent is exclusive: the next
-    //    row's start minus this row's start; recompute the counts from the items)
-    for (int s0 = 0; s0 < nplaced; s0 += 64) {
-      const int s = s0 + lane;
-      if (s < nplaced) {
-        const unsigned a = it_a[sorted[s]], b = it_b[sorted[s]];
-        atomicAdd(&gcur[a & 0xffffu], (int)(b & 0xffffu));
-      }
-    }
+    // 6. advance the rows' global cursors by what the batch wrote
+    for (int r = tid; r < ny; r += kSlab) gcur[r] += bentc[r];
     __syncthreads();
   }
 }
 
-// chunk c of the row-partitioned stream -> its row and its slice [beg, end)
+// chunk c of the row-partitioned stream -> its row and its slice [beg, end).  (Staging the
+// rows' chunk starts in LDS for the search was tried: the extra barrier cost more than the eight
+// dependent L2 hits it saved.)
 __device__ __forceinline__ bool chunk_slice(const Dims &D, const int capacity, const int c,
                                             const int *__restrict__ row_start,
                                             const int *__restrict__ row_chunk_start, int &row, int &beg, int &end) {
@@ -394,26 +437,50 @@ __global__ __launch_bounds__(256) void colhist_kernel(const Dims D, const int ca
   if (!chunk_slice(D, capacity, blockIdx.x, row_start, row_chunk_start, row, beg, end)) return;
   for (int t = threadIdx.x; t < D.txp; t += 256) h[t] = 0;
   __syncthreads();
-  for (int e = beg + threadIdx.x; e < end; e += 256) atomicAdd(&h[tx_in[e]], 1);
+  // four entries (8 bytes) per load, from the aligned group that holds `beg` on
+  const uint2 *in4 = reinterpret_cast<const uint2 *>(tx_in);
+  for (int g = (beg >> 2) + threadIdx.x; g * 4 < end; g += 256) {
+    const uint2 v = in4[g];
+    const int e = g * 4;
+    if (e >= beg && e < end) atomicAdd(&h[v.x & 0xffffu], 1);
+    if (e + 1 >= beg && e + 1 < end) atomicAdd(&h[v.x >> 16], 1);
+    if (e + 2 >= beg && e + 2 < end) atomicAdd(&h[v.y & 0xffffu], 1);
+    if (e + 3 >= beg && e + 3 < end) atomicAdd(&h[v.y >> 16], 1);
+  }
   __syncthreads();
   int *out = tableB + (size_t)blockIdx.x * D.txp;
   for (int t = threadIdx.x; t < D.txp; t += 256) out[t] = h[t];
 }
 
 // ---- P5: per (row, column): exclusive prefix down the row's chunks; tile totals -----------
+// Lane l of every wave owns column tx0 + l (coalesced reads along a table row); the four waves
+// of the workgroup take a quarter of the row's chunks each (sum, then prefix: the table is read
+// twice, but a row's ~180 chunks at config 5 are walked by four waves and the grid has 4x the
+// workgroups of one-thread-per-column).
 __global__ __launch_bounds__(256) void colscan_kernel(const Dims D, const int *__restrict__ row_chunk_start,
                                                       int *__restrict__ tableB, unsigned *__restrict__ tile_cnt) {
-  const int tx = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
-  if (tx >= D.tiles_x) return;
+  __shared__ int part[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int tx = blockIdx.x * 64 + lane, row = blockIdx.y;
   const int c0 = row_chunk_start[row], c1 = row_chunk_start[row + 1];
+  const int per = (c1 - c0 + 3) >> 2;
+  const int cb = min(c0 + q * per, c1), ce = min(cb + per, c1);
+  const bool live = tx < D.tiles_x;
+  int sum = 0;
+  if (live)
+    for (int c = cb; c < ce; ++c) sum += tableB[(size_t)c * D.txp + tx];
+  part[q][lane] = sum;
+  __syncthreads();
   int run = 0;
-  for (int c = c0; c < c1; ++c) {
+  for (int k = 0; k < q; ++k) run += part[k][lane];
+  if (!live) return;
+  for (int c = cb; c < ce; ++c) {
     int *p = tableB + (size_t)c * D.txp + tx;
     const int v = *p;
     *p = run;
     run += v;
   }
-  tile_cnt[(size_t)row * D.tiles_x + tx] = (unsigned)run;
+  if (q == 3) tile_cnt[(size_t)row * D.tiles_x + tx] = (unsigned)run;
 }
 
 // ---- P7: per chunk, rank by column in LDS (stream order kept), write runs -----------------
@@ -513,12 +580,14 @@ __global__ __launch_bounds__(256) void colscatter_kernel(const Dims D, const int
     }
   }
   __syncthreads();
+  // destination of ranked slot j of column t: tile base + the chunk's prefix + (j - loff[t]);
+  // the first three are folded into loff (one coalesced load per table instead of two L2
+  // look-ups per entry)
   const int *pre = tableB + (size_t)blockIdx.x * D.txp;
   const unsigned *tb = tile_base + (size_t)row * D.tiles_x;
-  for (int j = tid; j < cnt; j += 256) {
-    const int t = s_stx[j];
-    ids_out[tb[t] + (unsigned)pre[t] + (unsigned)(j - loff[t])] = s_gid[j];
-  }
+  for (int t = tid; t < D.tiles_x; t += 256) loff[t] = (int)(tb[t] + (unsigned)pre[t] - (unsigned)loff[t]);
+  __syncthreads();
+  for (int j = tid; j < cnt; j += 256) ids_out[(unsigned)loff[s_stx[j]] + (unsigned)j] = s_gid[j];
 }
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -535,12 +604,12 @@ inline Layout make_layout(const Dims &D, int capacity) {
     off += align_up(bytes);
     return o;
   };
-  L.tableC = take(4 * (size_t)D.waves * D.tiles_y);
-  L.tableA = take(4 * (size_t)D.waves * D.tiles_y);
+  L.tableC = take(4 * (size_t)D.slabs * D.tiles_y);
+  L.tableA = take(4 * (size_t)D.slabs * D.tiles_y);
   L.gtot = take(4 * (size_t)D.tiles_y * D.groups);
   L.row_start = take(4 * (size_t)(D.tiles_y + 1));
   L.row_chunk_start = take(4 * (size_t)(D.tiles_y + 1));
-  L.tx = take(2 * (size_t)capacity);
+  L.tx = take(2 * (size_t)capacity + 8);  // P4 reads whole groups of four
   L.gid = take(4 * (size_t)capacity);
   L.chunk_slots = capacity / kChunk + D.tiles_y + 1;
   L.tableB = take(4 * (size_t)L.chunk_slots * D.txp);
@@ -551,8 +620,8 @@ inline Layout make_layout(const Dims &D, int capacity) {
 inline Dims make_dims(int n, int tiles_x, int tiles_y) {
   Dims D;
   D.n = n;
-  D.waves = (n + 63) / 64;
-  D.groups = (D.waves + kGroup - 1) / kGroup;
+  D.slabs = (n + kSlab - 1) / kSlab;
+  D.groups = (D.slabs + kGroup - 1) / kGroup;
   D.tiles_x = tiles_x;
   D.tiles_y = tiles_y;
   D.txp = (tiles_x + 3) & ~3;
@@ -596,16 +665,16 @@ int gsr_tile_partition2(int n, int capacity, const int *order, const void *recs,
   int *gids = reinterpret_cast<int *>(ws + L.gid), *tableB = reinterpret_cast<int *>(ws + L.tableB);
   unsigned *tile_cnt = reinterpret_cast<unsigned *>(ws + L.tile_cnt);
   const SplatRec *R = static_cast<const SplatRec *>(recs);
-  hipLaunchKernelGGL(rowcount_kernel, dim3(D.waves), dim3(64), 4 * (size_t)tiles_y, s, D, order, R, tableC);
+  hipLaunchKernelGGL(rowcount_kernel, dim3(D.slabs), dim3(kSlab), 4 * (size_t)tiles_y, s, D, order, R, tableC);
   hipLaunchKernelGGL(rowscan1_kernel, dim3(D.groups, gsr_cdiv(tiles_y, 64)), dim3(256), 0, s, D, (const int *)tableC,
                      tableA, gtot);
   hipLaunchKernelGGL(rowscan2_kernel, dim3(1), dim3(1024), 0, s, D, capacity, gtot, row_start, row_chunk_start,
                      count_out);
-  hipLaunchKernelGGL(emit_kernel, dim3(D.waves), dim3(64), 16 * (size_t)tiles_y, s, D, capacity, order, R,
+  hipLaunchKernelGGL(emit_kernel, dim3(D.slabs), dim3(kSlab), 28 * (size_t)tiles_y, s, D, capacity, order, R,
                      (const int *)tableA, (const int *)gtot, (const int *)row_start, txs, gids);
   hipLaunchKernelGGL(colhist_kernel, dim3(L.chunk_slots), dim3(256), 0, s, D, capacity, (const int *)row_start,
                      (const int *)row_chunk_start, (const unsigned short *)txs, tableB);
-  hipLaunchKernelGGL(colscan_kernel, dim3(gsr_cdiv(tiles_x, 256), tiles_y), dim3(256), 0, s, D,
+  hipLaunchKernelGGL(colscan_kernel, dim3(gsr_cdiv(tiles_x, 64), tiles_y), dim3(256), 0, s, D,
                      (const int *)row_chunk_start, tableB, tile_cnt);
   int rc = gsr_tile_bases(tiles_x * tiles_y, tile_cnt, tile_bins, s);
   if (rc != GSR_OK) return rc;
