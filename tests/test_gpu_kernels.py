@@ -510,6 +510,36 @@ def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
         assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max() + 1e-12, nm
 
 
+@pytest.mark.parametrize("n,W,H,scale_hi", [(20_000, 272, 16368, 0.08),   # 17 x 1023 tiles: the row tables at their largest
+                                            (20_000, 16384, 272, 0.08),   # 1024 x 17: the 1024-column scatter
+                                            (6_000, 3200, 1800, 1.5),     # huge splats: batches above the start-mask size
+                                            (70_000, 3200, 1800, 0.02)])  # several scan groups, mostly one-tile splats
+def test_two_level_partition_equals_banded_lists(n, W, H, scale_hi):
+    """The two large-grid list builders (csrc/tile_partition2.hip and the tile-row bands of
+    csrc/tile_scatter.hip) produce the same ids / bins, bit for bit, on grid shapes and splat
+    sizes that reach the corners of the two-level code."""
+    import rasterizer.cuda as C
+
+    bw = 16
+    cam, sc = make(n, W, H, scale_lo=0.01, scale_hi=scale_hi)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    nb = C.tile_bands(tb)
+    assert nb > 1
+    g = dict(xys=cu(xys), depths=cu(depths), radii=cu(radii), conics=cu(conics), opac=cu(sc["opacities"]))
+    cnt1, recs1 = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
+    o1, c1 = C.depth_order(g["depths"], g["radii"], cnt1)
+    I1 = int(c1[-1].item())
+    assert I1 > 0
+    ids_t, bins_t = C.bin_sorted(n, I1, o1, c1, g["xys"], g["radii"], tb, bw, recs1)
+    cntb, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb, bands=nb)
+    o2, c2 = C.depth_order(g["depths"], g["radii"], cntb)
+    I2 = int(c2[-1].item())
+    ids_b, bins_b = C.bin_sorted(n, I2, o2, c2, g["xys"], g["radii"], tb, bw, recs)
+    assert I1 == I2 and torch.equal(bins_t, bins_b) and torch.equal(ids_t, ids_b)
+    assert int(bins_t[:, 1].max()) == I1
+
+
 def test_count_reach_errors():
     import rasterizer.cuda as C
 
