@@ -360,19 +360,29 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
 //   'm': sort_mid.hip + edge detection
 // GSR_TILE_SORT=r|m|s overrides (A/B measurements).  Grids of more than one
 // band need the per-band counts of gsr_count_reach, i.e. reach records.
-//   't': two-level partition (tile_partition2.hip): grids above 16384 tiles given ONE count per
-//        Gaussian (num_bands == 1) and the reach records
-char tile_sort_mode(int tiles_x, int tiles_y, bool have_records, int num_bands) {
+//   't': two-level partition (tile_partition2.hip), given ONE count per Gaussian (num_bands == 1)
+//        and the reach records: grids above 16384 tiles, and smaller grids whose lists hold at
+//        least GSR_P2_MIN + 3 N entries (default 3 M + 3 N).  Measured at 1080p, N and I in
+//        millions: two-level 66 + 48 N + 7.8 I us, single pass 40 + 23 N + 16.4 I us (uniform
+//        scenes; on spatially coherent ones -- many lanes of a step on one tile -- the
+//        single-pass walk is slower still).  Not when the caller wants slot_of_entry.
+char tile_sort_mode(int tiles_x, int tiles_y, bool have_records, int num_bands, int num_points, int num_intersects,
+                    bool want_slots) {
   static const char forced = [] {
     const char *e = getenv("GSR_TILE_SORT");
     return e ? e[0] : '\0';
   }();
+  static const long long p2_min = [] {
+    const char *e = getenv("GSR_P2_MIN");
+    return e ? atoll(e) : 3000000ll;
+  }();
   if (forced == 'r' || forced == 'm') return forced;
   const int bands = gsr_tile_band_rows(tiles_x, tiles_y, nullptr);
-  if (forced == 't' && have_records && num_bands == 1 && gsr_tile_partition2_supported(tiles_x, tiles_y)) return 't';
-  if (bands == 1) return 's';
+  const bool p2_ok = have_records && num_bands == 1 && !want_slots && gsr_tile_partition2_supported(tiles_x, tiles_y);
+  if (forced == 't' && p2_ok) return 't';
+  if (bands == 1) return (forced == '\0' && p2_ok && num_intersects >= p2_min + 3ll * num_points) ? 't' : 's';
   if (!have_records) return 'r';
-  if (num_bands == 1) return gsr_tile_partition2_supported(tiles_x, tiles_y) ? 't' : 'r';
+  if (num_bands == 1) return p2_ok ? 't' : 'r';
   return bands > 1 ? 's' : 'r';
 }
 
@@ -406,7 +416,8 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   GSR_REQUIRE(tiles_x <= 65535 && tiles_y <= 65535, "bin_sorted: tile grid too large");
   hipStream_t s = (hipStream_t)stream;
   const int num_tiles = tiles_x * tiles_y;
-  const char mode = tile_sort_mode(tiles_x, tiles_y, reach_records != nullptr, num_bands);
+  const char mode = tile_sort_mode(tiles_x, tiles_y, reach_records != nullptr, num_bands, num_points,
+                                   num_intersects, slot_of_entry != nullptr);
   GSR_REQUIRE(!device_sized || mode == 's' || mode == 't',
               "bin_sorted_dev: needs the tile scatter / two-level partition (<= 16384 tiles, or reach records)");
   GSR_REQUIRE(slot_of_entry == nullptr || mode == 's', "bin_sorted: slot_of_entry needs the single-pass tile scatter");

@@ -82,10 +82,6 @@ __device__ __forceinline__ void band_segment(const Bands &B, const int b, const 
   beg = s < I ? s : I;
   end = e < I ? e : I;
 }
-__device__ __forceinline__ int band_tiles(const Bands &B, const int b) {
-  const int t0 = b * B.tiles_per_band;
-  return B.num_tiles - t0 < B.tiles_per_band ? B.num_tiles - t0 : B.tiles_per_band;
-}
 
 // grid (max chunks, bands); table[band][chunk][T] with T = padded tiles per band
 __global__ __launch_bounds__(256) void hist_kernel(const int I_cap, const Bands B, const int chunk, const int T,
