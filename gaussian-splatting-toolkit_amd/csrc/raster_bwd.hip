@@ -29,6 +29,8 @@
 // retires 32 (G=4) or 64 (G=8) components: 9 atomics per tile-splat instead of 72.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "raster_common.h"
 
 #ifndef GSR_BWD_GROUP
@@ -438,7 +440,8 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
 // one global atomic per (tile, splat, component) at the end of the batch.
 template <int CMAX>
 __global__ __launch_bounds__(256) void raster_bwd_generic_kernel(
-    const int tiles_x, const int img_w, const int img_h, const int channels,
+    const int tiles_x, const int img_w, const int img_h, const int channels, const int cstride,
+    const int with_alpha,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
     const float2 *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
@@ -469,12 +472,12 @@ __global__ __launch_bounds__(256) void raster_bwd_generic_kernel(
   if (inside) {
     const size_t pid = (size_t)row * img_w + col;
     T_final = final_Ts[pid];
-    vout_alpha = v_output_alpha ? v_output_alpha[pid] : 0.f;
+    vout_alpha = (with_alpha && v_output_alpha) ? v_output_alpha[pid] : 0.f;
     bin_final = final_idx[pid];
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
       if (c < channels) {
-        vout[c] = v_output[pid * channels + c];
+        vout[c] = v_output[pid * cstride + c];
         bgdot += background[c] * vout[c];
       }
   }
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256) void raster_bwd_generic_kernel(
       const float fac = alpha * T;
       float v_alpha = 0.f;
       float *acc = s_dyn + t * stride;
-      const float *rgb = colors + (size_t)s_id[t] * channels;
+      const float *rgb = colors + (size_t)s_id[t] * cstride;
 #pragma unroll
       for (int ch = 0; ch < CMAX; ++ch)
         if (ch < channels) {
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256) void raster_bwd_generic_kernel(
       if (acc[4] != 0.f) unsafeAtomicAdd(v_conic + 3 * (size_t)g + 2, acc[4]);
       if (acc[5] != 0.f) unsafeAtomicAdd(v_opacity + g, acc[5]);
       for (int ch = 0; ch < channels; ++ch)
-        if (acc[6 + ch] != 0.f) unsafeAtomicAdd(v_colors + (size_t)g * channels + ch, acc[6 + ch]);
+        if (acc[6 + ch] != 0.f) unsafeAtomicAdd(v_colors + (size_t)g * cstride + ch, acc[6 + ch]);
     }
   }
 }
@@ -558,17 +561,21 @@ int launch_generic(unsigned img_h, unsigned img_w, unsigned bw, unsigned channel
                    float *v_xy, float *v_conic, float *v_colors, float *v_opacity, hipStream_t s) {
   const int tiles_x = (int)gsr_cdiv(img_w, bw), tiles_y = (int)gsr_cdiv(img_h, bw);
   const dim3 grd(tiles_x, tiles_y), blk(bw, bw);
-  const size_t dyn = (size_t)bw * bw * (6 + channels) * sizeof(float);
-#define GSR_LAUNCH_BWD(CM)                                                                        \
-  hipLaunchKernelGGL(raster_bwd_generic_kernel<CM>, grd, blk, dyn, s, tiles_x, (int)img_w,        \
-                     (int)img_h, (int)channels, ids, reinterpret_cast<const int2 *>(bins),        \
-                     reinterpret_cast<const float2 *>(xys), conics, colors, opac, background,     \
-                     final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,      \
-                     v_opacity)
-  if (channels <= 4) GSR_LAUNCH_BWD(4);
-  else if (channels <= 8) GSR_LAUNCH_BWD(8);
-  else if (channels <= 16) GSR_LAUNCH_BWD(16);
-  else GSR_LAUNCH_BWD(32);
+  // More than 32 channels: 32 per pass.  v_alpha is linear in the channels (sum over c of
+  // (rgb_c T - buffer_c ra) v_out_c, minus T_final ra sum_c bg_c v_out_c), so every pass adds its
+  // share of v_xy / v_conic / v_opacity; the v_output_alpha term goes with the first pass.
+#define GSR_LAUNCH_BWD(CM, C0, CN)                                                                \
+  hipLaunchKernelGGL(raster_bwd_generic_kernel<CM>, grd, blk,                                     \
+                     (size_t)bw * bw * (6 + (CN)) * sizeof(float), s, tiles_x, (int)img_w,        \
+                     (int)img_h, (int)(CN), (int)channels, (C0) == 0 ? 1 : 0, ids,                \
+                     reinterpret_cast<const int2 *>(bins), reinterpret_cast<const float2 *>(xys), \
+                     conics, colors + (C0), opac, background + (C0), final_Ts, final_idx,         \
+                     v_output + (C0), v_output_alpha, v_xy, v_conic, v_colors + (C0), v_opacity)
+  if (channels <= 4) GSR_LAUNCH_BWD(4, 0, channels);
+  else if (channels <= 8) GSR_LAUNCH_BWD(8, 0, channels);
+  else if (channels <= 16) GSR_LAUNCH_BWD(16, 0, channels);
+  else
+    for (unsigned c0 = 0; c0 < channels; c0 += 32) GSR_LAUNCH_BWD(32, c0, std::min(32u, channels - c0));
 #undef GSR_LAUNCH_BWD
   GSR_CHECK_LAUNCH("rasterize_backward(generic)");
   return GSR_OK;

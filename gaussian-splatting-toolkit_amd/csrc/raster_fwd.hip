@@ -17,8 +17,10 @@
 //    and no workgroup barrier is ever waited on by a second wave.  dx/dy terms
 //    are shared across the quad.  Workgroups are remapped so that 8x4-tile blocks go to the
 //    XCDs round-robin (shared splats stay in one L2, every XCD sees the whole frame).
-//  * generic (any block_width in [2,16], any channel count <= 32): one lane
+//  * generic (any block_width in [2,16], any channel count; 32 channels per pass): one lane
 //    per pixel, block_width^2 lanes per tile.
+#include <algorithm>
+
 #include "raster_common.h"
 
 namespace {
@@ -158,9 +160,13 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
 
 // ----------------------------------------------------------------- generic
 // One lane per pixel, bw*bw lanes per tile, batches of bw*bw splats in LDS.
+// `channels` (<= CMAX) of the `cstride` interleaved channels starting at the pointers given:
+// more than 32 channels are composited 32 at a time (the walk, T and final_idx are the same in
+// every pass; the reference holds all channels of its 256 pixels in shared memory as __half and
+// stops at what fits, ~90).
 template <int CMAX>
 __global__ __launch_bounds__(256) void raster_fwd_generic_kernel(
-    const int tiles_x, const int img_w, const int img_h, const int channels,
+    const int tiles_x, const int img_w, const int img_h, const int channels, const int cstride,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
     const float2 *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void raster_fwd_generic_kernel(
         break;
       }
       const float vis = alpha * T;
-      const float *col_g = colors + (size_t)s_id[t] * channels;
+      const float *col_g = colors + (size_t)s_id[t] * cstride;
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
         if (c < channels) acc[c] += col_g[c] * vis;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void raster_fwd_generic_kernel(
     final_idx[pid] = last;
 #pragma unroll
     for (int c = 0; c < CMAX; ++c)
-      if (c < channels) out_img[pid * channels + c] = acc[c] + T * background[c];
+      if (c < channels) out_img[pid * cstride + c] = acc[c] + T * background[c];
   }
 }
 
@@ -237,15 +243,16 @@ int launch_generic(int tiles_x, int tiles_y, unsigned bw, unsigned img_w, unsign
                    const float *background, float *out_img, float *final_Ts, int32_t *final_idx,
                    hipStream_t s) {
   const dim3 grd(tiles_x, tiles_y), blk(bw, bw);
-#define GSR_LAUNCH_FWD(CM)                                                                      \
+#define GSR_LAUNCH_FWD(CM, C0, CN)                                                              \
   hipLaunchKernelGGL(raster_fwd_generic_kernel<CM>, grd, blk, 0, s, tiles_x, (int)img_w,        \
-                     (int)img_h, (int)channels, ids, reinterpret_cast<const int2 *>(bins),      \
-                     reinterpret_cast<const float2 *>(xys), conics, colors, opac, background,   \
-                     out_img, final_Ts, final_idx)
-  if (channels <= 4) GSR_LAUNCH_FWD(4);
-  else if (channels <= 8) GSR_LAUNCH_FWD(8);
-  else if (channels <= 16) GSR_LAUNCH_FWD(16);
-  else GSR_LAUNCH_FWD(32);
+                     (int)img_h, (int)(CN), (int)channels, ids, reinterpret_cast<const int2 *>(bins), \
+                     reinterpret_cast<const float2 *>(xys), conics, colors + (C0), opac,        \
+                     background + (C0), out_img + (C0), final_Ts, final_idx)
+  if (channels <= 4) GSR_LAUNCH_FWD(4, 0, channels);
+  else if (channels <= 8) GSR_LAUNCH_FWD(8, 0, channels);
+  else if (channels <= 16) GSR_LAUNCH_FWD(16, 0, channels);
+  else
+    for (unsigned c0 = 0; c0 < channels; c0 += 32) GSR_LAUNCH_FWD(32, c0, std::min(32u, channels - c0));
 #undef GSR_LAUNCH_FWD
   GSR_CHECK_LAUNCH("rasterize_forward(generic)");
   return GSR_OK;

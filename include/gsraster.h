@@ -254,8 +254,10 @@ int gsr_rasterize_backward(unsigned img_height, unsigned img_width,
 /* generic channel count; replace nd_rasterize_forward_tensor /
  * nd_rasterize_backward_tensor (bindings.cu:330-469), kernels
  * forward.cu:159-276 / backward.cu:23-131.  Accumulation is fp32 here (the
- * reference accumulates in __half). 1 <= channels <= GSR_MAX_CHANNELS. */
-#define GSR_MAX_CHANNELS 32
+ * reference accumulates in __half). 1 <= channels <= GSR_MAX_CHANNELS; above 32
+ * channels the lists are walked once per 32 channels (the reference keeps all
+ * channels of a tile's 256 pixels in 48 KB of shared memory: ~90 at most). */
+#define GSR_MAX_CHANNELS 1024
 int gsr_rasterize_forward_nd(int tiles_x, int tiles_y, unsigned block_width,
                              unsigned img_width, unsigned img_height,
                              unsigned channels,

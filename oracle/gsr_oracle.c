@@ -759,21 +759,17 @@ GSR_API void gsr_oracle_rasterize_backward(
   }
 #pragma omp parallel for schedule(static)
   for (int g = 0; g < num_points; ++g) {
-    double s[64];
-    int ns = stride < 64 ? stride : 64;
-    for (int k = 0; k < ns; ++k) s[k] = 0.0;
-    for (int t = 0; t < nthreads; ++t) {
-      const double *Ag = accs + ((size_t)t * num_points + g) * stride;
-      for (int k = 0; k < ns; ++k) s[k] += Ag[k];
+    const int ns = stride;
+    /* component k of Gaussian g: the threads' partial sums added in thread order */
+    for (int k = 0; k < ns; ++k) {
+      double sk = 0.0;
+      for (int t = 0; t < nthreads; ++t) sk += accs[((size_t)t * num_points + g) * stride + k];
+      const float f = (float)sk;
+      if (k < 2) v_xy[2 * g + k] = f;
+      else if (k < 5) v_conic[3 * g + (k - 2)] = f;
+      else if (k == 5) v_opacity[g] = f;
+      else v_colors[(size_t)channels * g + (k - 6)] = f;
     }
-    v_xy[2 * g] = (float)s[0];
-    v_xy[2 * g + 1] = (float)s[1];
-    v_conic[3 * g] = (float)s[2];
-    v_conic[3 * g + 1] = (float)s[3];
-    v_conic[3 * g + 2] = (float)s[4];
-    v_opacity[g] = (float)s[5];
-    for (int c = 0; c < channels && c < 58; ++c)
-      v_colors[(size_t)channels * g + c] = (float)s[6 + c];
     if (want_abs) {
       for (int k = 0; k < ns; ++k) {
         double t = 0.0;

@@ -265,7 +265,7 @@ def test_rasterize_backward(n, W, H, bw, ck, kw):
         grad_close(npy(g), r, name=nm)
 
 
-@pytest.mark.parametrize("channels", [1, 4, 7, 32])
+@pytest.mark.parametrize("channels", [1, 4, 7, 32, 33, 96])  # above 32: one pass per 32 channels
 def test_nd_rasterize(channels):
     import rasterizer.cuda as C
 
