@@ -28,6 +28,9 @@
 size_t gsr_sort_mid_workspace_bytes(int n);
 int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, void *workspace,
                  size_t workspace_bytes, hipStream_t s);
+size_t gsr_sort_mid_depth_extra(int n, int rows);
+int gsr_sort_mid_depth(int n, const float *depths, const int *radii, const int *counts, int rows, int *order,
+                       int *cum, void *workspace, size_t workspace_bytes, hipStream_t s);
 int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsigned *keys_out,
                        int *vals_out, int key_bits, void *workspace, size_t workspace_bytes,
                        hipStream_t s);
@@ -275,7 +278,8 @@ GSR_EXPORT size_t gsr_depth_order_workspace_bytes(int num_points, int num_bands)
   const size_t st = scan_temp((size_t)num_points * num_bands);
   // [depth keys][ either: rocPRIM (sorted keys + temp)  or: sort_mid workspace ; scan temp shares it ]
   const size_t rocprim_need = kb + align_up(std::max(depth_sort_temp(num_points), st));
-  const size_t mid_need = align_up(std::max(gsr_sort_mid_workspace_bytes(num_points), st));
+  const size_t mid_need = align_up(std::max(gsr_sort_mid_workspace_bytes(num_points) +
+                                                gsr_sort_mid_depth_extra(num_points, num_bands), st));
   return kb + (use_mid_sort(num_points) ? mid_need : rocprim_need);
 }
 
@@ -298,13 +302,13 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   unsigned *keys_in = reinterpret_cast<unsigned *>(ws);
   char *rest = ws + kb;
   size_t rest_bytes = workspace_bytes - kb;
+  if (use_mid_sort(num_points))  // keys, sort, gather of the counts and their scan in 13 launches (sort_mid.hip)
+    return gsr_sort_mid_depth(num_points, depths, radii, num_tiles_hit, num_bands, order, cum_sorted, rest,
+                              rest_bytes, s);
   hipLaunchKernelGGL(depth_keys_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, num_points,
                      depths, radii, keys_in);
   GSR_CHECK_LAUNCH("depth_order(keys)");
-  if (use_mid_sort(num_points)) {
-    int rc = gsr_sort_mid(num_points, keys_in, order, 31, rest, rest_bytes, s);
-    if (rc != GSR_OK) return rc;
-  } else {
+  {
     unsigned *keys_out = reinterpret_cast<unsigned *>(rest);
     size_t temp_bytes = rest_bytes - kb;
     GSR_CHECK_HIP(rocprim::radix_sort_pairs<depth_sort_config>(
@@ -416,8 +420,11 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   GSR_REQUIRE(tiles_x <= 65535 && tiles_y <= 65535, "bin_sorted: tile grid too large");
   hipStream_t s = (hipStream_t)stream;
   const int num_tiles = tiles_x * tiles_y;
+  // (device-sized: `num_intersects` is a capacity -- the caller's estimate plus head-room, 25 % and
+  // rounding in rasterizer/rasterize.py; the path is chosen for the list length it stands for)
   const char mode = tile_sort_mode(tiles_x, tiles_y, reach_records != nullptr, num_bands, num_points,
-                                   num_intersects, slot_of_entry != nullptr);
+                                   device_sized ? (int)(0.75 * num_intersects) : num_intersects,
+                                   slot_of_entry != nullptr);
   GSR_REQUIRE(!device_sized || mode == 's' || mode == 't',
               "bin_sorted_dev: needs the tile scatter / two-level partition (<= 16384 tiles, or reach records)");
   GSR_REQUIRE(slot_of_entry == nullptr || mode == 's', "bin_sorted: slot_of_entry needs the single-pass tile scatter");
