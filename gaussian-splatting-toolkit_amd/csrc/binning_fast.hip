@@ -77,6 +77,47 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(const int n, const floa
   keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0u;
 }
 
+// The per-Gaussian record of the list builders: centre, conic, the sigma bound of the exact
+// reach test and the tile box (conics == nullptr: every box tile counts, smax = inf).
+__device__ __forceinline__ SplatRec make_splat_record(const int g, const float *__restrict__ xys,
+                                                      const int *__restrict__ radii,
+                                                      const float *__restrict__ conics,
+                                                      const float *__restrict__ opacities, const int tiles_x,
+                                                      const int tiles_y, const int bw) {
+  SplatRec rec{0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0u, 0u};
+  const int r = radii[g];
+  if (r > 0) {
+    int minx, miny, maxx, maxy;
+    const float x = xys[2 * g], y = xys[2 * g + 1];
+    gsr_tile_bbox(x, y, (float)r, tiles_x, tiles_y, 0.f, bw, minx, miny, maxx, maxy);
+    rec.x = x;
+    rec.y = y;
+    rec.smax = INFINITY;
+    if (conics) {
+      const gsr::Reach rc = gsr::make_reach(x, y, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g]);
+      rec.a = rc.a;
+      rec.b = rc.b;
+      rec.c = rc.c;
+      rec.smax = rc.smax;
+    }
+    if (maxx > minx && maxy > miny && !(rec.smax < 0.f)) {
+      rec.box0 = (unsigned)minx | ((unsigned)miny << 16);
+      rec.box1 = (unsigned)(maxx - minx) | ((unsigned)(maxy - miny) << 16);
+    }
+  }
+  return rec;
+}
+
+// records only (gsr_count_reach with counts == NULL): what the two-level partition needs
+__global__ __launch_bounds__(256) void reach_records_kernel(const int n, const float *__restrict__ xys,
+                                                            const int *__restrict__ radii,
+                                                            const float *__restrict__ conics,
+                                                            const float *__restrict__ opacities, const int tiles_x,
+                                                            const int tiles_y, SplatRec *__restrict__ recs) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) recs[g] = make_splat_record(g, xys, radii, conics, opacities, tiles_x, tiles_y, 16);
+}
+
 // One wave handles 64 Gaussians and walks their (Gaussian, tile row) items
 // LOAD-BALANCED: rows are numbered consecutively (prefix sum of the box heights)
 // and lane l takes rows l, l+64, ... -- a lane per Gaussian looping over its own
@@ -115,26 +156,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(
     if (mode && recs) {
       rec = recs[g];
     } else {
-      const int r = radii[g];
-      if (r > 0) {
-        int minx, miny, maxx, maxy;
-        const float x = xys[2 * g], y = xys[2 * g + 1];
-        gsr_tile_bbox(x, y, (float)r, tiles_x, tiles_y, 0.f, bw, minx, miny, maxx, maxy);
-        rec.x = x;
-        rec.y = y;
-        rec.smax = INFINITY;
-        if (conics) {
-          const gsr::Reach rc = gsr::make_reach(x, y, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g]);
-          rec.a = rc.a;
-          rec.b = rc.b;
-          rec.c = rc.c;
-          rec.smax = rc.smax;
-        }
-        if (maxx > minx && maxy > miny && !(rec.smax < 0.f)) {
-          rec.box0 = (unsigned)minx | ((unsigned)miny << 16);
-          rec.box1 = (unsigned)(maxx - minx) | ((unsigned)(maxy - miny) << 16);
-        }
-      }
+      rec = make_splat_record(g, xys, radii, conics, opacities, tiles_x, tiles_y, bw);
       if (!mode) recs[g] = rec;
     }
     if (kBands && mode) {  // keep the rows of this band only
@@ -290,7 +312,10 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   GSR_REQUIRE(num_bands >= 1 && num_bands <= kMaxBands, "depth_order: num_bands must be in [1,16]");
   GSR_REQUIRE((long long)num_points * num_bands < (1ll << 31), "depth_order: num_points * num_bands too large");
   if (num_points == 0) return GSR_OK;
-  GSR_REQUIRE(depths && radii && num_tiles_hit && order && cum_sorted && workspace, "depth_order: null pointer");
+  GSR_REQUIRE(depths && radii && order && workspace, "depth_order: null pointer");
+  GSR_REQUIRE((num_tiles_hit == nullptr) == (cum_sorted == nullptr),
+              "depth_order: num_tiles_hit and cum_sorted are given (or left NULL: order only) together");
+  const bool order_only = cum_sorted == nullptr;
   const size_t need = gsr_depth_order_workspace_bytes(num_points, num_bands);
   if (workspace_bytes < need) {
     gsr_set_error("depth_order: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -315,6 +340,7 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
         rest + kb, temp_bytes, (const unsigned *)keys_in, keys_out, rocprim::counting_iterator<int>(0),
         order, (size_t)num_points, 0u, 31u, s));
   }
+  if (order_only) return GSR_OK;
   // the sort is finished with its workspace (stream order): reuse it for the scan
   auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0),
                                              TilesInOrder{num_tiles_hit, order, num_points});
@@ -341,7 +367,7 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
                                void *reach_records, gsr_stream_t stream) {
   GSR_REQUIRE(num_points >= 0, "count_reach: num_points < 0");
   if (num_points == 0) return GSR_OK;
-  GSR_REQUIRE(xys && radii && conics && opacities && counts && reach_records, "count_reach: null pointer");
+  GSR_REQUIRE(xys && radii && conics && opacities && reach_records, "count_reach: null pointer");
   GSR_REQUIRE(tiles_x > 0 && tiles_y > 0 && tiles_x <= 65535 && tiles_y <= 65535, "count_reach: bad tile grid");
   GSR_REQUIRE((reinterpret_cast<uintptr_t>(reach_records) & 15) == 0, "count_reach: reach_records must be 16-byte aligned");
   int rpb = tiles_y;
@@ -349,6 +375,14 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
   if (bands < 1) bands = 1, rpb = tiles_y;  // grids the scatter does not serve: one count per Gaussian
   GSR_REQUIRE(num_bands == 1 || num_bands == bands, "count_reach: num_bands must be 1 or gsr_tile_bands()");
   if (num_bands == 1) bands = 1, rpb = tiles_y;
+  if (!counts) {  // records only: the caller's lists come from the two-level partition (gsr_bin_sorted_needs_counts)
+    GSR_REQUIRE(num_bands == 1, "count_reach: counts may be NULL with num_bands == 1 only");
+    hipLaunchKernelGGL(reach_records_kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream,
+                       num_points, xys, radii, conics, opacities, tiles_x, tiles_y,
+                       static_cast<SplatRec *>(reach_records));
+    GSR_CHECK_LAUNCH("count_reach(records)");
+    return GSR_OK;
+  }
   auto kernel = bands > 1 ? tile_rows_kernel<true> : tile_rows_kernel<false>;
   hipLaunchKernelGGL(kernel, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, (hipStream_t)stream, 0,
                      num_points, (const int *)nullptr, (const int *)nullptr, xys, radii, conics, opacities,
@@ -404,6 +438,14 @@ GSR_EXPORT size_t gsr_bin_sorted_workspace_bytes(int num_points, int num_interse
                                          scatter})));
 }
 
+GSR_EXPORT int gsr_bin_sorted_needs_counts(int num_points, int num_intersects, int tiles_x, int tiles_y,
+                                           int device_sized, int want_slots) {
+  if (tiles_x <= 0 || tiles_y <= 0 || num_points <= 0 || num_intersects <= 0) return 1;
+  const char mode = tile_sort_mode(tiles_x, tiles_y, true, 1, num_points,
+                                   device_sized ? (int)(0.75 * num_intersects) : num_intersects, want_slots != 0);
+  return mode == 't' ? 0 : 1;
+}
+
 namespace {
 // device_sized: the stream length is cum_sorted[bands * num_points - 1] on the device and
 // `num_intersects` is the capacity the caller sized its buffers for
@@ -441,7 +483,9 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
     GSR_CHECK_LAUNCH("bin_sorted(clear)");
   }
   if (num_points == 0 || num_intersects == 0) return GSR_OK;
-  GSR_REQUIRE(order && cum_sorted && xys && radii && gaussian_ids_sorted && workspace, "bin_sorted: null pointer");
+  GSR_REQUIRE(order && xys && radii && gaussian_ids_sorted && workspace, "bin_sorted: null pointer");
+  GSR_REQUIRE(cum_sorted || mode == 't',
+              "bin_sorted: cum_sorted may be NULL only where gsr_bin_sorted_needs_counts() says so");
   const size_t need = gsr_bin_sorted_workspace_bytes(num_points, num_intersects, tiles_x, tiles_y);
   if (workspace_bytes < need) {
     gsr_set_error("bin_sorted: workspace %zu < %zu bytes", workspace_bytes, need);

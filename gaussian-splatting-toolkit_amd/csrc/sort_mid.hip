@@ -339,7 +339,7 @@ int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, vo
 
 // ---- the depth ordering: order + inclusive prefix of the tile counts in that order -------
 // counts[rows][n] (index order) -> cum[rows * n]: inclusive scan of counts[r][order[i]] over
-// (r, i).  Needs the workspace of gsr_sort_mid_workspace_bytes(n) + gsr_sort_mid_depth_extra(n, rows).
+// (r, i); counts == cum == nullptr: the order only.  Needs the workspace of gsr_sort_mid_workspace_bytes(n) + gsr_sort_mid_depth_extra(n, rows).
 size_t gsr_sort_mid_depth_extra(int n, int rows) {
   using namespace gsr_sort;
   const size_t tiles = ((size_t)n * rows + kScanTile - 1) / kScanTile;
@@ -375,7 +375,7 @@ int gsr_sort_mid_depth(int n, const float *depths, const int *radii, const int *
   const int *vin = nullptr;
   for (int p = 0; p < passes; ++p) {
     const bool first = p == 0, last = p == passes - 1;
-    unsigned *kout = last ? nullptr : kbuf[p & 1];
+    unsigned *kout = (last && counts) ? nullptr : kbuf[p & 1];  // (the gather variant needs no sorted keys)
     int *vout = ((passes - 1 - p) & 1) ? vtmp : order;
     if (first)
       hipLaunchKernelGGL(hist_kernel<true>, dim3(chunks), dim3(kThreads), 0, s, n, kin, depths, radii, 0, chunks,
@@ -388,7 +388,7 @@ int gsr_sort_mid_depth(int n, const float *depths, const int *radii, const int *
       hipLaunchKernelGGL((scatter_kernel<true, false>), dim3(chunks), dim3(kThreads), 0, s, n, kin, depths, radii,
                          vin, 0, chunks, (const unsigned *)hist, (const unsigned *)totals, kout, vout,
                          (const int *)nullptr, (int *)nullptr, 0);
-    else if (last)
+    else if (last && counts)
       hipLaunchKernelGGL((scatter_kernel<false, true>), dim3(chunks), dim3(kThreads), 0, s, n, kin,
                          (const float *)nullptr, (const int *)nullptr, vin, 8 * p, chunks, (const unsigned *)hist,
                          (const unsigned *)totals, kout, vout, counts, cum, rows);
@@ -399,7 +399,8 @@ int gsr_sort_mid_depth(int n, const float *depths, const int *radii, const int *
     kin = kout;
     vin = vout;
   }
-  hipLaunchKernelGGL(scan_lookback_kernel, dim3(tiles), dim3(kThreads), 0, s, (int)total, cum, state);
+  if (counts)
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(tiles), dim3(kThreads), 0, s, (int)total, cum, state);
   GSR_CHECK_LAUNCH("sort_mid_depth");
   return GSR_OK;
 }

@@ -99,7 +99,10 @@ class _Render(Function):
             colors = torch.empty((n, 3), dtype=_f32, device=dev)
             _call("gsr_sh_forward_split", C.c_uint(n), C.c_uint(degree), C.c_uint(spec.sh_degree_to_use), _ptr(dirs),
                   _ptr(features_dc), _ptr(features_rest), _ptr(colors), C.c_float(0.5), C.c_int(1), _stream(dev))
-            counts, recs = _C.count_reach(xys, radii, conics, opac, tb)
+            # (long lists go through the two-level partition, which counts its entries itself: no
+            #  per-Gaussian counts, no scan -- include/gsraster.h "Lists without counts")
+            lean = not _C.lists_need_counts(n, capacity, tb, device_sized=True)
+            counts, recs = _C.count_reach(xys, radii, conics, opac, tb, counts=not lean)
             order, cum = _C.depth_order(depths, radii, counts)
             ids, bins = _C.bin_sorted(n, capacity, order, cum, xys, radii, tb, BLOCK, recs, device_sized=True,
                                       count_out=count_out)

@@ -243,27 +243,42 @@ def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: Tensor,
     return tile_bins
 
 
-def depth_order(depths: Tensor, radii: Tensor, num_tiles_hit: Tensor) -> Tuple[Tensor, Tensor]:
+def depth_order(depths: Tensor, radii: Tensor, num_tiles_hit: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
     """First half of the fused binning pipeline (``gsr_depth_order``):
     -> (order i32[N], cum_sorted i32[B*N]); ``cum_sorted[-1]`` is the number of
     intersections.  ``num_tiles_hit`` is [N], or the band-major [B*N] counts of
-    :func:`count_reach` on a tile grid of B = :func:`tile_bands` bands."""
+    :func:`count_reach` on a tile grid of B = :func:`tile_bands` bands, or None: the
+    order only, ``cum_sorted`` is None (lists without counts, :func:`lists_need_counts`)."""
     _check(depths, "depths", _f32)
     _check(radii, "radii", _i32)
-    _check(num_tiles_hit, "num_tiles_hit", _i32)
     n = depths.numel()
-    bands = num_tiles_hit.numel() // n if n else 1
-    if n and (num_tiles_hit.numel() != bands * n or bands < 1):
-        raise RuntimeError("depth_order: num_tiles_hit must hold N (or bands * N) counts")
+    bands = 1
+    if num_tiles_hit is not None:
+        _check(num_tiles_hit, "num_tiles_hit", _i32)
+        bands = num_tiles_hit.numel() // n if n else 1
+        if n and (num_tiles_hit.numel() != bands * n or bands < 1):
+            raise RuntimeError("depth_order: num_tiles_hit must hold N (or bands * N) counts")
     dev = depths.device
     with torch.cuda.device(dev):
         order = torch.empty((n,), dtype=_i32, device=dev)
-        cum = torch.empty((bands * n,), dtype=_i32, device=dev)
+        cum = torch.empty((bands * n,), dtype=_i32, device=dev) if num_tiles_hit is not None else None
         nbytes = int(_lib().gsr_depth_order_workspace_bytes(C.c_int(n), C.c_int(bands)))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
-        _call("gsr_depth_order", C.c_int(n), _ptr(depths), _ptr(radii), _ptr(num_tiles_hit), C.c_int(bands),
-              _ptr(order), _ptr(cum), _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+        _call("gsr_depth_order", C.c_int(n), _ptr(depths), _ptr(radii),
+              _ptr(num_tiles_hit) if num_tiles_hit is not None else None, C.c_int(bands),
+              _ptr(order), _ptr(cum) if cum is not None else None, _ptr(ws), C.c_size_t(nbytes), _stream(dev))
     return order, cum
+
+
+def lists_need_counts(num_points: int, num_intersects: int, tile_bounds: Tuple[int, int, int],
+                      device_sized: bool = True, want_slots: bool = False) -> bool:
+    """``gsr_bin_sorted_needs_counts``: False when :func:`bin_sorted` (exact lists, one
+    band) will take the two-level partition for these sizes -- the caller may then skip
+    the counts: ``count_reach(..., counts=False)``, ``depth_order(depths, radii, None)``,
+    ``bin_sorted(..., cum_sorted=None)``."""
+    return bool(_lib().gsr_bin_sorted_needs_counts(C.c_int(int(num_points)), C.c_int(int(num_intersects)),
+                                                   C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
+                                                   C.c_int(1 if device_sized else 0), C.c_int(1 if want_slots else 0)))
 
 
 def tile_bands(tile_bounds: Tuple[int, int, int]) -> int:
@@ -284,12 +299,13 @@ def publish_int32(src: Tensor, dst: Tensor) -> None:
 
 
 def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
-                tile_bounds: Tuple[int, int, int], bands: int = 1) -> Tuple[Tensor, Tensor]:
+                tile_bounds: Tuple[int, int, int], bands: int = 1, counts: bool = True) -> Tuple[Optional[Tensor], Tensor]:
     """``gsr_count_reach``: per Gaussian, the number of 16x16 tiles of its bounding
     box in which it can reach alpha >= 1/255 -> (counts i32[bands*N], band-major, summing to
     <= num_tiles_hit per Gaussian; opaque per-Gaussian records for :func:`bin_sorted`).
     ``bands``: 1 (default: one count per Gaussian; large grids then take the two-level
-    partition) or :func:`tile_bands` (tile-row bands: needed for ``want_slots``)."""
+    partition) or :func:`tile_bands` (tile-row bands: needed for ``want_slots``).
+    ``counts=False``: the records only (-> (None, records)), see :func:`lists_need_counts`."""
     _check(xys, "xys", _f32)
     _check(radii, "radii", _i32)
     _check(conics, "conics", _f32)
@@ -299,18 +315,18 @@ def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
         raise RuntimeError("count_reach: xys [N,2], conics [N,3], opacities [N,1] expected")
     dev = xys.device
     with torch.cuda.device(dev):
-        counts = torch.empty((int(bands) * n,), dtype=_i32, device=dev)
+        cnt = torch.empty((int(bands) * n,), dtype=_i32, device=dev) if counts else None
         recs = torch.empty((n, int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
         _call("gsr_count_reach", C.c_int(n), _ptr(xys), _ptr(radii), _ptr(conics), _ptr(opacities),
-              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_int(int(bands)), _ptr(counts), _ptr(recs),
-              _stream(dev))
-    return counts, recs
+              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_int(int(bands)),
+              _ptr(cnt) if cnt is not None else None, _ptr(recs), _stream(dev))
+    return cnt, recs
 
 
 MAX_SCATTER_TILES = 16384  # tile grids the device-sized path supports without reach records (tile_scatter.hip)
 
 
-def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Tensor, xys: Tensor,
+def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: Optional[Tensor], xys: Tensor,
                radii: Tensor, tile_bounds: Tuple[int, int, int], block_width: int,
                reach_records: Optional[Tensor] = None, device_sized: bool = False,
                count_out: Optional[Tensor] = None, want_slots: bool = False):
@@ -322,10 +338,12 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     the device from ``cum_sorted[-1]`` and the lists are cut at the capacity
     (``gsr_bin_sorted_dev``) -- the caller checks ``cum_sorted[-1] <= capacity``
     later, off the critical path; ``count_out`` (int32[1], pinned host memory or
-    device) receives that count.  ``want_slots``: also return ``slot_of_entry`` i32[I]
+    device) receives that count.  ``cum_sorted=None``: only where :func:`lists_need_counts`
+    is False.  ``want_slots``: also return ``slot_of_entry`` i32[I]
     (the inverse of the scatter, for :func:`rasterize_backward_det`)."""
     _check(order, "order", _i32)
-    _check(cum_sorted, "cum_sorted", _i32)
+    if cum_sorted is not None:
+        _check(cum_sorted, "cum_sorted", _i32)
     _check(xys, "xys", _f32)
     _check(radii, "radii", _i32)
     if reach_records is not None:
@@ -340,10 +358,11 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
         tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
         nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(int(num_points)), C.c_int(I),
                                                            C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
-        bands = cum_sorted.numel() // max(int(num_points), 1) if int(num_points) else 1
+        bands = cum_sorted.numel() // max(int(num_points), 1) if int(num_points) and cum_sorted is not None else 1
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         slots = torch.empty((I,), dtype=_i32, device=dev) if want_slots else None
-        head = (C.c_int(int(num_points)), C.c_int(I), _ptr(order), _ptr(cum_sorted), _ptr(xys), _ptr(radii),
+        head = (C.c_int(int(num_points)), C.c_int(I), _ptr(order),
+                _ptr(cum_sorted) if cum_sorted is not None else None, _ptr(xys), _ptr(radii),
                 _ptr(reach_records) if reach_records is not None else None, C.c_int(tile_bounds[0]),
                 C.c_int(tile_bounds[1]), C.c_uint(block_width), C.c_int(bands), _ptr(ids), _ptr(tile_bins))
         tail = (_ptr(slots) if want_slots else None, _ptr(ws), C.c_size_t(nbytes), _stream(dev))

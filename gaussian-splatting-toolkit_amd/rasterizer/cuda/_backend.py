@@ -34,6 +34,7 @@ SYMBOLS = (
     "gsr_depth_order_workspace_bytes",
     "gsr_depth_order",
     "gsr_bin_sorted_workspace_bytes",
+    "gsr_bin_sorted_needs_counts",
     "gsr_bin_sorted",
     "gsr_bin_sorted_dev",
     "gsr_publish_int32",

@@ -268,7 +268,8 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     return _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember)
 
 
-def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember):
+def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember,
+                 speculate=True):
     num_points = xys.size(0)
     # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
     # compute_cumulative_intersects + bin_and_sort_gaussians (bit for bit
@@ -278,9 +279,34 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
     # with the exact lists, i.e. the single-pass scatter path -- on grids above 16384 tiles that
     # is the banded one; otherwise such grids take the two-level partition, bands = 1)
     det = _deterministic["on"] and exact and os.environ.get("GSR_TILE_SORT", "s")[:1] not in ("r", "m")
+    banded = exact and (det or os.environ.get("GSR_TILE_SORT", "")[:1] == "b")
+    capacity = _speculative_capacity(xys.device, num_points, tile_bounds, exact) if speculate else None
+
+    if exact and capacity is not None and not banded and \
+            not _C.lists_need_counts(num_points, capacity, tile_bounds, device_sized=True, want_slots=det):
+        # The two-level partition counts its entries itself: records only, the depth order only,
+        # and the number of entries comes back through the pinned slot (`count_out`).
+        _, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False)
+        order, _ = _C.depth_order(depths, radii, None)
+        pending = _PendingCount(xys.device)
+        ids, bins = _C.bin_sorted(num_points, capacity, order, None, xys, radii, tile_bounds, block_width, records,
+                                  device_sized=True, count_out=pending.buf)
+        pending.mark()
+
+        def finish_lean():
+            num_intersects = pending.resolve()
+            _note_count(xys.device, num_points, tile_bounds, num_intersects)
+            if num_intersects > capacity:  # the guess was too small: build the lists again, sized exactly
+                n, i2, b2, _ = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds,
+                                            block_width, exact, remember, speculate=False)
+                return n, i2, b2, True
+            remember(num_intersects, ids, bins, None)
+            return num_intersects, ids, bins, False
+
+        return None, ids, bins, finish_lean
+
     tiles, records = num_tiles_hit, None
     if exact:
-        banded = det or os.environ.get("GSR_TILE_SORT", "")[:1] == "b"
         tiles, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds,
                                         bands=_C.tile_bands(tile_bounds) if banded else 1)
     order, cum_sorted = _C.depth_order(depths, radii, tiles)
@@ -294,7 +320,6 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
 
     build.aux = None
 
-    capacity = _speculative_capacity(xys.device, num_points, tile_bounds, exact)
     if capacity is None:
         num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
         _note_count(xys.device, num_points, tile_bounds, num_intersects)

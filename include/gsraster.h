@@ -165,7 +165,17 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  *     (band-major), gsr_depth_order scans them in (band, depth) order into
  *     cum_sorted[bands * n]; slower on large lists, but hands out slot_of_entry
  *     (deterministic backward).
- * Grids up to 16384 tiles: num_bands = 1, the single-pass scatter. */
+ * Grids up to 16384 tiles: num_bands = 1; the single-pass scatter, or -- once the
+ * lists are long (>= 3 M + 3 n entries) -- the two-level partition as well.
+ *
+ * Lists without counts.  The two-level partition counts its entries itself (per tile
+ * row, in depth order): where gsr_bin_sorted_needs_counts() returns 0 for the call
+ * about to be made (same num_points / num_intersects-or-capacity / grid; reach records
+ * and num_bands == 1 assumed), the caller may pass counts = NULL to gsr_count_reach
+ * (records only, no walk over the tile rows), num_tiles_hit = cum_sorted = NULL to
+ * gsr_depth_order (the order only: no gather, no scan) and cum_sorted = NULL to
+ * gsr_bin_sorted(_dev); the number of entries then arrives through count_out of
+ * gsr_bin_sorted_dev.  Same lists, two kernels and a scan less. */
 size_t gsr_reach_record_bytes(void);
 int gsr_tile_bands(int tiles_x, int tiles_y);
 int gsr_count_reach(int num_points, const float *xys, const int32_t *radii,
@@ -179,6 +189,8 @@ int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
                     size_t workspace_bytes, gsr_stream_t stream);
 size_t gsr_bin_sorted_workspace_bytes(int num_points, int num_intersects,
                                       int tiles_x, int tiles_y);
+int gsr_bin_sorted_needs_counts(int num_points, int num_intersects, int tiles_x,
+                                int tiles_y, int device_sized, int want_slots);
 int gsr_bin_sorted(int num_points, int num_intersects, const int32_t *order,
                    const int32_t *cum_sorted, const float *xys,
                    const int32_t *radii, const void *reach_records, int tiles_x,

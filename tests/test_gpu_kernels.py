@@ -540,6 +540,43 @@ def test_two_level_partition_equals_banded_lists(n, W, H, scale_hi):
     assert int(bins_t[:, 1].max()) == I1
 
 
+@pytest.mark.parametrize("n,W,H,lo,hi", [(30_000, 3840, 2160, 0.01, 0.08),     # large grid: always the two-level path
+                                         (300_000, 1920, 1080, 0.01, 0.08)])   # 1080p with long lists
+def test_lists_without_counts_equal_the_full_flow(n, W, H, lo, hi):
+    """include/gsraster.h "Lists without counts": records only + order only + cum_sorted = NULL
+    build the same ids / bins and report the same number of entries as the full flow."""
+    import rasterizer.cuda as C
+
+    bw = 16
+    cam, sc = make(n, W, H, scale_lo=lo, scale_hi=hi)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    g = dict(xys=cu(xys), depths=cu(depths), radii=cu(radii), conics=cu(conics), opac=cu(sc["opacities"]))
+    cnt, recs = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb)
+    order, cum = C.depth_order(g["depths"], g["radii"], cnt)
+    I = int(cum[-1].item())
+    cap = int(1.3 * I)
+    assert not C.lists_need_counts(n, cap, tb, device_sized=True)
+    assert C.lists_need_counts(n, cap, tb, device_sized=True, want_slots=True)  # slots: the single-pass / banded path
+    ids_full, bins_full = C.bin_sorted(n, I, order, cum, g["xys"], g["radii"], tb, bw, recs)
+    none, recs2 = C.count_reach(g["xys"], g["radii"], g["conics"], g["opac"], tb, counts=False)
+    assert none is None and torch.equal(recs, recs2)
+    order2, cum2 = C.depth_order(g["depths"], g["radii"], None)
+    assert cum2 is None and torch.equal(order, order2)
+    count = torch.zeros(1, dtype=torch.int32).pin_memory()
+    ids_lean, bins_lean = C.bin_sorted(n, cap, order2, None, g["xys"], g["radii"], tb, bw, recs2, device_sized=True,
+                                       count_out=count)
+    torch.cuda.synchronize()
+    assert int(count[0]) == I
+    assert torch.equal(bins_lean, bins_full) and torch.equal(ids_lean[:I], ids_full)
+    # a list too short for the two-level path must not be asked for without counts
+    if W < 3000:
+        assert C.lists_need_counts(n, 100_000, tb, device_sized=True)
+        with pytest.raises(RuntimeError, match="cum_sorted may be NULL only"):
+            C.bin_sorted(n, 100_000, order2, None, g["xys"], g["radii"], tb, bw, recs2, device_sized=True,
+                         count_out=count)
+
+
 def test_count_reach_errors():
     import rasterizer.cuda as C
 

@@ -54,6 +54,12 @@ def main():
     t_ord, (order, cum) = timed(lambda: C.depth_order(depths, radii, cnt))
     I = int(cum[-1].item())
     t_bin, _ = timed(lambda: C.bin_sorted(n, I, order, cum, xys, radii, tb, 16, recs))
+    if os.environ.get("LEAN"):  # lists without counts (two-level partition only)
+        cap = int(1.3 * I)
+        assert not C.lists_need_counts(n, cap, tb), "these sizes take the single-pass path"
+        t_cnt, (_, recs) = timed(lambda: C.count_reach(xys, radii, conics, opac, tb, counts=False))
+        t_ord, (order, _) = timed(lambda: C.depth_order(depths, radii, None))
+        t_bin, _ = timed(lambda: C.bin_sorted(n, cap, order, None, xys, radii, tb, 16, recs, device_sized=True))
     print(f"n={n} I'={I} count_reach {t_cnt:.1f} us  depth_order {t_ord:.1f} us  bin_sorted {t_bin:.1f} us "
           f"(GSR_TILE_SORT={os.environ.get('GSR_TILE_SORT', '-')}, GSR_DBG={os.environ.get('GSR_DBG', '-')})")
 
