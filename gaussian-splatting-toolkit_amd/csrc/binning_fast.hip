@@ -400,10 +400,12 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
 // band need the per-band counts of gsr_count_reach, i.e. reach records.
 //   't': two-level partition (tile_partition2.hip), given ONE count per Gaussian (num_bands == 1)
 //        and the reach records: grids above 16384 tiles, and smaller grids whose lists hold at
-//        least GSR_P2_MIN + 3 N entries (default 3 M + 3 N).  Measured at 1080p, N and I in
-//        millions: two-level 66 + 48 N + 7.8 I us, single pass 40 + 23 N + 16.4 I us (uniform
-//        scenes; on spatially coherent ones -- many lanes of a step on one tile -- the
-//        single-pass walk is slower still).  Not when the caller wants slot_of_entry.
+//        least GSR_P2_MIN (default 1 M) + GSR_P2_PER_N (default 0) x N entries.  It needs neither
+//        the per-Gaussian counts nor their scan (gsr_bin_sorted_needs_counts), and with those
+//        gone it is ahead of the single pass from ~2 M entries on (bench.py, 1080p: 200 k Gaussians
+//        / 2.2 M entries 0.79 -> 0.77 ms per step, 1 M / 4.46 M 1.14 -> 1.12, 1 M / 11 M 1.08 -> 1.03;
+//        on spatially coherent scenes -- many lanes of a step on one tile -- the single-pass walk
+//        degrades further).  Not when the caller wants slot_of_entry.
 char tile_sort_mode(int tiles_x, int tiles_y, bool have_records, int num_bands, int num_points, int num_intersects,
                     bool want_slots) {
   static const char forced = [] {
@@ -412,13 +414,17 @@ char tile_sort_mode(int tiles_x, int tiles_y, bool have_records, int num_bands, 
   }();
   static const long long p2_min = [] {
     const char *e = getenv("GSR_P2_MIN");
-    return e ? atoll(e) : 3000000ll;
+    return e ? atoll(e) : 1000000ll;
+  }();
+  static const double p2_per_n = [] {
+    const char *e = getenv("GSR_P2_PER_N");
+    return e ? atof(e) : 0.0;
   }();
   if (forced == 'r' || forced == 'm') return forced;
   const int bands = gsr_tile_band_rows(tiles_x, tiles_y, nullptr);
   const bool p2_ok = have_records && num_bands == 1 && !want_slots && gsr_tile_partition2_supported(tiles_x, tiles_y);
   if (forced == 't' && p2_ok) return 't';
-  if (bands == 1) return (forced == '\0' && p2_ok && num_intersects >= p2_min + 3ll * num_points) ? 't' : 's';
+  if (bands == 1) return (forced == '\0' && p2_ok && num_intersects >= p2_min + (long long)(p2_per_n * num_points)) ? 't' : 's';
   if (!have_records) return 'r';
   if (num_bands == 1) return p2_ok ? 't' : 'r';
   return bands > 1 ? 's' : 'r';
@@ -477,7 +483,9 @@ int bin_sorted_impl(bool device_sized, int num_points, int num_intersects, const
   }
   GSR_REQUIRE(num_bands == bands, "bin_sorted: num_bands must be 1 or gsr_tile_bands() (with reach records)");
   const bool nothing = num_points == 0 || num_intersects == 0;
-  if (nothing || mode != 's') {  // the scatter path writes every entry of tile_bins itself
+  // (the scatter path writes every entry of tile_bins itself, and so does the two-level one for rows of
+  //  up to 256 tiles)
+  if (nothing || (mode != 's' && !(mode == 't' && tiles_x <= 256))) {
     hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
                        reinterpret_cast<int2 *>(tile_bins));
     GSR_CHECK_LAUNCH("bin_sorted(clear)");

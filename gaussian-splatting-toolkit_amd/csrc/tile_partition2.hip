@@ -75,6 +75,23 @@ __device__ __forceinline__ int block_excl(const int v, int *__restrict__ wsum, i
   return base + incl - v;
 }
 
+__device__ __forceinline__ long long block_excl64(const long long v, long long *__restrict__ wsum, long long &total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  long long incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const long long t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  long long base = 0;
+  for (int k = 0; k < w; ++k) base += wsum[k];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + incl - v;
+}
+
 __device__ __forceinline__ int load_slab(SlabItems &W, int *__restrict__ wsum, const int i, const int n,
                                          const int *__restrict__ order, const SplatRec *__restrict__ recs) {
   const int tid = threadIdx.x;
@@ -234,6 +251,7 @@ __global__ __launch_bounds__(kSlab) void emit_kernel(const Dims D, const int cap
   __shared__ unsigned long long smask[kMaskBlocks];
   __shared__ int blkfirst[kMaskBlocks];  // starts before the block
   __shared__ int wsum[4];
+  __shared__ long long wsum64[4];
   extern __shared__ int rows_lds[];      // 7 arrays of tiles_y ints
   const int ny = D.tiles_y;
   int *wcnt = rows_lds;                  // [4][ny] per-wave item counts of a row, then the waves' first slots
@@ -255,11 +273,16 @@ __global__ __launch_bounds__(kSlab) void emit_kernel(const Dims D, const int cap
     for (int r = tid; r < 4 * ny; r += kSlab) wcnt[r] = 0;
     for (int r = tid; r < ny; r += kSlab) bentc[r] = 0;
     __syncthreads();
-    // 1. the batch's items; wave w ranks items [w kItems/4, (w+1) kItems/4) by row, in item order
+    // 1. the batch's items; wave w ranks the w-th contiguous quarter of them (rounded up to whole
+    //    rounds of 64: a short batch still keeps all four waves busy) by row, in item order
+    const int per = ((nb + 255) >> 8) << 6;  // items per wave
     int rank[kR], myrow[kR];
 #pragma unroll
     for (int r = 0; r < kR; ++r) {
-      const int idx = w * (kItems / 4) + r * 64 + lane;
+      myrow[r] = -1;
+      rank[r] = 0;
+      if (r * 64 >= per) continue;  // (uniform)
+      const int idx = w * per + r * 64 + lane;
       int k = 0, ty = 0, t0 = 0, t1 = 0;
       if (idx < nb) item_of(W, qa + idx, total, k, ty, t0, t1);
       const int cnt = t1 - t0;
@@ -293,8 +316,12 @@ __global__ __launch_bounds__(kSlab) void emit_kernel(const Dims D, const int cap
           ce += bentc[r];
         }
       }
-      int run_i = block_excl(ci, wsum, nplaced);
-      int run_e = block_excl(ce, wsum, E);
+      // one scan for both: items in the low half (<= kItems per batch: no carry), entries in the high half
+      long long tot;
+      const long long ex = block_excl64(((long long)ce << 32) | (long long)ci, wsum64, tot);
+      int run_i = (int)(ex & 0xffffffffll), run_e = (int)(ex >> 32);
+      nplaced = (int)(tot & 0xffffffffll);
+      E = (int)(tot >> 32);
       for (int j = 0; j < rp; ++j) {
         const int r = tid * rp + j;
         if (r < ny) {
@@ -313,7 +340,7 @@ __global__ __launch_bounds__(kSlab) void emit_kernel(const Dims D, const int cap
     // 3. placement
 #pragma unroll
     for (int r = 0; r < kR; ++r)
-      if (myrow[r] >= 0) sorted[wcnt[w * ny + myrow[r]] + rank[r]] = (unsigned short)(w * (kItems / 4) + r * 64 + lane);
+      if (myrow[r] >= 0) sorted[wcnt[w * ny + myrow[r]] + rank[r]] = (unsigned short)(w * per + r * 64 + lane);
     __syncthreads();
     // 4. entry offsets of the sorted items (thread t: sorted items t kR .. t kR + kR - 1)
     {
@@ -481,6 +508,64 @@ __global__ __launch_bounds__(256) void colscan_kernel(const Dims D, const int *_
     run += v;
   }
   if (q == 3) tile_cnt[(size_t)row * D.tiles_x + tx] = (unsigned)run;
+}
+
+// ---- P5 + P6 in one launch for rows of up to 256 tiles: one workgroup of 16 waves per tile row
+// (4 column groups of 64 x 4 quarters of the row's chunks); the row's tiles start at the row's
+// segment start (the lists are row-major), so the prefix over the row's columns finishes
+// tile_bins without the separate launch over all tiles.
+__global__ __launch_bounds__(1024) void colscan_row_kernel(const Dims D, const int capacity,
+                                                           const int *__restrict__ row_start,
+                                                           const int *__restrict__ row_chunk_start,
+                                                           int *__restrict__ tableB, unsigned *__restrict__ tile_base,
+                                                           int *__restrict__ tile_bins) {
+  __shared__ int part[4][256];
+  __shared__ int s_tot[256];
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, cg = wv & 3, q = wv >> 2;
+  const int tx = cg * 64 + lane, row = blockIdx.x;
+  const int c0 = row_chunk_start[row], c1 = row_chunk_start[row + 1];
+  const int per = (c1 - c0 + 3) >> 2;
+  const int cb = min(c0 + q * per, c1), ce = min(cb + per, c1);
+  const bool live = tx < D.tiles_x;
+  int sum = 0;
+  if (live)
+    for (int c = cb; c < ce; ++c) sum += tableB[(size_t)c * D.txp + tx];
+  part[q][tx] = sum;
+  __syncthreads();
+  int run = 0;
+  for (int k = 0; k < q; ++k) run += part[k][tx];
+  if (live)
+    for (int c = cb; c < ce; ++c) {
+      int *p = tableB + (size_t)c * D.txp + tx;
+      const int v = *p;
+      *p = run;
+      run += v;
+    }
+  if (q == 3) s_tot[tx] = live ? run : 0;
+  __syncthreads();
+  if (tid < 256) {  // exclusive prefix over the row's columns
+    const int v = s_tot[tid];
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    s_tot[tid] = incl - v;
+  }
+  __syncthreads();
+  if (tid < D.tiles_x) {
+    int before = 0;
+    for (int k = 0; k < (tid >> 6); ++k) before += wsum[k];
+    const int v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    const int base = min(row_start[row], capacity) + before + s_tot[tid];
+    const size_t tile = (size_t)row * D.tiles_x + tid;
+    tile_base[tile] = (unsigned)base;
+    tile_bins[2 * tile] = v ? base : 0;
+    tile_bins[2 * tile + 1] = v ? base + v : 0;
+  }
 }
 
 // ---- P7: per chunk, rank by column in LDS (stream order kept), write runs -----------------
@@ -674,10 +759,15 @@ int gsr_tile_partition2(int n, int capacity, const int *order, const void *recs,
                      (const int *)tableA, (const int *)gtot, (const int *)row_start, txs, gids);
   hipLaunchKernelGGL(colhist_kernel, dim3(L.chunk_slots), dim3(256), 0, s, D, capacity, (const int *)row_start,
                      (const int *)row_chunk_start, (const unsigned short *)txs, tableB);
-  hipLaunchKernelGGL(colscan_kernel, dim3(gsr_cdiv(tiles_x, 64), tiles_y), dim3(256), 0, s, D,
-                     (const int *)row_chunk_start, tableB, tile_cnt);
-  int rc = gsr_tile_bases(tiles_x * tiles_y, tile_cnt, tile_bins, s);
-  if (rc != GSR_OK) return rc;
+  if (tiles_x <= 256) {
+    hipLaunchKernelGGL(colscan_row_kernel, dim3(tiles_y), dim3(1024), 0, s, D, capacity, (const int *)row_start,
+                       (const int *)row_chunk_start, tableB, tile_cnt, tile_bins);
+  } else {
+    hipLaunchKernelGGL(colscan_kernel, dim3(gsr_cdiv(tiles_x, 64), tiles_y), dim3(256), 0, s, D,
+                       (const int *)row_chunk_start, tableB, tile_cnt);
+    int rc = gsr_tile_bases(tiles_x * tiles_y, tile_cnt, tile_bins, s);
+    if (rc != GSR_OK) return rc;
+  }
   if (tiles_x <= 256)
     hipLaunchKernelGGL(colscatter_kernel<256>, dim3(L.chunk_slots), dim3(256), 0, s, D, capacity,
                        (const int *)row_start, (const int *)row_chunk_start, (const unsigned short *)txs,
