@@ -40,7 +40,10 @@ w = json.load(open(f"{out}/{tag}_pmc_WRITE_SIZE.json"))["counters"]
 names = {"project_fwd": "project_fwd_kernel", "sh_fwd": "sh16_fwd_kernel", "count_reach": None,
          "raster_fwd": "raster_fwd_tile16_kernel", "raster_bwd": "raster_bwd_tile16_kernel",
          "sh_bwd": "sh16_bwd_kernel", "project_bwd": "project_bwd_kernel",
-         "tile_scatter": "gsr_ts::scatter_kernel", "tile_rows": "tile_rows_kernel"}
+         "tile_scatter": "gsr_ts::scatter_kernel", "tile_rows": "tile_rows_kernel",
+         "p2_rowcount": "gsr_p2::rowcount_kernel", "p2_emit": "gsr_p2::emit_kernel",
+         "p2_colscatter": "gsr_p2::colscatter_kernel", "reach_records": "reach_records_kernel",
+         "sort_scatter": "gsr_sort::scatter_kernel"}
 t = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
               f"({tag}_pmc_FETCH_SIZE.json, {tag}_pmc_WRITE_SIZE.json): KB units, FETCH_SIZE doubled on gfx950 as "
               "MI355X_MICROARCH.md#HBM prescribes (calibrated there for wide coalesced reads; the compositing "
