@@ -1,6 +1,7 @@
-// tile_partition2.hip -- the per-tile depth-sorted lists of LARGE tile grids (above 16384
-// tiles: 4K at 16 px = 240 x 135) by a two-level partition whose every global store is
-// coalesced, gfx950.
+// tile_partition2.hip -- the per-tile depth-sorted lists by a two-level partition whose every
+// global store is coalesced, gfx950.  The list builder of every list of at least 1 M entries and
+// of every tile grid above 16384 tiles (binning_fast.hip: tile_sort_mode); it counts its entries
+// itself, so its callers need neither per-Gaussian counts nor their scan.
 //
 // Why: the single-pass tile scatter (tile_scatter.hip) writes each list entry as one 4-byte
 // store to its own cache line.  The L2 retires such partial-line writes at ~70-85 M per ms

@@ -165,8 +165,8 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  *     (band-major), gsr_depth_order scans them in (band, depth) order into
  *     cum_sorted[bands * n]; slower on large lists, but hands out slot_of_entry
  *     (deterministic backward).
- * Grids up to 16384 tiles: num_bands = 1; the single-pass scatter, or -- once the
- * lists are long (>= 3 M + 3 n entries) -- the two-level partition as well.
+ * Grids up to 16384 tiles: num_bands = 1; the two-level partition from 1 M list
+ * entries on, the single-pass scatter below (and whenever slot_of_entry is wanted).
  *
  * Lists without counts.  The two-level partition counts its entries itself (per tile
  * row, in depth order): where gsr_bin_sorted_needs_counts() returns 0 for the call
