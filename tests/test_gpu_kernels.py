@@ -6,6 +6,8 @@ whose discrete decisions are numerically stable (the oracle flags the others:
 |alpha - 1/255|, |T(1-alpha) - 1e-4| or |sigma| within 1e-5 relative -- a
 1-ulp difference in exp() legitimately flips those); gradients 1e-3 relative
 with an absolute floor of 1e-3 x max|grad| (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -575,6 +577,22 @@ def test_lists_without_counts_equal_the_full_flow(n, W, H, lo, hi):
         with pytest.raises(RuntimeError, match="cum_sorted may be NULL only"):
             C.bin_sorted(n, 100_000, order2, None, g["xys"], g["radii"], tb, bw, recs2, device_sized=True,
                          count_out=count)
+
+
+def test_list_builders_agree_on_random_shapes():
+    """tools/exp/fuzz_lists.py in a process of its own (GSR_TILE_SORT is read once per process): the
+    two-level partition forced onto every size -- 1 to 400 k Gaussians, 1 x 1 to 1024 x 17 tile grids,
+    sub-pixel to screen-filling splats -- builds the lists of the single-pass / banded scatter, with
+    and without counts, and cuts memory-safely at a capacity that is too small."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSR_TILE_SORT="t")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_lists.py"), "60", "11"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") >= 40
 
 
 def test_count_reach_errors():
