@@ -47,6 +47,7 @@ KERNELS = (
     ("depth_order", "depth_order"),
     ("bin_sorted", "bin_sorted"),
     ("rasterize_forward", "raster_fwd"),
+    ("rasterize_forward_ex", "raster_fwd"),
     ("rasterize_forward_rgbd", "raster_fwd"),
     ("rasterize_backward", "raster_bwd"),
     ("rasterize_backward_rgbd", "raster_bwd"),

@@ -629,6 +629,18 @@ GSR_EXPORT int gsr_rasterize_backward(
     const float *final_Ts, const int32_t *final_idx, const float *v_output,
     const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
     int deep_tile_threshold, gsr_stream_t stream) {
+  return gsr_rasterize_backward_ex(img_height, img_width, block_width, num_points, gaussian_ids_sorted, tile_bins,
+                                   xys, conics, colors, opacities, background, final_Ts, final_idx, v_output,
+                                   v_output_alpha, v_xy, v_conic, v_colors, v_opacity, deep_tile_threshold, 0, stream);
+}
+
+GSR_EXPORT int gsr_rasterize_backward_ex(
+    unsigned img_height, unsigned img_width, unsigned block_width, int num_points,
+    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+    const float *conics, const float *colors, const float *opacities, const float *background,
+    const float *final_Ts, const int32_t *final_idx, const float *v_output,
+    const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+    int deep_tile_threshold, int accumulators_zeroed, gsr_stream_t stream) {
   if (block_width != 16)
     return gsr_rasterize_backward_nd(img_height, img_width, block_width, 3, num_points,
                                      gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
@@ -642,8 +654,10 @@ GSR_EXPORT int gsr_rasterize_backward(
                   v_conic && v_colors && v_opacity,
               "rasterize_backward: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
-  if (rc != GSR_OK) return rc;
+  if (!accumulators_zeroed) {  // (else: cleared by gsr_rasterize_forward_ex's zero_ptr, untouched since)
+    int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
+    if (rc != GSR_OK) return rc;
+  }
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
   // A/B knob for the reduction group size (4 or 8 splats per butterfly)

@@ -55,7 +55,16 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ background, float *__restrict__ out_img,
     float *__restrict__ final_Ts, int *__restrict__ final_idx, const float *__restrict__ extra,
-    const float bg_extra, float *__restrict__ out_extra, const int deep_threshold, const unsigned base_grid) {
+    const float bg_extra, float *__restrict__ out_extra, const int deep_threshold, const unsigned base_grid,
+    float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr, const unsigned zero_words) {
+  // (gsr_rasterize_forward_ex) the launch also clears `zero_words` words at `zero_ptr` -- the gradient
+  // accumulators of the coming backward: 36 MB of stores that vanish inside this VALU-bound kernel
+  // instead of a bandwidth-bound launch of their own -- every workgroup its slice, before any exit
+  if (zero_ptr) {
+    const unsigned per = (zero_words + gridDim.x - 1) / gridDim.x;
+    const unsigned w0 = blockIdx.x * per, w1 = min(w0 + per, zero_words);
+    for (unsigned i = w0 + threadIdx.x; i < w1; i += 64) zero_ptr[i] = 0u;
+  }
   __shared__ SplatA sA[kChunk];
   __shared__ SplatB sB[kChunk];
   __shared__ SplatC sC[kChunk];
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       const size_t pid = (size_t)row * img_w + col;
       const float Tp = fabsf(T[p]);
       final_Ts[pid] = Tp;
+      if (out_alpha) out_alpha[pid] = 1.f - Tp;
       final_idx[pid] = last[p];
       out_img[3 * pid] = cr[p] + Tp * bg0;
       out_img[3 * pid + 1] = cg[p] + Tp * bg1;
@@ -298,11 +308,29 @@ GSR_EXPORT int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_wi
                                      const float *opacities, const float *background,
                                      float *out_img, float *final_Ts, int32_t *final_idx,
                                      int deep_tile_threshold, gsr_stream_t stream) {
+  return gsr_rasterize_forward_ex(tiles_x, tiles_y, block_width, img_width, img_height, gaussian_ids_sorted,
+                                  tile_bins, xys, conics, colors, opacities, background, out_img, final_Ts,
+                                  final_idx, deep_tile_threshold, nullptr, nullptr, 0, stream);
+}
+
+GSR_EXPORT int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block_width,
+                                        unsigned img_width, unsigned img_height,
+                                        const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                                        const float *xys, const float *conics, const float *colors,
+                                        const float *opacities, const float *background,
+                                        float *out_img, float *final_Ts, int32_t *final_idx,
+                                        int deep_tile_threshold, float *out_alpha, void *zero_ptr,
+                                        size_t zero_bytes, gsr_stream_t stream) {
   int rc = check_common("rasterize_forward", tiles_x, tiles_y, block_width, img_width, img_height, 3);
   if (rc != GSR_OK) return rc;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities &&
                   background && out_img && final_Ts && final_idx,
               "rasterize_forward: null pointer");
+  GSR_REQUIRE((out_alpha == nullptr && zero_ptr == nullptr) || block_width == 16,
+              "rasterize_forward_ex: out_alpha / zero_ptr need block_width 16");
+  GSR_REQUIRE(zero_ptr == nullptr || ((zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0 &&
+                                      zero_bytes < ((size_t)1 << 34)),
+              "rasterize_forward_ex: zero_ptr / zero_bytes must be multiples of 4 (and below 16 GB)");
   if (block_width != 16)
     return launch_generic(tiles_x, tiles_y, block_width, img_width, img_height, 3,
                           gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
@@ -314,7 +342,8 @@ GSR_EXPORT int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_wi
                      (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
-                     out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base);
+                     out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base,
+                     out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2));
   GSR_CHECK_LAUNCH("rasterize_forward(tile16)");
   return GSR_OK;
 }
@@ -338,7 +367,8 @@ GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img
                      (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
-                     out_img, final_Ts, final_idx, extra, extra_background, out_extra, deep, base);
+                     out_img, final_Ts, final_idx, extra, extra_background, out_extra, deep, base,
+                     (float *)nullptr, (unsigned *)nullptr, 0u);
   GSR_CHECK_LAUNCH("rasterize_forward_rgbd");
   return GSR_OK;
 }

@@ -106,19 +106,25 @@ class _Render(Function):
             order, cum = _C.depth_order(depths, radii, counts)
             ids, bins = _C.bin_sorted(n, capacity, order, cum, xys, radii, tb, BLOCK, recs, device_sized=True,
                                       count_out=count_out)
+            acc, alpha = None, None
             if spec.render_depth:
                 img, dep, Ts, idx = _C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, xys, conics, colors, depths,
                                                               opac, background, 0.0)
             else:
-                img, Ts, idx = _C.rasterize_forward(tb, (BLOCK, BLOCK, 1), (W, H, 1), ids, bins, xys, conics, colors,
-                                                    opac, background)
+                # alpha = 1 - T and the backward's cleared accumulators come out of the compositing launch
+                if any(ctx.needs_input_grad[:6]):
+                    acc = _C.backward_accumulators(n, 3, dev)
+                img, Ts, idx, alpha = _C.rasterize_forward_ex(tb, (BLOCK, BLOCK, 1), (W, H, 1), ids, bins, xys, conics,
+                                                              colors, opac, background, want_alpha=True, zero=acc)
                 dep = None
         ctx.spec, ctx.stats, ctx.degree = spec, stats, degree
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means, raw_quats, features_dc, features_rest, viewmat, projmat, background, scales, quats,
                               opac, dirs, cov3d, xys, depths, radii, conics, comp, colors, ids, bins, Ts, idx)
         ctx.mark_non_differentiable(radii)
-        alpha = 1 - Ts
+        ctx.accumulators = acc
+        if alpha is None:
+            alpha = 1 - Ts
         if dep is None:
             return img, alpha, radii
         return img, alpha, radii, dep
@@ -141,8 +147,10 @@ class _Render(Function):
                 v_xy, v_conic, v_colors, v_depths, v_opac = _C.rasterize_backward_rgbd(
                     H, W, ids, bins, xys, conics, colors, depths, opac, background, 0.0, Ts, idx, v_img, v_dep, v_a)
             else:
+                acc, ctx.accumulators = ctx.accumulators, None
                 v_xy, v_conic, v_colors, v_opac = _C.rasterize_backward(
-                    H, W, BLOCK, ids, bins, xys, conics, colors, opac, background, Ts, idx, v_img, v_a)
+                    H, W, BLOCK, ids, bins, xys, conics, colors, opac, background, Ts, idx, v_img, v_a,
+                    accumulators=acc)
                 v_depths = None
             if stats is not None and stats.enabled:
                 _call("gsr_densify_stats_dev", C.c_int(n), _ptr(v_xy), _ptr(radii), C.c_float(1.0 / stats.max_dim),

@@ -416,8 +416,18 @@ def _deep_knobs():
     return _deep_cache["v"]
 
 
+def rasterize_forward_ex(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
+                         colors, opacities, background, want_alpha=False, zero=None):
+    """``gsr_rasterize_forward_ex`` (16x16 tiles, 3 channels): -> (out_img, final_Ts, final_idx, alpha or None);
+    ``alpha = 1 - final_Ts`` written by the kernel; ``zero``: a float32 tensor the launch clears (the
+    accumulators of the coming :func:`rasterize_backward` -- see ``accumulators``)."""
+    return _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys,
+                              conics, colors, opacities, background, nd=False, want_alpha=want_alpha, zero=zero,
+                              ex=True)
+
+
 def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
-                       colors, opacities, background, nd: bool):
+                       colors, opacities, background, nd: bool, want_alpha: bool = False, zero=None, ex: bool = False):
     _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
     channels = colors.size(1)
     W, H = int(img_size[0]), int(img_size[1])
@@ -436,6 +446,16 @@ def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_b
             if channels != 3:
                 raise RuntimeError("rasterize_forward expects 3 channels; use nd_rasterize_forward")
             deep = deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])
+            if ex:
+                if zero is not None:
+                    _check(zero, "zero", _f32)
+                    if zero.numel() == 0:
+                        zero = None
+                alpha = torch.empty((H, W), dtype=_f32, device=dev) if want_alpha else None
+                _call("gsr_rasterize_forward_ex", *head, *tail, C.c_int(deep),
+                      _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero is not None else None,
+                      C.c_size_t(zero.numel() * 4 if zero is not None else 0), _stream(dev))
+                return out_img, final_Ts, final_idx, alpha
             _call("gsr_rasterize_forward", *head, *tail, C.c_int(deep), _stream(dev))
     return out_img, final_Ts, final_idx
 
@@ -550,9 +570,17 @@ def rasterize_backward_det(img_height, img_width, gaussian_ids_sorted, tile_bins
     return v_xy, v_conic, v_colors, v_opacity
 
 
+def backward_accumulators(n: int, channels: int, device) -> Tensor:
+    """The flat float32 buffer :func:`rasterize_backward` carves ``v_xy | v_conic | v_colors | v_opacity``
+    out of.  Cleared by ``rasterize_forward_ex(zero=...)`` and handed back as ``accumulators`` it spares
+    the backward its own zero fill."""
+    with torch.cuda.device(device):
+        return torch.empty((n * (6 + channels),), dtype=_f32, device=device)
+
+
 def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
                         conics, colors, opacities, background, final_Ts, final_idx, v_output,
-                        v_output_alpha, nd: bool):
+                        v_output_alpha, nd: bool, accumulators: Optional[Tensor] = None):
     _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
     if not nd and colors.size(1) != 3:
         raise RuntimeError("colors must have 2 dimensions")  # message of bindings.cu:494-496
@@ -566,7 +594,11 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
     with torch.cuda.device(dev):
         # four contiguous tensors carved out of one allocation: the library
         # zero-fills them with a single memset when they are back to back
-        flat = torch.empty((n * (6 + channels),), dtype=_f32, device=dev)
+        zeroed = accumulators is not None and not nd and block_width == 16
+        if zeroed and (accumulators.numel() != n * (6 + channels) or accumulators.dtype != _f32 or
+                       not accumulators.is_contiguous()):
+            raise RuntimeError("rasterize_backward: accumulators must be backward_accumulators(n, channels, device)")
+        flat = accumulators if zeroed else torch.empty((n * (6 + channels),), dtype=_f32, device=dev)
         v_xy = flat[: 2 * n].view(n, 2)
         v_conic = flat[2 * n: 5 * n].view(n, 3)
         v_colors = flat[5 * n: (5 + channels) * n].view(n, channels)
@@ -580,19 +612,24 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
             _call("gsr_rasterize_backward_nd", *head, C.c_uint(channels), *tail, _stream(dev))
         else:
             tiles = ((img_width + block_width - 1) // block_width) * ((img_height + block_width - 1) // block_width)
-            _call("gsr_rasterize_backward", *head, *tail,
-                  C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)), _stream(dev))
+            if zeroed:
+                _call("gsr_rasterize_backward_ex", *head, *tail,
+                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)), C.c_int(1), _stream(dev))
+            else:
+                _call("gsr_rasterize_backward", *head, *tail,
+                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)), _stream(dev))
     return v_xy, v_conic, v_colors, v_opacity
 
 
 def rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
                        conics, colors, opacities, background, final_Ts, final_idx, v_output,
-                       v_output_alpha):
+                       v_output_alpha, accumulators: Optional[Tensor] = None):
     """-> (v_xy, v_conic, v_colors, v_opacity [N,1]);
-    replaces ``rasterize_backward_tensor`` (bindings.cu:476-528)."""
+    replaces ``rasterize_backward_tensor`` (bindings.cu:476-528).  ``accumulators``: a
+    :func:`backward_accumulators` buffer already cleared by :func:`rasterize_forward_ex`."""
     return _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins,
                                xys, conics, colors, opacities, background, final_Ts, final_idx,
-                               v_output, v_output_alpha, nd=False)
+                               v_output, v_output_alpha, nd=False, accumulators=accumulators)
 
 
 def nd_rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,

@@ -40,6 +40,8 @@ SYMBOLS = (
     "gsr_publish_int32",
     "gsr_rasterize_forward",
     "gsr_rasterize_backward",
+    "gsr_rasterize_forward_ex",
+    "gsr_rasterize_backward_ex",
     "gsr_rasterize_forward_nd",
     "gsr_rasterize_backward_nd",
     "gsr_cov2d_bounds",

@@ -361,9 +361,21 @@ class _RasterizeGaussians(Function):
         block = (block_width, block_width, 1)
         img_size = (img_width, img_height, 1)
         rasterize_fn = _C.rasterize_forward if colors.shape[-1] == 3 else _C.nd_rasterize_forward
+        # 16x16 tiles, 3 channels: the compositing kernel also writes alpha = 1 - T and, when a
+        # backward will follow, clears that backward's accumulators (gsr_rasterize_forward_ex)
+        fused = block_width == 16 and colors.shape[-1] == 3
+        acc = None
+        if fused and any(ctx.needs_input_grad[i] for i in (0, 3, 5, 6)) and not _deterministic["on"]:
+            acc = _C.backward_accumulators(xys.size(0), 3, xys.device)
+        alpha_out = [None]
 
         def composite(ids, bins):
-            return rasterize_fn(tile_bounds, block, img_size, ids, bins, xys, conics, colors, opacity, background)
+            if not fused:
+                return rasterize_fn(tile_bounds, block, img_size, ids, bins, xys, conics, colors, opacity, background)
+            img, Ts, idx, alpha_out[0] = _C.rasterize_forward_ex(tile_bounds, block, img_size, ids, bins, xys, conics,
+                                                                 colors, opacity, background, want_alpha=return_alpha,
+                                                                 zero=acc)
+            return img, Ts, idx
 
         num_intersects, gaussian_ids_sorted, tile_bins, finish = build_tile_lists(
             xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width)
@@ -380,6 +392,7 @@ class _RasterizeGaussians(Function):
             tile_bins = torch.zeros(0, 2, device=xys.device)
             final_Ts = torch.zeros(img_height, img_width, device=xys.device)
             final_idx = torch.zeros(img_height, img_width, device=xys.device)
+            acc, alpha_out[0] = None, None
         elif finish is None:
             out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
 
@@ -391,11 +404,12 @@ class _RasterizeGaussians(Function):
                                              colors.shape[-1] == 3 and _bin_cache["value"] is not None) else None
         ctx.num_intersects = num_intersects
         ctx.block_width = block_width
+        ctx.accumulators = acc  # cleared by the forward launch; used (once) by the backward
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity,
                               background, final_Ts, final_idx)
 
         if return_alpha:
-            return out_img, 1 - final_Ts
+            return out_img, (alpha_out[0] if alpha_out[0] is not None else 1 - final_Ts)
         return out_img
 
     @staticmethod
@@ -419,11 +433,16 @@ class _RasterizeGaussians(Function):
                     ctx.img_height, ctx.img_width, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity,
                     background, final_Ts, final_idx, v_out_img, v_out_alpha, *ctx.det)
             else:
-                rasterize_fn = _C.rasterize_backward if colors.shape[-1] == 3 else _C.nd_rasterize_backward
-                v_xy, v_conic, v_colors, v_opacity = rasterize_fn(
-                    ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
-                    conics, colors, opacity, background, final_Ts, final_idx, v_out_img, v_out_alpha,
-                )
+                acc, ctx.accumulators = ctx.accumulators, None  # a second backward (retain_graph) clears its own
+                if colors.shape[-1] == 3:
+                    v_xy, v_conic, v_colors, v_opacity = _C.rasterize_backward(
+                        ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
+                        conics, colors, opacity, background, final_Ts, final_idx, v_out_img, v_out_alpha,
+                        accumulators=acc)
+                else:
+                    v_xy, v_conic, v_colors, v_opacity = _C.nd_rasterize_backward(
+                        ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
+                        conics, colors, opacity, background, final_Ts, final_idx, v_out_img, v_out_alpha)
             v_opacity = v_opacity.reshape(opacity.shape)
 
         # xys, depths, radii, conics, num_tiles_hit, colors, opacity, then 5 non-differentiable

@@ -263,6 +263,36 @@ int gsr_rasterize_backward(unsigned img_height, unsigned img_width,
                            float *v_opacity, int deep_tile_threshold,
                            gsr_stream_t stream);
 
+/* The same two calls with what `_RasterizeGaussians.forward` does around them folded in
+ * (rasterize.py:145-176: `out_alpha = 1 - final_Ts`; the backward's zero-filled
+ * accumulators).  block_width 16 only when the extras are used.
+ *   out_alpha (nullable) [H,W]: 1 - final_Ts, written by the compositing kernel;
+ *   zero_ptr / zero_bytes (nullable; multiples of 4): cleared by the forward launch --
+ *     pass the backward's accumulators (v_xy .. v_opacity as one allocation), keep them
+ *     untouched, and call gsr_rasterize_backward_ex with accumulators_zeroed = 1: the
+ *     36 MB of stores at 1 M Gaussians disappear inside the VALU-bound forward kernel
+ *     instead of taking a bandwidth-bound launch of their own. */
+int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block_width,
+                             unsigned img_width, unsigned img_height,
+                             const int32_t *gaussian_ids_sorted,
+                             const int32_t *tile_bins, const float *xys,
+                             const float *conics, const float *colors,
+                             const float *opacities, const float *background,
+                             float *out_img, float *final_Ts, int32_t *final_idx,
+                             int deep_tile_threshold, float *out_alpha,
+                             void *zero_ptr, size_t zero_bytes, gsr_stream_t stream);
+int gsr_rasterize_backward_ex(unsigned img_height, unsigned img_width,
+                              unsigned block_width, int num_points,
+                              const int32_t *gaussian_ids_sorted,
+                              const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors,
+                              const float *opacities, const float *background,
+                              const float *final_Ts, const int32_t *final_idx,
+                              const float *v_output, const float *v_output_alpha,
+                              float *v_xy, float *v_conic, float *v_colors,
+                              float *v_opacity, int deep_tile_threshold,
+                              int accumulators_zeroed, gsr_stream_t stream);
+
 /* generic channel count; replace nd_rasterize_forward_tensor /
  * nd_rasterize_backward_tensor (bindings.cu:330-469), kernels
  * forward.cu:159-276 / backward.cu:23-131.  Accumulation is fp32 here (the

@@ -195,6 +195,56 @@ def test_depth_pass_and_binning_cache():
     assert R._geometry_key(xys, out["depths"], out["radii"], out["num_tiles_hit"], 96, 160, 16) != key_before
 
 
+def test_forward_ex_alpha_and_prezeroed_accumulators():
+    """gsr_rasterize_forward_ex: alpha written by the kernel is exactly 1 - final_Ts, the zero region is
+    cleared whatever it held, and a backward on those accumulators equals the backward that clears its
+    own; through the public op, a second backward (retain_graph) -- which finds the accumulators used
+    up -- gives the same gradients as the first."""
+    import rasterizer.cuda as C
+    from rasterizer.project_gaussians import project_gaussians
+    from rasterizer.rasterize import rasterize_gaussians
+
+    n, W, H = 20_000, 320, 208
+    cam = S.make_camera(W, H, yaw=0.05)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=9, scale_lo=0.01, scale_hi=0.08)
+    means, scales, quats, opac = (cu(sc[k]) for k in ("means3d", "scales", "quats", "opacities"))
+    cov3d, xys, depths, radii, conics, comp, tiles = C.project_gaussians_forward(
+        n, means, scales, 1.0, quats, cu(cam.viewmat[:3]), cu(cam.projmat), cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16, 0.01)
+    order, cum = C.depth_order(depths, radii, tiles)
+    I = int(cum[-1].item())
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    ids, bins = C.bin_sorted(n, I, order, cum, xys, radii, tb, 16)
+    rng = np.random.default_rng(0)
+    colors, bg = cu(rng.uniform(0, 1, (n, 3)).astype(np.float32)), cu(np.array(S.BACKGROUND, np.float32))
+    img0, Ts0, idx0 = C.rasterize_forward(tb, (16, 16, 1), (W, H, 1), ids, bins, xys, conics, colors, opac, bg)
+    acc = C.backward_accumulators(n, 3, DEV)
+    acc.fill_(float("nan"))
+    img1, Ts1, idx1, alpha = C.rasterize_forward_ex(tb, (16, 16, 1), (W, H, 1), ids, bins, xys, conics, colors, opac, bg,
+                                                    want_alpha=True, zero=acc)
+    assert torch.equal(img0, img1) and torch.equal(Ts0, Ts1) and torch.equal(idx0, idx1)
+    assert torch.equal(alpha, 1 - Ts1) and bool((acc == 0).all())
+    v_img = cu(rng.standard_normal((H, W, 3)).astype(np.float32))
+    v_alpha = cu(rng.standard_normal((H, W)).astype(np.float32))
+    ref = C.rasterize_backward(H, W, 16, ids, bins, xys, conics, colors, opac, bg, Ts0, idx0, v_img, v_alpha)
+    got = C.rasterize_backward(H, W, 16, ids, bins, xys, conics, colors, opac, bg, Ts0, idx0, v_img, v_alpha,
+                               accumulators=acc)
+    for a, b in zip(got, ref):  # same sums, atomic order differs
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+    with pytest.raises(RuntimeError, match="accumulators must be"):
+        C.rasterize_backward(H, W, 16, ids, bins, xys, conics, colors, opac, bg, Ts0, idx0, v_img, v_alpha,
+                             accumulators=acc[:-1])
+    # public op: two backwards over one graph
+    xy_l, con_l, col_l, op_l = (t.clone().requires_grad_(True) for t in (xys, conics, colors, opac))
+    rgb, al = rasterize_gaussians(xy_l, depths, radii, con_l, tiles, col_l, op_l, H, W, 16, background=bg,
+                                  return_alpha=True)
+    loss = (rgb * v_img).sum() + (al * v_alpha).sum()
+    g1 = torch.autograd.grad(loss, (xy_l, con_l, col_l, op_l), retain_graph=True)
+    g2 = torch.autograd.grad(loss, (xy_l, con_l, col_l, op_l))
+    for a, b, r in zip(g1, g2, ref):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+        assert float((a.reshape(r.shape) - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-12
+
+
 def test_empty_scene_and_all_culled():
     from rasterizer import project_gaussians, rasterize_gaussians
 
