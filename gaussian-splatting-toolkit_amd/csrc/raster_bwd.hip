@@ -689,7 +689,7 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
     const float *opacities, const float *background, float extra_background, const float *final_Ts,
     const int32_t *final_idx, const float *v_output, const float *v_output_extra, const float *v_output_alpha,
     float *v_xy, float *v_conic, float *v_colors, float *v_extra, float *v_opacity, int deep_tile_threshold,
-    gsr_stream_t stream) {
+    int accumulators_zeroed, gsr_stream_t stream) {
   GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward_rgbd: empty image");
   GSR_REQUIRE(num_points >= 0, "rasterize_backward_rgbd: num_points < 0");
   if (num_points == 0) return GSR_OK;
@@ -698,9 +698,11 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
                   v_opacity,
               "rasterize_backward_rgbd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
-  if (rc != GSR_OK) return rc;
-  if (int zrc = gsr_zero_async(v_extra, sizeof(float) * (size_t)num_points, s)) return zrc;
+  if (!accumulators_zeroed) {  // (else: cleared by gsr_rasterize_forward_rgbd's zero_ptr)
+    int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
+    if (rc != GSR_OK) return rc;
+    if (int zrc = gsr_zero_async(v_extra, sizeof(float) * (size_t)num_points, s)) return zrc;
+  }
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);

@@ -354,12 +354,16 @@ GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img
                                           const float *extra, const float *opacities,
                                           const float *background, float extra_background, float *out_img,
                                           float *out_extra, float *final_Ts, int32_t *final_idx,
-                                          int deep_tile_threshold, gsr_stream_t stream) {
+                                          int deep_tile_threshold, float *out_alpha, void *zero_ptr,
+                                          size_t zero_bytes, gsr_stream_t stream) {
   int rc = check_common("rasterize_forward_rgbd", tiles_x, tiles_y, 16, img_width, img_height, 3);
   if (rc != GSR_OK) return rc;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && extra && opacities && background &&
                   out_img && out_extra && final_Ts && final_idx,
               "rasterize_forward_rgbd: null pointer");
+  GSR_REQUIRE(zero_ptr == nullptr || ((zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0 &&
+                                      zero_bytes < ((size_t)1 << 34)),
+              "rasterize_forward_rgbd: zero_ptr / zero_bytes must be multiples of 4 (and below 16 GB)");
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
   const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
@@ -368,7 +372,7 @@ GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
                      out_img, final_Ts, final_idx, extra, extra_background, out_extra, deep, base,
-                     (float *)nullptr, (unsigned *)nullptr, 0u);
+                     out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2));
   GSR_CHECK_LAUNCH("rasterize_forward_rgbd");
   return GSR_OK;
 }

@@ -107,13 +107,14 @@ class _Render(Function):
             ids, bins = _C.bin_sorted(n, capacity, order, cum, xys, radii, tb, BLOCK, recs, device_sized=True,
                                       count_out=count_out)
             acc, alpha = None, None
+            # alpha = 1 - T and the backward's cleared accumulators come out of the compositing launch
+            if any(ctx.needs_input_grad[:6]):
+                acc = _C.backward_accumulators(n, 4 if spec.render_depth else 3, dev)
             if spec.render_depth:
-                img, dep, Ts, idx = _C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, xys, conics, colors, depths,
-                                                              opac, background, 0.0)
+                img, dep, Ts, idx, alpha = _C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, xys, conics, colors,
+                                                                     depths, opac, background, 0.0, want_alpha=True,
+                                                                     zero=acc)
             else:
-                # alpha = 1 - T and the backward's cleared accumulators come out of the compositing launch
-                if any(ctx.needs_input_grad[:6]):
-                    acc = _C.backward_accumulators(n, 3, dev)
                 img, Ts, idx, alpha = _C.rasterize_forward_ex(tb, (BLOCK, BLOCK, 1), (W, H, 1), ids, bins, xys, conics,
                                                               colors, opac, background, want_alpha=True, zero=acc)
                 dep = None
@@ -144,8 +145,10 @@ class _Render(Function):
             if spec.render_depth:
                 if v_dep is None:
                     v_dep = torch.zeros(H, W, device=dev)
+                acc, ctx.accumulators = ctx.accumulators, None
                 v_xy, v_conic, v_colors, v_depths, v_opac = _C.rasterize_backward_rgbd(
-                    H, W, ids, bins, xys, conics, colors, depths, opac, background, 0.0, Ts, idx, v_img, v_dep, v_a)
+                    H, W, ids, bins, xys, conics, colors, depths, opac, background, 0.0, Ts, idx, v_img, v_dep, v_a,
+                    accumulators=acc)
             else:
                 acc, ctx.accumulators = ctx.accumulators, None
                 v_xy, v_conic, v_colors, v_opac = _C.rasterize_backward(

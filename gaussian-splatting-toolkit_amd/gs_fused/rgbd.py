@@ -42,9 +42,19 @@ class _RasterizeRGBD(Function):
             xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, BLOCK)
         dev = xys.device
 
+        from rasterizer import rasterize as _R
+
+        # alpha = 1 - T and the backward's cleared accumulators come out of the compositing launch
+        acc = None
+        if any(ctx.needs_input_grad[i] for i in (0, 3, 5, 6, 7)) and not _R.is_deterministic():
+            acc = _C.backward_accumulators(n, 4, dev)
+        alpha_out = [None]
+
         def composite(ids, bins):
-            return _C.rasterize_forward_rgbd(tile_bounds, (img_width, img_height, 1), ids, bins, xys, conics, colors,
-                                             extra, opacity, background, extra_background)
+            img_, ext_, Ts_, idx_, alpha_out[0] = _C.rasterize_forward_rgbd(
+                tile_bounds, (img_width, img_height, 1), ids, bins, xys, conics, colors, extra, opacity, background,
+                extra_background, want_alpha=True, zero=acc)
+            return img_, ext_, Ts_, idx_
 
         if finish is not None:  # lists sized from the previous view: composite, then check the count
             img, ext, Ts, idx = composite(ids, bins)
@@ -63,14 +73,14 @@ class _RasterizeRGBD(Function):
             idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
             ids = torch.zeros(0, dtype=torch.int32, device=dev)
             bins = torch.zeros(0, 2, dtype=torch.int32, device=dev)
-        from rasterizer import rasterize as _R
-
+            acc, alpha_out[0] = None, None
+        ctx.accumulators = acc
         ctx.det = _R._bin_cache["value"][3] if (_R.is_deterministic() and num_intersects >= 1 and
                                                 _R._bin_cache["value"] is not None) else None
         ctx.set_materialize_grads(False)
         ctx.meta = (img_height, img_width, num_intersects, float(extra_background))
         ctx.save_for_backward(ids, bins, xys, conics, colors, extra, opacity, background, Ts, idx)
-        return img, 1 - Ts, ext
+        return img, (alpha_out[0] if alpha_out[0] is not None else 1 - Ts), ext
 
     @staticmethod
     def backward(ctx, v_img, v_alpha, v_ext):
@@ -88,9 +98,10 @@ class _RasterizeRGBD(Function):
                 H, W, ids, bins, xys, conics, colors, opacity, background, Ts, idx, v_img, v_alpha, *ctx.det,
                 extra=extra, extra_background=ebg, v_output_extra=v_ext)
         else:
+            acc, ctx.accumulators = ctx.accumulators, None  # a second backward (retain_graph) clears its own
             v_xy, v_conic, v_colors, v_extra, v_opacity = _C.rasterize_backward_rgbd(
                 H, W, ids, bins, xys, conics, colors, extra, opacity, background, ebg, Ts, idx, v_img, v_ext,
-                v_alpha)
+                v_alpha, accumulators=acc)
         return (v_xy, None, None, v_conic, None, v_colors, v_extra.view(extra.shape),
                 v_opacity.reshape(opacity.shape)) + (None,) * 4
 

@@ -477,9 +477,11 @@ def nd_rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile
 
 
 def rasterize_forward_rgbd(tile_bounds, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors, extra,
-                           opacities, background, extra_background: float):
+                           opacities, background, extra_background: float, want_alpha: bool = False, zero=None):
     """RGB + one extra channel in one pass (``gsr_rasterize_forward_rgbd``, 16x16 tiles):
-    -> (out_img [H,W,3], out_extra [H,W], final_Ts [H,W], final_idx i32[H,W])."""
+    -> (out_img [H,W,3], out_extra [H,W], final_Ts [H,W], final_idx i32[H,W]) [+ alpha = 1 - final_Ts
+    when ``want_alpha``].  ``zero``: a float32 tensor the launch clears (``backward_accumulators(n, 4, dev)``
+    for the coming :func:`rasterize_backward_rgbd`)."""
     _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
     _check(extra, "extra", _f32)
     if colors.size(1) != 3 or extra.numel() != xys.size(0):
@@ -491,19 +493,26 @@ def rasterize_forward_rgbd(tile_bounds, img_size, gaussian_ids_sorted, tile_bins
         ext = torch.empty((H, W), dtype=_f32, device=dev)
         Ts = torch.empty((H, W), dtype=_f32, device=dev)
         idx = torch.empty((H, W), dtype=_i32, device=dev)
+        alpha = torch.empty((H, W), dtype=_f32, device=dev) if want_alpha else None
+        if zero is not None:
+            _check(zero, "zero", _f32)
         _call("gsr_rasterize_forward_rgbd", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(W),
               C.c_uint(H), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
               _ptr(extra), _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(img), _ptr(ext),
               _ptr(Ts), _ptr(idx),
               C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])),
-              _stream(dev))
+              _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero is not None else None,
+              C.c_size_t(zero.numel() * 4 if zero is not None else 0), _stream(dev))
+    if want_alpha:
+        return img, ext, Ts, idx, alpha
     return img, ext, Ts, idx
 
 
 def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bins, xys, conics, colors, extra,
                             opacities, background, extra_background, final_Ts, final_idx, v_output,
-                            v_output_extra, v_output_alpha):
-    """-> (v_xy, v_conic, v_colors, v_extra [N], v_opacity [N,1]); ``gsr_rasterize_backward_rgbd``."""
+                            v_output_extra, v_output_alpha, accumulators: Optional[Tensor] = None):
+    """-> (v_xy, v_conic, v_colors, v_extra [N], v_opacity [N,1]); ``gsr_rasterize_backward_rgbd``.
+    ``accumulators``: ``backward_accumulators(n, 4, dev)`` already cleared by the forward launch."""
     _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
     _check(extra, "extra", _f32)
     v_output = _check(v_output.contiguous(), "v_output", _f32)
@@ -513,7 +522,10 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
     n = xys.size(0)
     dev = xys.device
     with torch.cuda.device(dev):
-        flat = torch.empty((n * 10,), dtype=_f32, device=dev)
+        if accumulators is not None and (accumulators.numel() != n * 10 or accumulators.dtype != _f32 or
+                                         not accumulators.is_contiguous()):
+            raise RuntimeError("rasterize_backward_rgbd: accumulators must be backward_accumulators(n, 4, device)")
+        flat = accumulators if accumulators is not None else torch.empty((n * 10,), dtype=_f32, device=dev)
         v_xy, v_conic = flat[: 2 * n].view(n, 2), flat[2 * n: 5 * n].view(n, 3)
         v_colors, v_opacity = flat[5 * n: 8 * n].view(n, 3), flat[8 * n: 9 * n].view(n, 1)
         v_extra = flat[9 * n:]
@@ -524,7 +536,8 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
               _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic),
               _ptr(v_colors), _ptr(v_extra), _ptr(v_opacity),
               C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(),
-                                          ((img_width + 15) // 16) * ((img_height + 15) // 16))), _stream(dev))
+                                          ((img_width + 15) // 16) * ((img_height + 15) // 16))),
+              C.c_int(1 if accumulators is not None else 0), _stream(dev))
     return v_xy, v_conic, v_colors, v_extra, v_opacity
 
 

@@ -397,7 +397,9 @@ int gsr_sh_backward_split(unsigned num_points, unsigned degree,
  * (one scalar per Gaussian, e.g. its depth) together: out_img [H,W,3] over
  * `background`, out_extra [H,W] over `extra_background`; final_Ts / final_idx as
  * gsr_rasterize_forward.  block_width is 16.  The backward takes the cotangents of
- * both images (and of alpha, NULL = 0) and returns v_extra [n] next to the usual four. */
+ * both images (and of alpha, NULL = 0) and returns v_extra [n] next to the usual four.
+ * out_alpha / zero_ptr / zero_bytes / accumulators_zeroed: as in gsr_rasterize_forward_ex /
+ * gsr_rasterize_backward_ex (the accumulators are v_xy .. v_opacity, v_extra: 10 n floats). */
 int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img_width,
                                unsigned img_height,
                                const int32_t *gaussian_ids_sorted,
@@ -407,7 +409,9 @@ int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img_width,
                                const float *background, float extra_background,
                                float *out_img, float *out_extra,
                                float *final_Ts, int32_t *final_idx,
-                               int deep_tile_threshold, gsr_stream_t stream);
+                               int deep_tile_threshold, float *out_alpha,
+                               void *zero_ptr, size_t zero_bytes,
+                               gsr_stream_t stream);
 int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
                                 int num_points,
                                 const int32_t *gaussian_ids_sorted,
@@ -421,7 +425,7 @@ int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
                                 const float *v_output_alpha, float *v_xy,
                                 float *v_conic, float *v_colors, float *v_extra,
                                 float *v_opacity, int deep_tile_threshold,
-                                gsr_stream_t stream);
+                                int accumulators_zeroed, gsr_stream_t stream);
 
 /* ---- per-Gaussian activations (caller-side glue) ----------
  * exp(scales), quats / |quats|, sigmoid(opacities) and the normalised view
