@@ -121,7 +121,11 @@ class _PendingCount:
 
     def resolve(self) -> int:
         self.event.synchronize()
-        return int(self.buf[0])
+        count = int(self.buf[0])
+        if count < 0:  # the int32 count wrapped (more than 2^31 - 1 intersections)
+            raise RuntimeError("rasterize_gaussians: the number of (Gaussian, tile) intersections does not fit the "
+                               "int32 lists (the reference's cum_tiles_hit is int32 as well)")
+        return count
 
 
 # unary, parameter-free ops: the same op on the same leaf at the same version = the same values
@@ -321,7 +325,13 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
     build.aux = None
 
     if capacity is None:
-        num_intersects = int(cum_sorted[-1].item())  # the one host sync (utils.py:124)
+        # the one host sync (utils.py:124).  The count is summed in 64 bits: the int32 prefix
+        # (the reference's `torch.cumsum(num_tiles_hit, dtype=torch.int32)`) wraps beyond 2^31 - 1
+        # intersections, and lists sized from a wrapped count are written out of bounds
+        num_intersects = int(tiles.sum(dtype=torch.int64).item())
+        if num_intersects >= 2**31:
+            raise RuntimeError(f"rasterize_gaussians: {num_intersects} (Gaussian, tile) intersections do not fit the "
+                               f"int32 lists (the reference's cum_tiles_hit is int32 as well)")
         _note_count(xys.device, num_points, tile_bounds, num_intersects)
         ids, bins = build(num_intersects) if num_intersects >= 1 else (None, None)
         remember(num_intersects, ids, bins, build.aux)

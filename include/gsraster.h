@@ -137,6 +137,9 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  *                     first; cum_sorted[n] = inclusive scan of num_tiles_hit in
  *                     that order (cum_sorted[n-1] = number of intersections).
  *   gsr_bin_sorted  : gaussian_ids_sorted[I], tile_bins[T,2].
+ * All counts and list offsets are int32, as in the reference (`cum_tiles_hit`): a view with
+ * 2^31 or more (Gaussian, tile) intersections is out of range -- sum num_tiles_hit in 64 bits
+ * before sizing the lists if that can happen (the Python package does and raises).
  *
  * Exact lists (optional, block_width 16 only).  The reference lists every tile
  * of a splat's 3-sigma SQUARE (forward.cu:73-82); about half of those (splat,

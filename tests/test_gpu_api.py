@@ -245,6 +245,25 @@ def test_forward_ex_alpha_and_prezeroed_accumulators():
         assert float((a.reshape(r.shape) - r).abs().max()) <= 1e-5 * float(r.abs().max()) + 1e-12
 
 
+def test_more_than_int32_intersections_is_an_error_not_a_memory_fault():
+    """120 k screen-filling splats on a 188 x 125 tile grid: 2.8e9 box intersections.  The reference's int32
+    `cum_tiles_hit` wraps there; here the count is summed in 64 bits and the call refuses."""
+    from rasterizer.project_gaussians import project_gaussians
+    from rasterizer.rasterize import rasterize_gaussians
+
+    W, H, n = 3008, 2000, 120_000
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=2, scale_lo=5.0, scale_hi=5.0)
+    camt = CameraTensors.from_numpy(cam, DEV)
+    xys, depths, radii, conics, comp, tiles, cov3d = project_gaussians(
+        cu(sc["means3d"]), cu(sc["scales"]), 1, cu(sc["quats"]), camt.viewmat[:3, :], camt.projmat, cam.fx, cam.fy,
+        cam.cx, cam.cy, H, W, 16)
+    assert int(tiles.sum(dtype=torch.int64)) >= 2**31
+    colors = torch.rand(n, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="do not fit the int32 lists"):
+        rasterize_gaussians(xys, depths, radii, conics, tiles, colors, cu(sc["opacities"]), H, W, 16)
+
+
 def test_empty_scene_and_all_culled():
     from rasterizer import project_gaussians, rasterize_gaussians
 
