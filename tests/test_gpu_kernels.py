@@ -595,6 +595,20 @@ def test_list_builders_agree_on_random_shapes():
     assert out.stdout.count(" ok") >= 40
 
 
+def test_compositing_kernels_on_random_shapes():
+    """tools/exp/fuzz_raster.py: tile16 (through the _ex entry points) and generic compositing kernels against
+    the oracle on 60 random image shapes (1 x 1 px up), block widths, splat sizes and opacities; gradients
+    within 1e-3 of the largest + 2e-5 of the summed term magnitudes on Gaussians without a borderline pixel."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_raster.py"), "60", "31"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") >= 40
+
+
 def test_count_reach_errors():
     import rasterizer.cuda as C
 
