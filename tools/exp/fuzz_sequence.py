@@ -1,0 +1,77 @@
+"""Fuzz of the list cache / speculative sizing / count-free flow state machine of `rasterize_gaussians`: a random
+sequence of views over scenes of different sizes, resolutions and opacities (the number of Gaussians and list
+entries jumps up and down, so guesses overflow and are rebuilt) must give, call by call, exactly the images
+and (up to atomic summation order) the gradients of the same calls made without speculation and without cache.
+python tools/exp/fuzz_sequence.py [calls] [seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd")]
+import numpy as np
+import torch
+from harness import scene as S
+from harness.pipeline import CameraTensors
+from rasterizer import project_gaussians, rasterize_gaussians
+from rasterizer import rasterize as R
+
+DEV = torch.device("cuda:0")
+
+
+def main():
+    calls = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    specs = [(3000, 160, 96, 0.01, 0.1), (60_000, 640, 360, 0.01, 0.08), (250_000, 640, 360, 0.02, 0.1),
+             (20_000, 2560, 1600, 0.01, 0.08), (400_000, 1280, 720, 0.002, 0.02)]
+    scenes = []
+    for n, W, H, lo, hi in specs:
+        cam = S.make_camera(W, H)
+        sc = S.make_scene(n, cam, sh_degree=0, seed=n, scale_lo=lo, scale_hi=hi)
+        scenes.append((cam, {k: torch.from_numpy(v).to(DEV) for k, v in sc.items()}))
+    bad = 0
+
+    def run(idx, frac, ofac, yaw, want_alpha, speculate):
+        cam0, sc = scenes[idx]
+        cam = S.make_camera(cam0.width, cam0.height, yaw=yaw)
+        ct = CameraTensors.from_numpy(cam, DEV)
+        n = max(1, int(sc["means3d"].shape[0] * frac))
+        os.environ["GSR_NO_SPECULATION"] = "0" if speculate else "1"
+        if not speculate:
+            R._bin_cache["key"] = None
+        means = sc["means3d"][:n].clone().requires_grad_(True)
+        opac = (sc["opacities"][:n] * ofac).clone().requires_grad_(True)
+        xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
+            means, sc["scales"][:n], 1.0, sc["quats"][:n], ct.viewmat[:3], ct.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+            cam.height, cam.width, 16)
+        g = torch.Generator(device="cpu").manual_seed(idx * 7 + 1)
+        colors = torch.rand(n, 3, generator=g).to(DEV).requires_grad_(True)
+        out = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac, cam.height, cam.width, 16,
+                                  return_alpha=want_alpha)
+        rgb, alpha = out if want_alpha else (out, None)
+        v = torch.rand(cam.height, cam.width, 3, generator=g).to(DEV)
+        loss = (rgb * v).sum() + (alpha.sum() * 0.5 if alpha is not None else 0.0)
+        grads = torch.autograd.grad(loss, (means, opac, colors))
+        return rgb.detach(), None if alpha is None else alpha.detach(), grads
+
+    for k in range(calls):
+        idx = int(rng.integers(len(scenes)))
+        frac = float(rng.choice([1.0, 1.0, 0.5, 0.1, 0.02]))
+        ofac = float(rng.choice([1.0, 1.0, 0.2, 0.01]))
+        yaw = float(rng.choice([0.0, 0.0, 0.1, -0.2]))
+        want_alpha = bool(rng.integers(2))
+        a = run(idx, frac, ofac, yaw, want_alpha, True)
+        b = run(idx, frac, ofac, yaw, want_alpha, False)
+        ok = torch.equal(a[0], b[0]) and (a[1] is None or torch.equal(a[1], b[1]))
+        for ga, gb in zip(a[2], b[2]):
+            ok = ok and float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12
+        spec = specs[idx]
+        print(f"call {k}: scene {idx} ({int(spec[0] * frac)} Gaussians, {spec[1]}x{spec[2]}) opacity x{ofac} yaw {yaw} "
+              f"alpha={want_alpha}: {'ok' if ok else 'MISMATCH'}", flush=True)
+        bad += 0 if ok else 1
+    os.environ["GSR_NO_SPECULATION"] = "0"
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
