@@ -192,6 +192,9 @@ def _compact(params, moments, stats, cfg, step, densify, max_dim, samples, seed,
                     outs.append(o)
                     items.append((m, o, w, KIND_MOMENT))
                 new_moments[k] = tuple(outs)
+        # (zero-width rows -- `features_rest` of an SH-degree-0 model is [N, 0, 3] -- have nothing to move:
+        #  their outputs above already have the new number of rows)
+        items = [it for it in items if it[2] > 0]
         for i in range(0, len(items), MAX_TENSORS):
             chunk = items[i:i + MAX_TENSORS]
             arr = (_RefineTensor * len(chunk))()

@@ -258,3 +258,44 @@ def test_densify_stats_first_call_semantics():
     np.testing.assert_allclose(gn.cpu().numpy(), stats[0], rtol=1e-6)
     np.testing.assert_array_equal(vc.cpu().numpy(), stats[1].astype(np.int32))
     np.testing.assert_allclose(m2.cpu().numpy(), stats[2], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_refinement_of_an_sh_degree_0_model():
+    """`features_rest` of an SH-degree-0 model is [N, 0, 3]: nothing to move, but the row count must follow
+    (found by tools/exp/fuzz_refine.py: the compaction used to refuse the zero-width tensor)."""
+    rng = np.random.default_rng(11)
+    n = 5000
+    params = _random_model(rng, n, K=2)
+    params["features_rest"] = params["features_rest"][:, :0]
+    moments = {k: (rng.standard_normal(v.shape).astype(np.float32), rng.uniform(0, 1, v.shape).astype(np.float32))
+               for k, v in params.items()}
+    cfg = RO.RefineConfig()
+    stats = (np.abs(rng.standard_normal(n) * 1e-6).astype(np.float32), rng.integers(1, 30, n).astype(np.float32),
+             rng.uniform(0, 0.2, n).astype(np.float32))
+    ok = _stable(params, stats, cfg, 1920)
+    params["scales"][~ok] = np.log(0.2)
+    params["opacities"][~ok] = 1.0
+    stats[0][~ok] = 0
+    stats[2][~ok] = 0
+    ref_p, ref_m, _ = RO.refine(params, moments, stats, cfg, 3700, 20, 1920, samples=None, seed=5)
+    p, m, info = _gpu_refine(params, moments, stats, cfg, 3700, 20, 1920, samples=None, seed=5)
+    assert info["n_out"] == ref_p["means"].shape[0] != n
+    assert p["features_rest"].shape == (info["n_out"], 0, 3) and m["features_rest"][0].shape == (info["n_out"], 0, 3)
+    for k in ("quats", "features_dc", "opacities"):
+        np.testing.assert_array_equal(p[k], ref_p[k])
+        np.testing.assert_array_equal(m[k][0], ref_m[k][0])
+
+
+@pytest.mark.gpu
+def test_hip_refinement_with_random_configurations():
+    """tools/exp/fuzz_refine.py: 60 random configurations (thresholds, schedule, 1-4 split samples, SH degree
+    0-3, 1 to 200 k Gaussians, with and without optimizer state / statistics) against the numpy oracle."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_refine.py"), "60", "51"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") >= 50
