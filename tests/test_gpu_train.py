@@ -57,6 +57,23 @@ def test_training_with_refinement_grows_the_model_and_keeps_learning():
         assert abs(n1 - n2) <= 0.01 * n1, (res["refinements"], res2["refinements"])
 
 
+@pytest.mark.parametrize("deg", [0, 1])
+def test_training_with_refinement_at_low_sh_degrees(deg):
+    """SH degree 0 (`features_rest` is [N, 0, 3]) and 1 through the whole loop: split SH op, refinement with
+    Adam-state surgery, fused Adam on the regrown tensors."""
+    from gs_fused import RefineConfig
+    from harness.train import TrainConfig, train
+
+    rcfg = RefineConfig(warmup_length=40, refine_every=20, reset_alpha_every=6, stop_screen_size_at=200,
+                        stop_split_at=260, densify_grad_thresh=0.0002)
+    cfg = TrainConfig(num_gaussians=20_000, init_gaussians=4_000, width=320, height=180, num_views=8, iters=260,
+                      sh_degree=deg, sh_degree_interval=60, log_every=10, densify=True, refine=rcfg)
+    res = train(cfg, torch.device("cuda", 0))
+    assert np.isfinite(res["param_checksum"])
+    assert res["num_gaussians_end"] != res["num_gaussians_start"] and len(res["refinements"]) >= 3, res
+    assert res["psnr_end"] > res["psnr_start"] + 3.0, res
+
+
 def test_resume_from_checkpoint_after_densification(tmp_path):
     """A run that densified and saved can be resumed by a trainer that starts from the
     initial number of Gaussians: the model and the FusedAdam state are resized on load
