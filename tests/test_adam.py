@@ -139,3 +139,19 @@ def test_fused_adam_rematerialises_nonconforming_state():
     p.grad = torch.randn_like(p)
     with pytest.raises(RuntimeError):
         opt.step()
+
+
+@pytest.mark.gpu
+def test_fused_ops_on_random_shapes():
+    """tools/exp/fuzz_fused.py: FusedAdam against torch.optim.Adam on random tensor lists (1-14 tensors, ragged
+    shapes, betas incl. 0, missing and sparse-valued gradients, 1-5 steps) and the L1+SSIM head against the CPU
+    oracle on random image sizes (from 11 x 11) and lambdas."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_fused.py"), "40", "61"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") == 40
