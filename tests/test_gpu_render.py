@@ -136,3 +136,18 @@ def test_view_graph_replays_equal_eager_views():
     small.replay(cams[1].viewmat, cams[1].projmat, cams[1].campos, (gts[1],))
     torch.cuda.synchronize()
     assert not small.fits()
+
+
+def test_render_gaussians_with_random_list_capacities():
+    """tools/exp/fuzz_render.py: capacities that are too small (down to one entry), exact and ample, on random
+    view sizes, SH degrees and depth on / off: the reported count never depends on the capacity, fitting
+    capacities give the same image and gradients, cut lists stay finite and memory-safe through the backward."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_render.py"), "30", "71"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") == 30

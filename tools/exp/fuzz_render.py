@@ -1,0 +1,73 @@
+"""Fuzz of gs_fused.render_gaussians with list capacities that are too small, about right and ample: the
+entry count reported must not depend on the capacity, a capacity that fits must give the ample run's images and
+gradients, one that does not must stay memory-safe (cut lists, no fault) in the forward AND the backward.
+python tools/exp/fuzz_render.py [cases] [seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd")]
+import numpy as np
+import torch
+from gs_fused import ViewSpec, render_gaussians
+from harness import scene as S
+from harness.pipeline import CameraTensors
+from harness.train import blob_scene, orbit_cameras
+
+DEV = "cuda:0"
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    bad = 0
+    bg = torch.tensor(S.BACKGROUND, device=DEV)
+    for k in range(cases):
+        n = int(rng.choice([1, 64, 3000, 40_000, 150_000]))
+        W, H = int(rng.integers(17, 1300)), int(rng.integers(17, 800))
+        deg = int(rng.integers(1, 4))
+        use = int(rng.integers(0, deg + 1))
+        depth = bool(rng.integers(2))
+        raw = blob_scene(n, seed=int(rng.integers(1 << 20)), sh_degree=deg, scale_lo=0.01, scale_hi=float(rng.choice([0.05, 0.3])))
+        cam = CameraTensors.from_numpy(orbit_cameras(8, W, H)[int(rng.integers(8))], DEV)
+        spec = ViewSpec(H, W, cam.fx, cam.fy, cam.cx, cam.cy, use, render_depth=depth)
+        g = torch.Generator(device="cpu").manual_seed(k)
+        v_img = torch.rand(H, W, 3, generator=g).to(DEV)
+
+        def run(capacity):
+            p = {q: torch.from_numpy(v).to(DEV).requires_grad_(True) for q, v in raw.items()}
+            out = render_gaussians(p["means"], p["scales"], p["quats"], p["opacities"], p["features_dc"],
+                                   p["features_rest"], cam.viewmat, cam.projmat, cam.campos, bg, spec, capacity=capacity)
+            loss = (out["rgb"] * v_img).sum() + out["alpha"].sum() + (out["depth"].sum() if depth else 0.0)
+            grads = torch.autograd.grad(loss, list(p.values()))
+            torch.cuda.synchronize()
+            return int(out["count"][0]), out["rgb"].detach(), grads
+
+        tag = f"case {k}: n={n} {W}x{H} deg={deg}/{use} depth={depth}"
+        try:
+            count, rgb, grads = run(1 << 26)
+            if count < 1:
+                print(tag, "empty view ok")
+                continue
+            for cap in (max(1, count // int(rng.integers(2, 50))), count, count + int(rng.integers(1, 100_000)), 1):
+                c2, rgb2, grads2 = run(cap)
+                assert c2 == count, f"count {c2} != {count} at capacity {cap}"
+                if cap >= count:
+                    assert torch.equal(rgb, rgb2), f"image differs at capacity {cap}"
+                    for nm, a, b in zip(raw.keys(), grads, grads2):
+                        err, ref = float((a - b).abs().max()), float(a.abs().max())
+                        assert err <= 3e-4 * ref + 1e-12, f"grad of {nm} at capacity {cap}: {err:.3e} vs max {ref:.3e}"
+                else:
+                    assert bool(torch.isfinite(rgb2).all()), f"non-finite image with cut lists (capacity {cap})"
+                    for nm, b in zip(raw.keys(), grads2):
+                        assert bool(torch.isfinite(b).all()), f"non-finite grad of {nm} with cut lists (capacity {cap})"
+            print(tag, f"count={count} ok", flush=True)
+        except AssertionError as e:
+            bad += 1
+            print(tag, "MISMATCH", str(e)[:300], flush=True)
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
