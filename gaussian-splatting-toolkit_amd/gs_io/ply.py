@@ -31,7 +31,8 @@ def write_gaussian_ply(path: str, params: Dict[str, np.ndarray]) -> None:
     n = xyz.shape[0]
     f_dc = np.asarray(params["features_dc"], np.float32).reshape(n, 3)
     rest = np.asarray(params["features_rest"], np.float32)
-    f_rest = np.ascontiguousarray(rest.transpose(0, 2, 1)).reshape(n, -1)  # channel-major
+    # channel-major; the width is spelled out so that an empty model (N = 0) keeps its SH degree
+    f_rest = np.ascontiguousarray(rest.transpose(0, 2, 1)).reshape(n, rest.shape[1] * rest.shape[2])
     cols = [xyz, np.zeros_like(xyz), f_dc, f_rest, np.asarray(params["opacities"], np.float32).reshape(n, 1),
             np.asarray(params["scales"], np.float32).reshape(n, 3),
             np.asarray(params["quats"], np.float32).reshape(n, 4)]

@@ -46,3 +46,16 @@ def test_reader_rejects_other_files(tmp_path):
     p.write_bytes(b"plx\n")
     with pytest.raises(ValueError):
         read_gaussian_ply(str(p))
+
+
+@pytest.mark.parametrize("K", [1, 4, 16])
+def test_empty_model_keeps_its_sh_degree(tmp_path, K):
+    """N = 0 (everything culled): the file still lists the f_rest properties of the model's SH degree."""
+    f = np.float32
+    raw = {"means": np.zeros((0, 3), f), "scales": np.zeros((0, 3), f), "quats": np.zeros((0, 4), f),
+           "opacities": np.zeros((0, 1), f), "features_dc": np.zeros((0, 3), f), "features_rest": np.zeros((0, K - 1, 3), f)}
+    path = str(tmp_path / "empty.ply")
+    write_gaussian_ply(path, raw)
+    back = read_gaussian_ply(path)
+    for k, v in raw.items():
+        assert back[k].shape == v.shape, k
