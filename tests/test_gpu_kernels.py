@@ -623,6 +623,20 @@ def test_projection_and_sh_on_random_cameras_and_scales():
     assert out.stdout.count(" ok") == 60
 
 
+def test_depth_order_on_random_sizes_rows_and_key_distributions():
+    """tools/exp/fuzz_depth_order.py: 1 to 4 M + 1 Gaussians (both sort paths), 1-16 count rows, ties / narrow /
+    sorted / reversed keys, culled Gaussians: the stable order and the inclusive prefix of the counts in that
+    order (the decoupled look-back scan) against numpy; also the order-only call."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_depth_order.py"), "40", "81"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") == 40
+
+
 def test_count_reach_errors():
     import rasterizer.cuda as C
 
