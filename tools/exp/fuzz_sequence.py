@@ -30,7 +30,7 @@ def main():
         scenes.append((cam, {k: torch.from_numpy(v).to(DEV) for k, v in sc.items()}))
     bad = 0
 
-    def run(idx, frac, ofac, yaw, want_alpha, speculate):
+    def run(idx, frac, ofac, yaw, want_alpha, second, speculate):
         cam0, sc = scenes[idx]
         cam = S.make_camera(cam0.width, cam0.height, yaw=yaw)
         ct = CameraTensors.from_numpy(cam, DEV)
@@ -50,8 +50,20 @@ def main():
         rgb, alpha = out if want_alpha else (out, None)
         v = torch.rand(cam.height, cam.width, 3, generator=g).to(DEV)
         loss = (rgb * v).sum() + (alpha.sum() * 0.5 if alpha is not None else 0.0)
+        # the models' second call of a view (depth pass, vanilla_gs.py:840): same geometry, depths as
+        # colours, and an opacity tensor that is equal in value (`second` 1: a clone -- unknown provenance,
+        # compared on the device), or scaled (2: the lists must be rebuilt); 0: no second call
+        depth_img = None
+        if second:
+            if not speculate:
+                R._bin_cache["key"] = None
+            opac2 = opac.detach().clone() if second == 1 else opac.detach() * 0.5
+            depth_img = rasterize_gaussians(xys, depths, radii, conics, tiles, depths[:, None].repeat(1, 3), opac2,
+                                            cam.height, cam.width, 16, background=torch.zeros(3, device=DEV))
+            loss = loss + depth_img.sum() * 0.1
+            depth_img = depth_img.detach()
         grads = torch.autograd.grad(loss, (means, opac, colors))
-        return rgb.detach(), None if alpha is None else alpha.detach(), grads
+        return rgb.detach(), None if alpha is None else alpha.detach(), grads, depth_img
 
     for k in range(calls):
         idx = int(rng.integers(len(scenes)))
@@ -59,14 +71,16 @@ def main():
         ofac = float(rng.choice([1.0, 1.0, 0.2, 0.01]))
         yaw = float(rng.choice([0.0, 0.0, 0.1, -0.2]))
         want_alpha = bool(rng.integers(2))
-        a = run(idx, frac, ofac, yaw, want_alpha, True)
-        b = run(idx, frac, ofac, yaw, want_alpha, False)
+        second = int(rng.integers(3))
+        a = run(idx, frac, ofac, yaw, want_alpha, second, True)
+        b = run(idx, frac, ofac, yaw, want_alpha, second, False)
         ok = torch.equal(a[0], b[0]) and (a[1] is None or torch.equal(a[1], b[1]))
+        ok = ok and (a[3] is None or torch.equal(a[3], b[3]))
         for ga, gb in zip(a[2], b[2]):
             ok = ok and float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12
         spec = specs[idx]
         print(f"call {k}: scene {idx} ({int(spec[0] * frac)} Gaussians, {spec[1]}x{spec[2]}) opacity x{ofac} yaw {yaw} "
-              f"alpha={want_alpha}: {'ok' if ok else 'MISMATCH'}", flush=True)
+              f"alpha={want_alpha} second={second}: {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += 0 if ok else 1
     os.environ["GSR_NO_SPECULATION"] = "0"
     print("mismatches:", bad)
