@@ -1,0 +1,66 @@
+"""GPU, world_size 2 over gloo with both ranks on cuda:0: the data-parallel trainer on the real HIP path (per-rank
+views, hooked gradient exchange, fused Adam, all-reduced densification statistics, refinement with
+counter-based split samples).  Both replicas must end with the same N and bit-identical parameters.  (RCCL needs
+one GPU per rank: the 8-GPU run is the driver's; the exchange logic is the same object.)"""
+import math
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(rank, world, port, q):
+    import torch.distributed as dist
+
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import harness.train as HT
+    from gs_fused import RefineConfig
+
+    rcfg = RefineConfig(warmup_length=30, refine_every=15, reset_alpha_every=4, stop_screen_size_at=120,
+                        stop_split_at=150, densify_grad_thresh=0.0004)
+    cfg = HT.TrainConfig(num_gaussians=12_000, init_gaussians=3_000, width=256, height=160, num_views=6, iters=140,
+                         sh_degree=2, sh_degree_interval=40, eval_views=2, densify=True, refine=rcfg)
+    res = HT.train(cfg, torch.device("cuda", 0), rank, world)
+    q.put((rank, res["param_checksum"], res["num_gaussians_start"], res["num_gaussians_end"], res["refinements"],
+           res["psnr_start"], res["psnr_end"], res["allreduce_bytes"][:3]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_on_one_gpu_keep_identical_replicas_through_refinement():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = results
+    assert a[2] == b[2] == 3_000
+    assert a[4] == b[4] and len(a[4]) >= 3, (a[4], b[4])   # same refinement history on both ranks
+    assert a[3] == b[3] and a[3] != 3_000                    # N changed, identically
+    assert a[1] == b[1] and math.isfinite(a[1]), (a[1], b[1])  # bit-identical parameters
+    assert math.isfinite(a[5]) and math.isfinite(a[6])      # (an opacity reset sits right before the end: no PSNR claim)
+    assert a[7] and all(x > 0 for x in a[7])                 # gradients were exchanged
