@@ -1,0 +1,49 @@
+"""GPU: the bench.py contract the driver depends on -- one JSON line with the agreed fields, at N = 1 and, self-
+spawned from a plain `python bench.py --gpus 2`, at N = 2 (gloo here: both ranks share cuda:0)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--gaussians", "60000", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "2", "--no-pmc"]
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, capture_output=True,
+                         text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # exactly one JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    d = _run([])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "Mpix/s" and d["value"] > 0 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert abs(d["value"] - 640 * 360 / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    assert "workload" in d["config"] and "60000" in d["config"]["workload"] and "60000" in d["metric"].replace(" ", "").replace(",", "") or "60k" in d["metric"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+
+
+def test_plain_invocation_with_two_gpus_spawns_its_ranks():
+    d = _run(["--gpus", "2", "--backend", "gloo", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # whole-job value: both ranks' pixels over the slowest rank's time
+    assert abs(d["value"] - 2 * 640 * 360 / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    assert d["allreduce_bytes"] and d["allreduce_bytes"] > 0
