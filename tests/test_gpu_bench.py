@@ -47,3 +47,23 @@ def test_plain_invocation_with_two_gpus_spawns_its_ranks():
     # whole-job value: both ranks' pixels over the slowest rank's time
     assert abs(d["value"] - 2 * 640 * 360 / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
     assert d["allreduce_bytes"] and d["allreduce_bytes"] > 0
+
+
+def test_the_drivers_torchrun_form():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`: the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL + [
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
