@@ -88,7 +88,14 @@ class KernelTimers:
         return timed
 
     def summary_ms(self):
+        """mean duration of one call, per stage"""
         return {k: (float(np.mean([a.elapsed_time(b) for a, b in v])) if v else 0.0)
+                for k, v in self.pairs.items()}
+
+    def total_ms(self, bracketed_steps):
+        """time per STEP, per stage (calls per step x mean duration): what ranks the stages"""
+        n = max(1, bracketed_steps)
+        return {k: (float(np.sum([a.elapsed_time(b) for a, b in v])) / n if v else 0.0)
                 for k, v in self.pairs.items()}
 
 
@@ -128,6 +135,141 @@ def cpu_baseline(sc, cam, bg, v_img, v_alpha, deg):
     }, r["num_intersects"]
 
 
+# BASELINE config 3 ("gs-train gaussian-splatting on a nerfstudio-style synthetic scene (~1M Gaussians),
+# 1xMI355X, 7k iters"; config 4 = the same under per-view data parallelism).  ONE definition: bench.py's
+# `train` record, tests/test_gpu_train.py::test_config3_* and tools/train_bench.py --config3 all use it.
+def config3(iters=7000):
+    from gs_fused import RefineConfig
+    from harness.train import TrainConfig
+
+    return TrainConfig(
+        num_gaussians=CONFIG3["truth_gaussians"], width=1920, height=1080, num_views=48, iters=iters,
+        sh_degree=3, sh_degree_interval=1000,          # vanilla_gs.py:67 (reference default)
+        densify=True, refine=RefineConfig(),           # every reference default, densify_grad_thresh = 2e-4 included
+        init="sfm", init_gaussians=CONFIG3["seed_points"],  # populate_modules from a sparse point cloud
+        means_lr_schedule=True,                        # method_configs.py:98-104
+        scene="objects", scene_scale=CONFIG3["truth_scale"], tex_cell=CONFIG3["tex_cell"],
+        scene_objects=CONFIG3["objects"], scene_extent=CONFIG3["extent"], cam_radius=CONFIG3["cam_radius"],
+        phase_every=50, log_every=500)
+
+
+# the hidden scene: 140 textured spheres (radius 0.18-0.45) in a ball of radius 2.5, tiled by 3 M flat
+# Gaussians; 48 cameras on an orbit of radius 5 (the near half overflows the frame).  The model starts
+# from 200 k noisy surface points.  Chosen by tools/exp/exp_seed.sh (round 3): with the reference's
+# threshold the model settles near 0.45 M Gaussians whatever the scene (0.15 M when the scene fills 40 %
+# of the frame, 0.5 M when it overflows it): the rule stops splitting once a Gaussian's mean screen-space
+# gradient x max(W, H) / 2 falls below 2e-4, i.e. at a roughly fixed number of Gaussians per covered pixel.
+CONFIG3 = {"truth_gaussians": 3_000_000, "seed_points": 200_000, "truth_scale": (0.003, 0.008), "tex_cell": 0.03,
+           "objects": (140, 0.18, 0.45), "extent": 2.5, "cam_radius": 5.0}
+
+
+def fixed_1m(iters=400):
+    """The throughput figure at the size BASELINE names: 1 M Gaussians at 1080p, N FIXED (no refinement),
+    the toolkit's full iteration.  Config 3 above follows the reference's rule, which keeps the model
+    below 1 M on a 48-view scene; this is the rate at 1 M."""
+    from harness.train import TrainConfig
+
+    return TrainConfig(num_gaussians=1_000_000, width=1920, height=1080, num_views=16, iters=iters,
+                       sh_degree=3, sh_degree_interval=max(1, iters // 4), phase_every=20)
+
+
+def train_only(args):
+    """`bench.py --train-only`: BASELINE config 3 (N = 1) / config 4 (N > 1) through harness.train.train;
+    rank 0 prints the record as one JSON line.  Run as a subprocess of the main bench so that a
+    failure here can never cost the raster line."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = args.backend
+    if backend == "auto":
+        backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
+    from harness.train import train
+
+    cfg = config3(args.train_iters)
+    res = train(cfg, dev, rank, world)
+    res1m = train(fixed_1m(), dev, rank, world) if args.train_iters >= 1000 else None
+    if world > 1:
+        cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        res["replicas_identical"] = bool(lo.item() == hi.item())
+    if rank == 0:
+        losses = res.pop("losses", None) or [None]
+        hist = res.pop("refinements")
+        rec = {
+            "metric": "train iters/s (BASELINE config 3" + (" / 4" if world > 1 else "") + ")",
+            "iters_per_s": round(res["iters_per_s"], 1), "views_per_s": round(res["views_per_s"], 1),
+            "n_gpus": world, "iters": res["iters"], "seconds": round(res["seconds"], 2),
+            "resolution": f"{cfg.width}x{cfg.height}",
+            "gaussians": {"start": res["num_gaussians_start"], "end": res["num_gaussians_end"],
+                          "max": max([n for _, n in hist] + [res["num_gaussians_start"]]),
+                          "history_step_N": hist[:: max(1, len(hist) // 24)]},
+            "refinements": len(hist),
+            "psnr": {"start": round(res["psnr_start"], 2), "end": round(res["psnr_end"], 2)},
+            "loss_first_last": [losses[0], losses[-1]],
+            "phase_ms_median": res["phase_ms_median"],
+            "list_overflow_views": res["list_overflow_views"],
+            "render": res["render"],
+            "scene": (f"hidden truth: {cfg.num_gaussians} flat textured Gaussians on {cfg.scene_objects[0]} spheres in a ball of "
+                      f"radius {cfg.scene_extent} (harness.train.blob_scene 'objects'), {cfg.num_views} views from an orbit of "
+                      f"radius {cfg.cam_radius} rendered by this rasterizer"),
+            "why_not_1M": ("every reference default incl. densify_grad_thresh 2e-4: the rule stops splitting at a roughly fixed "
+                           "number of Gaussians per covered pixel, ~0.45 M here (tools/exp/exp_seed.sh, DESIGN 4.7); "
+                           "the rate at a fixed 1 M Gaussians is in `fixed_1m`"),
+            "model_start": (f"{cfg.init}: {cfg.init_gaussians} noisy surface points with 8-bit colours; scales = 3-NN distance, "
+                            "random quats, opacity 0.1 (vanilla_gs.py:128-174)"),
+            "refinement": {"densify_grad_thresh": res["densify_grad_thresh"], "schedule": "reference defaults "
+                           "(warm-up 500, every 100, opacity reset every 3000, screen-size rules until 4000)"},
+            "allreduce_bytes_step_bytes": res["allreduce_bytes"] or None,
+            "replicas_identical": res.get("replicas_identical"),
+            "parallelism": (f"dp{world} per-view, {backend}" if world > 1 else "single"),
+            "update": res["update"],
+        }
+        if res1m is not None:
+            rec["fixed_1m"] = {"workload": "1 M Gaussians at 1920x1080, N fixed (no refinement), full training iteration",
+                               "iters_per_s": round(res1m["iters_per_s"], 1), "views_per_s": round(res1m["views_per_s"], 1),
+                               "iters": res1m["iters"], "psnr": [round(res1m["psnr_start"], 2), round(res1m["psnr_end"], 2)],
+                               "phase_ms_median": res1m["phase_ms_median"],
+                               "allreduce_bytes_step_bytes": res1m["allreduce_bytes"] or None}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def train_record(args, world):
+    """Run `--train-only` in a fresh process (own process group, own spawn) -> dict for the line."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE") and not k.startswith("TORCHELASTIC")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--train-only", "--gpus", str(world), "--train-iters",
+           str(args.train_iters), "--backend", args.backend]
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=args.train_timeout)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not lines:
+            return {"error": f"rc {out.returncode}", "stderr_tail": out.stderr[-800:]}
+        rec = json.loads(lines[-1])
+        rec["wall_s_including_setup"] = round(time.perf_counter() - t0, 1)
+        return rec
+    except subprocess.TimeoutExpired:
+        return {"error": f"timeout after {args.train_timeout} s"}
+    except Exception as e:  # the raster line must survive anything that goes wrong here
+        return {"error": repr(e)}
+
+
 def _spawned(rank, world, port, argv):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -150,15 +292,28 @@ def cpu_baseline_one_thread(sc, cam, bg, v_img, v_alpha, deg, budget_gaussians=6
     finally:
         O.set_threads(before)
     res["cores"] = 1
+    res["not_comparable_with"] = "cpu_baseline: this is a DIFFERENT, smaller workload (a 60 k-Gaussian subset)"
     res["sample"] = (f"first {n} Gaussians of the workload ({I} reference list entries) at {cam.width}x{cam.height}, one "
                      f"thread; " + res["sample"].split("; ", 1)[1])
     return res
 
 
-def pmc_pass(counters, argv, kernel_substr, timeout_s=240):
+# stage -> substrings of the kernel names it launches (rocprofv3 kernel trace)
+STAGE_KERNELS = {
+    "project_fwd": ("project_fwd_kernel",), "sh_fwd": ("sh16_fwd_kernel", "sh_fwd_kernel", "sh_split_fwd_kernel"),
+    "count_reach": ("reach_records_kernel", "tile_rows_kernel<false>"),
+    "depth_order": ("gsr_sort::", "depth_keys_kernel"),
+    "bin_sorted": ("gsr_p2::", "gsr_ts::", "tile_rows_kernel<true>", "publish_int_kernel"),
+    "raster_fwd": ("raster_fwd_tile16_kernel", "raster_fwd_generic_kernel"),
+    "raster_bwd": ("raster_bwd_tile16_kernel", "raster_bwd_generic_kernel", "reduce_partials_kernel"),
+    "sh_bwd": ("sh16_bwd_kernel", "sh_bwd_kernel", "sh_split_bwd_kernel"), "project_bwd": ("project_bwd_kernel",),
+}
+
+
+def pmc_pass(counters, argv, timeout_s=240):
     """One separate `rocprofv3 --kernel-trace --pmc <counters>` pass over a short run of this
     script (MI355X_MICROARCH.md, HBM section: counters in their own pass, kernel trace only).
-    -> {counter: mean per launch of the kernels whose name contains `kernel_substr`} or None."""
+    -> {kernel name: {counter: [value per launch, ...]}} or None."""
     import csv
     import glob
     import shutil
@@ -180,13 +335,25 @@ def pmc_pass(counters, argv, kernel_substr, timeout_s=240):
         vals = {}
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if kernel_substr in row["Kernel_Name"]:
-                    vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-        return {k: float(np.mean(v)) for k, v in vals.items()} or None
+                vals.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], []).append(
+                    float(row["Counter_Value"]))
+        return vals or None
     except Exception:
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def pmc_stage(vals, stage, counter, steps):
+    """-> (mean per launch of the stage's LARGEST kernel, sum over all the stage's launches per step)"""
+    if not vals:
+        return None, None
+    per_kernel = {k: v[counter] for k, v in vals.items()
+                  if counter in v and any(sub in k for sub in STAGE_KERNELS[stage])}
+    if not per_kernel:
+        return None, None
+    top = max(per_kernel.values(), key=lambda v: float(np.mean(v)))
+    return float(np.mean(top)), float(sum(np.sum(v) for v in per_kernel.values())) / max(1, steps)
 
 
 def main():
@@ -228,6 +395,10 @@ def main():
                          "float atomics")
     ap.add_argument("--scene", default="uniform", choices=["uniform", "longtail"],
                     help="longtail: 10 %% of the tiles hold ~10x the list depth (clustered Gaussians)")
+    ap.add_argument("--train-iters", type=int, default=7000,
+                    help="iterations of the config-3 training record (BASELINE metric, second half); 0: skip it")
+    ap.add_argument("--train-timeout", type=int, default=900)
+    ap.add_argument("--train-only", action="store_true", help="run only the config-3 training leg and print its record")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -249,6 +420,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.train_only:
+        return train_only(args)
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -351,12 +524,14 @@ def main():
 
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    bracketed_steps = 0
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         # per-kernel HIP events on every `event_every`-th timed step: a pair of event
         # records per native call costs ~4 us of GPU idle time (18 pairs: 5 % of a step)
         timers.enabled = args.event_every > 0 and i % args.event_every == 0
+        bracketed_steps += int(timers.enabled)
         step()
         marks[i + 1].record()
     barrier()
@@ -372,6 +547,12 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     pixels = W * H
     value = world * pixels / (elapsed / args.steps) / 1e6
+    allreduce_bytes = exchange.bytes_last if world > 1 else None
+    if world > 1:
+        # the timed job is over: the other ranks leave (and free their GPUs) while rank 0 runs the
+        # training leg in a fresh process group of its own and then prints the line
+        dist.barrier()
+        dist.destroy_process_group()
 
     if rank == 0:
         kern_ms = timers.summary_ms()
@@ -386,44 +567,69 @@ def main():
         # entry + the per-pixel images (40 I + 20 P, 76 I + 24 P)
         alg["raster_fwd"] = 40 * staged_fwd + 20 * pixels
         alg["raster_bwd"] = 76 * staged_bwd + 24 * pixels
-        dominant = max(kern_ms, key=lambda k: kern_ms[k])
+        # the stages as BUILT move other bytes than the reference's scan / map / sort / bin-edges
+        # organisation SURVEY prices: per-stage figures use these
+        alg.update(S.built_pipeline_bytes(N, list_entries, tiles))
+        step_ms_by_stage = timers.total_ms(bracketed_steps)
+        # the dominant stage is the one with the most time per STEP (calls x mean), not per call
+        dominant = max(step_ms_by_stage, key=lambda k: step_ms_by_stage[k])
         ach = alg[dominant] / (kern_ms[dominant] * 1e-3) / 1e9 if kern_ms[dominant] > 0 else 0.0
         roofline = {
             "kernel": dominant, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
             "algorithmic_bytes": alg[dominant], "kernel_ms": round(kern_ms[dominant], 4),
+            "launches_per_step": round(step_ms_by_stage[dominant] / kern_ms[dominant], 2) if kern_ms[dominant] > 0 else 0,
+            "ms_per_step_in_kernel": round(step_ms_by_stage[dominant], 4),
             "staged_list_entries": {"raster_fwd": staged_fwd, "raster_bwd": staged_bwd, "lists": list_entries},
         }
         # HBM traffic and VALU occupancy of the dominant kernel, measured now: separate rocprofv3
         # counter passes over a short run of this same command (skipped with --no-pmc / N > 1)
-        kn = {"raster_bwd": "raster_bwd_tile16_kernel", "raster_fwd": "raster_fwd_tile16_kernel",
-              "sh_fwd": "sh16_fwd_kernel", "sh_bwd": "sh16_bwd_kernel", "project_fwd": "project_fwd_kernel",
-              "project_bwd": "project_bwd_kernel"}.get(dominant)
-        if world == 1 and not args.no_pmc and kn is not None:
+        stage_traffic = None
+        if world == 1 and not args.no_pmc:
             sub = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
-            for flag in ("--steps", "--warmup", "--event-every", "--gpus"):
+            for flag in ("--steps", "--warmup", "--event-every", "--gpus", "--train-iters"):
                 while flag in sub:
                     i = sub.index(flag)
                     del sub[i:i + 2]
-            sub += ["--steps", "3", "--warmup", "2", "--event-every", "0", "--no-cpu-baseline", "--no-pmc"]
-            f = pmc_pass(["FETCH_SIZE"], sub, kn)
-            w = pmc_pass(["WRITE_SIZE"], sub, kn)
-            if f and w and "FETCH_SIZE" in f and "WRITE_SIZE" in w:
-                # KB units; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section)
-                roofline["traffic"] = int((2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024)
-                roofline["traffic_raw"] = {"FETCH_SIZE_KB": round(f["FETCH_SIZE"], 1), "WRITE_SIZE_KB": round(w["WRITE_SIZE"], 1)}
-            q = pmc_pass(["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], sub, kn)
-            if q and "SQ_INSTS_VALU" in q and q.get("GRBM_GUI_ACTIVE", 0) > 0:
+            sub += ["--steps", "3", "--warmup", "2", "--event-every", "0", "--no-cpu-baseline", "--no-pmc",
+                    "--train-iters", "0"]
+            sub_steps = 2 + 1 + 3  # warm-up, the staged-entry count step, timed
+            f = pmc_pass(["FETCH_SIZE"], sub)
+            w = pmc_pass(["WRITE_SIZE"], sub)
+            # KB units; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md, HBM section)
+            to_bytes = lambda fk, wk: int((2 * fk + wk) * 1024)
+            fl, _ = pmc_stage(f, dominant, "FETCH_SIZE", sub_steps)
+            wl, _ = pmc_stage(w, dominant, "WRITE_SIZE", sub_steps)
+            if fl is not None and wl is not None:
+                roofline["traffic"] = to_bytes(fl, wl)  # per launch of the dominant kernel
+                roofline["traffic_raw"] = {"FETCH_SIZE_KB": round(fl, 1), "WRITE_SIZE_KB": round(wl, 1)}
+            stage_traffic = {}
+            for st in STAGE_KERNELS:
+                _, fs = pmc_stage(f, st, "FETCH_SIZE", sub_steps)
+                _, ws = pmc_stage(w, st, "WRITE_SIZE", sub_steps)
+                if fs is not None and ws is not None:
+                    stage_traffic[st] = to_bytes(fs, ws)  # all launches of the stage, per step
+            q = pmc_pass(["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], sub)
+            qi, _ = pmc_stage(q, dominant, "SQ_INSTS_VALU", sub_steps)
+            qa, _ = pmc_stage(q, dominant, "GRBM_GUI_ACTIVE", sub_steps)
+            if qi is not None and qa:
                 # the compositing kernels are VALU-issue bound, not HBM bound:
                 # wave64 VALU instructions x 4 cycles / SIMD-cycles the kernel was resident
-                simd_cycles = q["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-                roofline["valu_busy"] = round(q["SQ_INSTS_VALU"] * 4.0 / simd_cycles, 3)
+                simd_cycles = qa / 8.0 * 1024.0
+                roofline["valu_busy"] = round(qi * 4.0 / simd_cycles, 3)
                 roofline["limiter"] = "VALU issue (SQ_INSTS_VALU x 4 cycles / SIMD-cycles resident, this run)"
         # every kernel's own fraction, and the end-to-end figure from SURVEY 8(d)
-        per_kernel = {
-            k: {"ms": round(kern_ms[k], 4), "GBps": round(alg[k] / (kern_ms[k] * 1e-3) / 1e9, 1) if kern_ms[k] > 0 else 0.0}
-            for k in kern_ms
-        }
+        # per stage: mean ms of one call, calls per step, its algorithmic bytes per call (as built),
+        # the rate that gives, and -- with the counter passes -- the HBM bytes all its launches moved per step
+        per_kernel = {}
+        for k in kern_ms:
+            calls = step_ms_by_stage[k] / kern_ms[k] if kern_ms[k] > 0 else 0.0
+            gbps = alg[k] / (kern_ms[k] * 1e-3) / 1e9 if kern_ms[k] > 0 else 0.0
+            per_kernel[k] = {"ms": round(kern_ms[k], 4), "calls_per_step": round(calls, 2),
+                             "algorithmic_bytes": int(alg[k]), "GBps": round(gbps, 1),
+                             "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBS, 4)}
+            if stage_traffic and k in stage_traffic:
+                per_kernel[k]["traffic_per_step"] = stage_traffic[k]
         end_to_end = alg_job["total"] / (ms_per_step * 1e-3) / 1e9
 
         cpu = cpu1 = None
@@ -436,7 +642,8 @@ def main():
         n_name = f"{N // 1_000_000}M" if N % 1_000_000 == 0 else (f"{N // 1000}k" if N % 1000 == 0 else str(N))
 
         line = {
-            "metric": f"raster fwd+bwd Mpix/s @{res_name} ({n_name} Gaussians, SH{deg})",
+            "metric": f"raster fwd+bwd Mpix/s @{res_name} ({n_name} Gaussians, SH{deg})"
+                      + ("; train iters/s in `train`" if args.train_iters > 0 else ""),
             "value": round(value, 2),
             "unit": "Mpix/s",
             "n_gpus": world,
@@ -470,7 +677,7 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "cpu_baseline_one_thread": cpu1,
+            "cpu_baseline_one_thread_60k_gaussian_subset": cpu1,
             "kernels": per_kernel,
             "kernel_events": f"HIP events around each native call on every {args.event_every}th timed step" if args.event_every > 1 else "HIP events around each native call on every timed step",
             "end_to_end_algorithmic_GBps": round(end_to_end, 1),
@@ -478,12 +685,12 @@ def main():
             "allreduce_ms": (round(float(np.mean([a.elapsed_time(b) for a, b in comm_events])), 4)
                              if comm_events else None),
             "allreduce_ms_note": "exposed part: from the end of the queued backward to the last collective" if comm_events else None,
-            "allreduce_bytes": exchange.bytes_last if world > 1 else None,
+            "allreduce_bytes": allreduce_bytes,
         }
+        # the second half of BASELINE's metric: config 3 (N = 1) / config 4 (N > 1) training, timed inside
+        # this run (a fresh process: its failure cannot cost the line above)
+        line["train"] = train_record(args, world) if args.train_iters > 0 else None
         print(json.dumps(line), flush=True)
-
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

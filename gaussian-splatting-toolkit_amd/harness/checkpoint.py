@@ -75,6 +75,8 @@ def save_checkpoint(directory: str, step: int, model, optims: Dict[str, torch.op
         "pipeline": {_PREFIX + k: model.gauss[k].detach() for k in PARAM_NAMES},
         "optimizers": optimizer_state_dicts(model, optims),
         "schedulers": {},
+        # exactly what the reference writes for this method: mixed_precision=False -> a DISABLED
+        # GradScaler, whose state_dict() is {} and whose load_state_dict is a no-op (trainer.py:126,425,467)
         "scalers": {},
     }, path)
     if save_only_latest:
@@ -107,14 +109,16 @@ def load_model_state(model, state: Dict[str, torch.Tensor]) -> int:
     return newp
 
 
-def load_checkpoint(path: str, model, optims: Dict[str, torch.optim.Optimizer]) -> int:
+def load_checkpoint(path: str, model, optims: Dict[str, torch.optim.Optimizer], trust_pickle: bool = False) -> int:
     """trainer.py:404-443 for one file or a directory (latest step).  The model is resized,
     every optimizer is pointed at the new parameter objects and gets the saved Adam state
     (``step``, ``exp_avg``, ``exp_avg_sq``) and learning rate.  Returns the step to resume
     at (``loaded step + 1``)."""
     if os.path.isdir(path):
         path = latest_checkpoint(path)
-    loaded = torch.load(path, map_location="cpu", weights_only=False)
+    # the payload is tensors, dicts, numbers and strings: the safe loader reads it.  A third-party
+    # .ckpt may carry arbitrary pickled objects -- those only on the caller's explicit say-so.
+    loaded = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
     old = {k: model.gauss[k] for k in PARAM_NAMES}
     load_model_state(model, loaded["pipeline"])
     for name in PARAM_NAMES:
@@ -137,8 +141,11 @@ def load_checkpoint(path: str, model, optims: Dict[str, torch.optim.Optimizer]) 
                 raise ValueError(f"optimizer state of {name} has {st['exp_avg'].shape[0]} rows, the model {new.shape[0]}")
             step = st["step"]
             keep_tensor_step = isinstance(o, torch.optim.Adam)  # torch's Adam keeps `step` as a tensor
+            # ... a float32 one, on the parameter's device when the group is fused or capturable
+            step_dev = new.device if (g.get("fused") or g.get("capturable")) else "cpu"
             o.state[new] = {
-                "step": (torch.as_tensor(float(step)) if keep_tensor_step else int(float(step))),
+                "step": (torch.tensor(float(step), dtype=torch.float32, device=step_dev) if keep_tensor_step
+                         else int(float(step))),
                 "exp_avg": st["exp_avg"].to(device=new.device, dtype=torch.float32).contiguous(),
                 "exp_avg_sq": st["exp_avg_sq"].to(device=new.device, dtype=torch.float32).contiguous(),
             }

@@ -124,14 +124,18 @@ class GradientExchange:
         self.bytes_last = 0
         self._bytes = 0
         self._handles = []
+        self.use_hooks = True
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self._ws = dist.get_world_size(group) if self.enabled else 1
         self._avg_in_collective = self.enabled and dist.get_backend(group) == "nccl" and average
 
     def attach(self) -> "GradientExchange":
-        """(Re-)register the hooks, e.g. after refinement replaced the parameter objects."""
+        """(Re-)register the hooks, e.g. after refinement replaced the parameter objects.
+        With ``use_hooks = False`` (HIP-graph replay: a hook would issue its collective during the
+        warm-up backwards and bake one into the captured graph) nothing is registered and the
+        caller starts the exchange with `start_all()` after the replay."""
         self.detach()
-        if self.enabled:
+        if self.enabled and self.use_hooks:
             for name, p in self.named.items():
                 self._handles.append(p.register_post_accumulate_grad_hook(
                     lambda param, name=name: self._start(name, param)))
@@ -151,8 +155,11 @@ class GradientExchange:
         rows = self.active_rows.get(name)
         stage = None
         if rows is not None and g.dim() >= 2 and rows < g.shape[1]:
+            # the kernels write B[k] * v with B[k] = 0 into the inactive bands: exact zeros unless a
+            # cotangent was non-finite on this rank only -- zero them so the replicas cannot diverge
+            g[:, max(rows, 0):].zero_()
             if rows <= 0:
-                return  # exact zeros on every rank
+                return  # zeros on every rank
             stage = g[:, :rows].contiguous()  # the active bands, packed
             buf = stage
         else:
@@ -178,7 +185,14 @@ class GradientExchange:
 
     def finish(self) -> int:
         """Wait for the collectives started during this backward; parameters that received
-        no gradient on this rank are exchanged as zeros.  Returns the bytes exchanged."""
+        no gradient on this rank are exchanged as zeros.  Returns the bytes exchanged.
+
+        Collectives match across ranks by ISSUE ORDER: the hook-started ones follow the order in
+        which autograd produces the gradients, the late ones (below) the order of `named`.  Every
+        rank must therefore build the same autograd graph over the same set of parameters -- true
+        for per-view data parallelism (same model, same ops, another camera); a rank-dependent
+        branch that drops a parameter from the graph on one rank only would pair different
+        tensors' collectives."""
         if not self.enabled:
             return 0
         seen = {id(g) for _, _, g, _, _ in self.pending}
@@ -215,3 +229,137 @@ def view_for_rank(step: int, rank: int, world_size: int, num_views: int) -> int:
     """Deterministic per-rank view schedule: ranks never render the same view in
     the same step (the reference relies on per-rank RNG seeds, train.py:54)."""
     return (step * world_size + rank) % num_views
+
+
+class ShardedAdam:
+    """The other way to spend the same wire bytes: instead of all-reducing
+    236 B per Gaussian and running Adam over ALL rows on every rank,
+
+        reduce-scatter the gradients  ->  Adam on this rank's 1/n of the rows  ->  all-gather the parameters
+
+    2 (n-1)/n x 236 B per Gaussian on the wire either way; the Adam kernel and both moments shrink to
+    1/n (0.30 -> 0.04 ms and 472 -> 59 B per Gaussian at n = 8).  Rows, not a flat buffer: a parameter
+    is [N, ...] row-major, so rows [r q, (r+1) q) of every tensor are one contiguous slice and refinement
+    (which replaces all six tensors every `refine_every` iterations) needs no re-packing -- the shard
+    parameters are re-made as views of the new tensors.  q = N // n; the N - n q tail rows (< n) are
+    all-reduced and updated redundantly by every rank.
+
+    Adam is element-wise, and for n = 2 `(a + b) / 2` is the same number whichever collective forms it:
+    the parameters stay bit-identical to the all-reduce path (tests/test_dp_gloo.py, tests/test_gpu_dp.py).
+
+    `make_optimizer(param_groups)` builds the inner optimizer (gs_fused.FusedAdam on the GPU,
+    torch.optim.Adam elsewhere); its parameters are VIEWS of the model's rows."""
+
+    def __init__(self, named_params, lrs, make_optimizer, group=None, average: bool = True):
+        self.group, self.average = group, average
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+        self.lrs = dict(lrs)
+        self.make_optimizer = make_optimizer
+        self._avg = self.enabled and dist.get_backend(group) == "nccl" and average
+        self.bytes_last = 0
+        self.step_count = 0
+        self.bind(named_params, None)
+
+    # ---- layout
+    def _split(self, n):
+        q = n // self.world
+        return q, q * self.world
+
+    def bind(self, named_params, full_moments) -> None:
+        """(Re-)create the shard views over `named_params`; `full_moments` = {name: (exp_avg,
+        exp_avg_sq)} full-size tensors to cut this rank's state from (after refinement), or None."""
+        self.named = dict(named_params)
+        n = next(iter(self.named.values())).shape[0]
+        q, body = self._split(n)
+        self.q, self.body, self.n = q, body, n
+        lo, hi = self.rank * q, (self.rank + 1) * q
+        self.main, self.tail, self.gshard = {}, {}, {}
+        groups = []
+        for name, p in self.named.items():
+            d = p.detach()
+            self.main[name] = torch.nn.Parameter(d[lo:hi])          # a view: updating it updates the model
+            self.tail[name] = torch.nn.Parameter(d[body:]) if body < n else None
+            self.gshard[name] = torch.empty_like(d[lo:hi])
+            ps = [self.main[name]] + ([self.tail[name]] if self.tail[name] is not None else [])
+            groups.append({"params": ps, "lr": self.lrs[name], "name": name})
+        old_step = self.step_count
+        self.inner = self.make_optimizer(groups)
+        if full_moments is not None:
+            for name in self.named:
+                if full_moments.get(name) is None:
+                    continue
+                m, v = full_moments[name]
+                for prm, sl in ((self.main[name], slice(lo, hi)), (self.tail[name], slice(body, n))):
+                    if prm is None:
+                        continue
+                    self.inner.state[prm] = {"step": self._step_value(old_step), "exp_avg": m[sl].clone(),
+                                             "exp_avg_sq": v[sl].clone()}
+
+    def _step_value(self, k):
+        # torch.optim.Adam keeps `step` as a tensor, gs_fused.FusedAdam as an int
+        return torch.tensor(float(k)) if isinstance(self.inner, torch.optim.Adam) else int(k)
+
+    def set_lr(self, name, lr) -> None:
+        for g in self.inner.param_groups:
+            if g["name"] == name:
+                g["lr"] = lr
+
+    # ---- one update
+    def step(self) -> int:
+        """gradients in `p.grad` of the full parameters -> updated, replica-identical parameters.
+        Returns the bytes this rank handed to collectives."""
+        lo, hi = self.rank * self.q, (self.rank + 1) * self.q
+        nbytes = 0
+        for name, p in self.named.items():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            g = g.contiguous()
+            if self.enabled:
+                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+                if self.q > 0:
+                    dist.reduce_scatter_tensor(self.gshard[name], g[:self.body], op=op, group=self.group)
+                    nbytes += g[:self.body].numel() * 4
+                if self.body < self.n:
+                    dist.all_reduce(g[self.body:], op=op, group=self.group)
+                    nbytes += g[self.body:].numel() * 4
+                if self.average and not self._avg:
+                    self.gshard[name].div_(self.world)
+                    g[self.body:].div_(self.world)
+            else:
+                self.gshard[name].copy_(g[lo:hi])
+            self.main[name].grad = self.gshard[name]
+            if self.tail[name] is not None:
+                self.tail[name].grad = g[self.body:]
+        self.inner.step()
+        self.step_count += 1
+        if self.enabled and self.q > 0:
+            for name, p in self.named.items():
+                d = p.detach()
+                dist.all_gather_into_tensor(d[:self.body], d[lo:hi], group=self.group)  # in place
+                nbytes += d[lo:hi].numel() * 4
+        self.bytes_last = nbytes
+        return nbytes
+
+    # ---- refinement / checkpoints need the whole state
+    def full_moments(self):
+        """{name: (exp_avg, exp_avg_sq)} at full size on every rank (one all-gather per moment)."""
+        out = {}
+        lo, hi = self.rank * self.q, (self.rank + 1) * self.q
+        for name, p in self.named.items():
+            st = self.inner.state.get(self.main[name])
+            if not st or "exp_avg" not in st:
+                continue
+            pair = []
+            for key in ("exp_avg", "exp_avg_sq"):
+                full = torch.zeros_like(p.detach())
+                if self.q > 0:
+                    if self.enabled:
+                        dist.all_gather_into_tensor(full[:self.body], st[key].contiguous(), group=self.group)
+                    else:
+                        full[lo:hi].copy_(st[key])
+                if self.tail[name] is not None:
+                    full[self.body:].copy_(self.inner.state[self.tail[name]][key])
+                pair.append(full)
+            out[name] = tuple(pair)
+        return out

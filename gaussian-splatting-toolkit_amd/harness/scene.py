@@ -149,3 +149,17 @@ def algorithmic_bytes(n: int, num_intersects: int, pixels: int, tiles: int, sh_b
     per["count_reach"] = 64 * N
     per["total"] = sum(v for k, v in per.items() if k not in ("depth_order", "bin_sorted", "count_reach"))
     return per
+
+
+def built_pipeline_bytes(n: int, list_entries: int, tiles: int):
+    """Compulsory HBM traffic of the list construction AS BUILT, which is
+    not the reference's organisation that `algorithmic_bytes` prices (scan / map / 64-bit sort /
+    bin edges):
+      count_reach  60 N              reads xys, radii, conics, opacity (28 B), writes one 32-B record
+      depth_order  12 N              reads depth + radius (8 B), writes the order (4 B)
+      bin_sorted   36 N + 24 I' + 8 T   two-level partition: order + record per Gaussian, 8 B written
+                                     + 14 B read + 4 B written per list entry (rounded up to 24
+                                     with the chunk tables), tile_bins
+    I' = list entries after the exact reach test."""
+    N, I, T = n, list_entries, tiles
+    return {"count_reach": 60 * N, "depth_order": 12 * N, "bin_sorted": 36 * N + 24 * I + 8 * T}

@@ -70,7 +70,7 @@ def orbit_cameras(n_views: int, width: int, height: int, radius: float = 6.0, fo
 
 
 def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale_lo=0.01, scale_hi=0.06,
-               kind: str = "ball"):
+               kind: str = "ball", tex_cell: float = 0.04, objects=(48, 0.18, 0.45)):
     """Raw (pre-activation) Gaussians around the origin.  kind="ball": semi-transparent
     Gaussians filling a ball (a smooth volume).  kind="shell": opaque, small, flat-ish
     Gaussians on three nested textured spheres -- surfaces with detail at the pixel scale,
@@ -80,6 +80,37 @@ def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale
     p /= np.linalg.norm(p, axis=-1, keepdims=True)
     K = S.num_sh_bases(sh_degree)
     f32 = np.float32
+    if kind == "objects":
+        # a nerfstudio-style object scene: `n_obj` opaque spheres of different sizes scattered in a
+        # ball (silhouettes against the background, mutual occlusion), each tiled by small FLAT
+        # Gaussians aligned with the surface and textured with a high-contrast checker whose cells
+        # are a few Gaussians wide -- detail a sparse start cannot represent without densifying
+        n_obj, r_lo, r_hi = int(objects[0]), float(objects[1]), float(objects[2])
+        centres = rng.standard_normal((n_obj, 3))
+        centres *= (extent * rng.uniform(0.15, 1.0, (n_obj, 1)) ** (1 / 3)) / np.linalg.norm(centres, axis=-1, keepdims=True)
+        radii = rng.uniform(r_lo, r_hi, n_obj)
+        which = rng.choice(n_obj, n, p=radii ** 2 / np.sum(radii ** 2))  # by area
+        r = radii[which][:, None]
+        means = centres[which] + p * (r + 0.002 * rng.standard_normal((n, 1)))
+        base = rng.uniform(0.15, 0.85, (n_obj, 3))[which]
+        other = rng.uniform(0.0, 1.0, (n_obj, 3))[which]
+        cell = tex_cell / r[:, 0]  # checker cell size in radians: `tex_cell` scene units on every sphere
+        u = np.arctan2(p[:, 0], p[:, 2]) * np.maximum(np.sqrt(1 - p[:, 1] ** 2), 0.2)
+        v = np.arcsin(np.clip(p[:, 1], -1, 1))
+        chk = ((np.floor(u / cell) + np.floor(v / cell)) % 2)[:, None]
+        colour = np.where(chk > 0, base, other) * (0.85 + 0.15 * rng.uniform(0, 1, (n, 1)))
+        dc = (np.clip(colour, 0, 1) - 0.5) / SH_C0
+        s_t = rng.uniform(math.log(scale_lo), math.log(scale_hi), (n, 2))
+        scales = np.concatenate([s_t, s_t.min(axis=1, keepdims=True) + math.log(0.15)], axis=1)  # thin along the normal
+        # quaternion (w, x, y, z) turning the local z axis into the outward normal p
+        quats = np.stack([1.0 + p[:, 2], -p[:, 1], p[:, 0], np.zeros(n)], axis=-1)
+        quats[np.linalg.norm(quats, axis=-1) < 1e-6] = (0.0, 1.0, 0.0, 0.0)
+        quats /= np.linalg.norm(quats, axis=-1, keepdims=True)
+        return {
+            "means": means.astype(f32), "scales": scales.astype(f32), "quats": quats.astype(f32),
+            "opacities": rng.uniform(2.0, 5.0, (n, 1)).astype(f32), "features_dc": dc.astype(f32),
+            "features_rest": (rng.standard_normal((n, K - 1, 3)) * 0.02).astype(f32),
+        }
     if kind == "shell":
         radius = np.array([0.7, 1.1, 1.5])[rng.integers(0, 3, n)][:, None]
         means = p * (radius + 0.004 * rng.standard_normal((n, 1)))
@@ -101,6 +132,67 @@ def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale
         "features_dc": dc.astype(f32),
         "features_rest": (rng.standard_normal((n, K - 1, 3)) * 0.05).astype(f32),
     }
+
+
+def knn_mean_distance(points: np.ndarray, k: int = 3) -> np.ndarray:
+    """Mean distance to the k nearest neighbours, the reference's initial scale
+    (`k_nearest_sklearn`, vanilla_gs.py:136-140, 260-280: k + 1 neighbours, self dropped)."""
+    from sklearn.neighbors import NearestNeighbors
+
+    d, _ = NearestNeighbors(n_neighbors=k + 1, algorithm="auto", metric="euclidean").fit(points).kneighbors(points)
+    return d[:, 1:].astype(np.float32).mean(axis=-1)
+
+
+def random_quats(n: int, rng) -> np.ndarray:
+    """`random_quat_tensor` (gs_toolkit/utils/comms.py:69-84): uniform on the unit 3-sphere."""
+    u, v, w = rng.uniform(size=n), rng.uniform(size=n), rng.uniform(size=n)
+    return np.stack([np.sqrt(1 - u) * np.sin(2 * math.pi * v), np.sqrt(1 - u) * np.cos(2 * math.pi * v),
+                     np.sqrt(u) * np.sin(2 * math.pi * w), np.sqrt(u) * np.cos(2 * math.pi * w)], -1).astype(np.float32)
+
+
+def seed_model(truth: Dict[str, np.ndarray], n_seed: int, kind: str, seed: int, sh_degree: int = 3,
+               sfm_noise: float = 0.01, random_scale: float = 3.4):
+    """The model's start as `GaussianSplattingModel.populate_modules` builds it
+    (vanilla_gs.py:128-174) -- NOT a copy of the truth:
+      kind="sfm":    a sparse point cloud with 8-bit colours, standing in for the COLMAP points
+                     a nerfstudio-style dataset ships: `n_seed` surface points of the hidden scene
+                     with `sfm_noise` of triangulation error; colour = the point's view-independent
+                     colour.  means = the points, features_dc = RGB2SH(colour);
+      kind="random": `random_init=True`: means uniform in a cube of edge `random_scale`
+                     (the reference's 10 is for its unit-normalised real scenes; 3.4 encloses
+                     this scene's radius-1.5 shells), features_dc = rand.
+    Both: log-scales = log(mean distance to the 3 nearest seeds) on all three axes, random unit
+    quaternions, opacity logit(0.1), higher SH bands zero."""
+    rng = np.random.default_rng(seed)
+    K = S.num_sh_bases(sh_degree)
+    f32 = np.float32
+    if kind == "sfm":
+        pick = np.sort(rng.choice(truth["means"].shape[0], n_seed, replace=False))
+        means = truth["means"][pick] + rng.standard_normal((n_seed, 3)).astype(f32) * f32(sfm_noise)
+        rgb8 = np.round(np.clip(truth["features_dc"][pick] * SH_C0 + 0.5, 0, 1) * 255.0)
+        dc = ((rgb8 / 255.0) - 0.5) / SH_C0
+    elif kind == "random":
+        means = (rng.uniform(size=(n_seed, 3)) - 0.5) * random_scale
+        dc = rng.uniform(size=(n_seed, 3))
+    else:
+        raise ValueError(f"unknown seed kind {kind!r}")
+    means = means.astype(f32)
+    avg = np.maximum(knn_mean_distance(means, 3), 1e-7)
+    return {
+        "means": means,
+        "scales": np.repeat(np.log(avg)[:, None], 3, axis=1).astype(f32),
+        "quats": random_quats(n_seed, rng),
+        "opacities": np.full((n_seed, 1), math.log(0.1 / 0.9), f32),
+        "features_dc": dc.astype(f32),
+        "features_rest": np.zeros((n_seed, K - 1, 3), f32),
+    }
+
+
+def means_lr(step: int, lr_init: float = 1.6e-4, lr_final: float = 1.6e-6, max_steps: int = 30000) -> float:
+    """`ExponentialDecayScheduler` without warm-up, the schedule of the "means" group
+    (configs/method_configs.py:98-104, engine/schedulers.py:94-135)."""
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
 class GaussianParams(torch.nn.Module):
@@ -207,30 +299,47 @@ class TrainConfig:
     save_every: int = 0                   # steps_per_save; 0 = never
     resume_from: Optional[str] = None     # a .ckpt file or a directory (latest step)
     scene: str = "ball"                   # blob_scene kind
+    # where the model starts: "perturbed" = the hidden scene with noise on the means and washed-out
+    # colour (optionally a subset, init_gaussians); "sfm" / "random" = the reference's own
+    # initialisations from a sparse point cloud / uniformly random points (seed_model)
+    init: str = "perturbed"
+    means_lr_schedule: bool = False       # exponential decay of the "means" learning rate (method_configs.py:98-104)
+    # data parallel only: reduce-scatter -> Adam on this rank's rows -> all-gather (parallel.ShardedAdam)
+    # instead of all-reduce + Adam over every row on every rank
+    sharded_adam: bool = False
+    phase_every: int = 0                  # HIP events around render / loss / backward / optimizer on every k-th iteration
     scene_scale: tuple = (0.01, 0.06)     # range of the truth's Gaussian scales
+    tex_cell: float = 0.04                # scene "objects": checker cell size in scene units
+    scene_objects: tuple = (48, 0.18, 0.45)  # scene "objects": number of spheres, radius range
+    cam_radius: float = 6.0               # radius of the camera orbit
+    scene_extent: float = 1.5             # radius of the ball the scene fills
 
 
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     """Fit a perturbed copy of a hidden scene to its own renders.  Returns timing
     and quality numbers; every rank ends with identical parameters."""
-    cams_np = orbit_cameras(cfg.num_views, cfg.width, cfg.height)
+    cams_np = orbit_cameras(cfg.num_views, cfg.width, cfg.height, radius=cfg.cam_radius)
     cams = [CameraTensors.from_numpy(c, device) for c in cams_np]
     bg = torch.tensor(S.BACKGROUND, device=device)
 
     mk = lambda: blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree, kind=cfg.scene,
-                            scale_lo=cfg.scene_scale[0], scale_hi=cfg.scene_scale[1])
+                            scale_lo=cfg.scene_scale[0], scale_hi=cfg.scene_scale[1], tex_cell=cfg.tex_cell,
+                            objects=cfg.scene_objects, extent=cfg.scene_extent)
     truth = GaussianParams(mk(), device)
     with torch.no_grad():
         gt = [truth.render(c, bg, cfg.sh_degree)["rgb"] for c in cams]
 
-    # the model starts from the truth with perturbed geometry / washed-out colour
     raw = mk()
     rng = np.random.default_rng(cfg.seed + 1)
-    raw["means"] += rng.standard_normal(raw["means"].shape).astype(np.float32) * 0.01
-    raw["features_dc"] *= 0.3
-    raw["features_rest"] *= 0.0
-    raw["opacities"] -= 0.5
-    if cfg.init_gaussians is not None and cfg.init_gaussians < cfg.num_gaussians:
+    if cfg.init in ("sfm", "random"):
+        raw = seed_model(raw, cfg.init_gaussians or 50_000, cfg.init, cfg.seed + 1, cfg.sh_degree)
+    else:
+        # the model starts from the truth with perturbed geometry / washed-out colour
+        raw["means"] += rng.standard_normal(raw["means"].shape).astype(np.float32) * 0.01
+        raw["features_dc"] *= 0.3
+        raw["features_rest"] *= 0.0
+        raw["opacities"] -= 0.5
+    if cfg.init == "perturbed" and cfg.init_gaussians is not None and cfg.init_gaussians < cfg.num_gaussians:
         # a coarser start for densification to refine: a subset, each Gaussian standing in for
         # num/init of the truth's (scales grown by the cube root of that ratio)
         keep = np.sort(rng.choice(cfg.num_gaussians, cfg.init_gaussians, replace=False))
@@ -250,6 +359,20 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             optims = {"all": FusedAdam(groups, eps=1e-15)}
     else:
         optims = {k: torch.optim.Adam([model.gauss[k]], lr=lr, eps=1e-15) for k, lr in LRS.items()}
+    sharded = None
+    if cfg.sharded_adam and world > 1:
+        from .parallel import ShardedAdam
+
+        if cfg.save_every or cfg.resume_from:
+            raise NotImplementedError("checkpoints with sharded_adam: gather ShardedAdam.full_moments() first")
+        if cfg.fused_adam and device.type == "cuda":
+            from gs_fused import FusedAdam
+
+            make = lambda groups: FusedAdam(groups, eps=1e-15)
+        else:
+            make = lambda groups: torch.optim.Adam(groups, eps=1e-15)
+        sharded = ShardedAdam({k: model.gauss[k] for k in PARAM_NAMES}, LRS, make)
+        optims = {}
     fused_clamp = False
     if cfg.fused_loss and device.type == "cuda":
         from gs_fused import l1_ssim_loss
@@ -296,7 +419,13 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     losses = []
     # gradient exchange: started per parameter from autograd hooks (overlaps the rest of the
     # backward), SH bands above the warm-up degree left out
-    exchange = GradientExchange({k: model.gauss[k] for k in PARAM_NAMES}, average=True).attach()
+    exchange = GradientExchange({k: model.gauss[k] for k in PARAM_NAMES}, average=True)
+    # a replayed HIP graph fires no hooks, and a hook during capture would put a collective INTO the
+    # graph (and reduce every gradient twice): under use_graph the exchange is started after the replay
+    exchange.use_hooks = not cfg.use_graph
+    if sharded is not None:
+        exchange.enabled = False  # the gradients travel by reduce-scatter inside ShardedAdam.step()
+    exchange.attach()
     exchanged_bytes = []
     if device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -306,6 +435,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     use_fused = (cfg.fused_render or cfg.use_graph) and device.type == "cuda" and cfg.split_sh and cfg.fused_loss \
         and cfg.sh_degree in (1, 2, 3)
     fstats = caps = vgraph = vkey = None
+    generation = 0
     overflow_views = 0
     if use_fused:
         from gs_fused import DensifyStats, ListCapacity, ViewSpec, render_gaussians
@@ -326,7 +456,13 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                     caps.capacity = max(caps.capacity, ((int(1.5 * need) + 65536 + (1 << 20) - 1) >> 20) << 20)
                     break
                 caps.capacity = ((int(1.5 * need) + (1 << 20)) >> 20) << 20
+    def zero_grads():
+        for p_ in model.param_list():
+            p_.grad = None
+
+    phase_marks = []
     for step in range(start_step, cfg.iters):
+        ph = None
         v = view_for_rank(step, rank, world, cfg.num_views)
         deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
         exchange.active_rows["features_rest"] = (deg + 1) ** 2 - 1
@@ -336,7 +472,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             fstats.enabled = not (cfg.densify and step >= rcfg.stop_split_at)
             g_ = model.gauss
             if cfg.use_graph:
-                key = (spec, model.num_points, caps.capacity, fstats.enabled)
+                # `generation` counts the refinements that swapped parameter tensors: N can come out
+                # unchanged (k culled, k duplicated) while every tensor the graph points at is gone
+                key = (spec, model.num_points, caps.capacity, fstats.enabled, generation)
                 if vkey != key:  # new SH degree, N changed by refinement, or larger lists: capture again
                     vgraph = ViewGraph({k: g_[k] for k in PARAM_NAMES}, spec, caps.capacity, graph_loss, bg,
                                        [(cfg.height, cfg.width, 3)], stats=fstats)
@@ -351,8 +489,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                 if world > 1:
                     exchange.start_all()
             else:
-                for o in optims.values():
-                    o.zero_grad(set_to_none=True)
+                zero_grads()
                 slot = caps.slot(device)
                 used = caps.capacity
                 out = render_gaussians(g_["means"], g_["scales"], g_["quats"], g_["opacities"], g_["features_dc"],
@@ -364,12 +501,20 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                 if caps.overflowed():
                     overflow_views += 1
         else:
-            for o in optims.values():
-                o.zero_grad(set_to_none=True)
+            zero_grads()
+            ph = _phase_marks(5) if (cfg.phase_every and step % cfg.phase_every == 0 and device.type == "cuda") else None
+            if ph:
+                ph[0].record()
             out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp)
             rgb = out["rgb"]
+            if ph:
+                ph[1].record()
             loss = loss_fn(rgb, gt[v])
+            if ph:
+                ph[2].record()
             loss.backward()
+            if ph:
+                ph[3].record()
         # densification statistics (vanilla_gs.py:344-372; not updated past stop_split_at, :347)
         if use_fused or (cfg.densify and step >= rcfg.stop_split_at):
             pass
@@ -390,12 +535,26 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                     vis_counts += visible.to(torch.int32)
                     max_2dsize = torch.where(visible, torch.maximum(max_2dsize, size), max_2dsize)
         stats_first = False
-        if world > 1:
+        if world > 1 and sharded is None:
             b = exchange.finish()
             if not exchanged_bytes or exchanged_bytes[-1][1] != b:
                 exchanged_bytes.append((step, b))
+        if cfg.means_lr_schedule:
+            # the scheduler steps after the optimizer (trainer.py:479-525): iteration `step` runs at lr(step)
+            if sharded is not None:
+                sharded.set_lr("means", means_lr(step, LRS["means"]))
+            else:
+                grp = optims["all"].param_groups[0] if "all" in optims else optims["means"].param_groups[0]
+                grp["lr"] = means_lr(step, LRS["means"])
         for o in optims.values():
             o.step()
+        if sharded is not None:
+            b = sharded.step()
+            if not exchanged_bytes or exchanged_bytes[-1][1] != b:
+                exchanged_bytes.append((step, b))
+        if ph:
+            ph[4].record()
+            phase_marks.append(ph)
         # refinement_after: every refine_every iterations, after the optimizer step
         # (TrainingCallback(update_every_num_iters=refine_every), vanilla_gs.py:610-616)
         if cfg.densify and step % rcfg.refine_every == 0 and step > rcfg.warmup_length:
@@ -409,9 +568,12 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                 moments = {}
                 for o in optims.values():
                     moments.update(_adam_moments(o, old))
+                if sharded is not None:
+                    moments = sharded.full_moments()  # refinement moves whole rows of both moments
                 new, new_moments, info = _refine(old, moments, (xys_grad_norm, vis_counts, max_2dsize), rcfg, step,
                                                  cfg.num_views, max_dim, seed=cfg.refine_seed + step)
                 if any(new[k] is not old[k] for k in PARAM_NAMES):
+                    generation += 1
                     model.replace(new)
                     cur = {k: model.gauss[k] for k in PARAM_NAMES}
                     for o in optims.values():
@@ -425,6 +587,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                             fstats = DensifyStats(n, device, max_dim)
                     history.append((step, model.num_points))
                     exchange.rebind({k: model.gauss[k] for k in PARAM_NAMES})
+                if sharded is not None:
+                    # new tensors, or the same ones with an opacity reset (which zeroed moments in the
+                    # gathered copies): cut this rank's rows again
+                    sharded.bind({k: model.gauss[k] for k in PARAM_NAMES}, new_moments)
             # the statistics restart after every refinement_after past the warm-up (:491-493)
             stats_first = True
             if use_fused:
@@ -442,6 +608,12 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     psnr1 = evaluate()
+    phases = None
+    if phase_marks:
+        names = ("render", "loss", "backward", "stats_exchange_optimizer")
+        ms = np.array([[m[i].elapsed_time(m[i + 1]) for i in range(4)] for m in phase_marks])
+        phases = {k: round(float(np.median(ms[:, i])), 4) for i, k in enumerate(names)}
+        phases["samples"] = len(phase_marks)
     checksum = float(sum(p.detach().double().sum() for p in model.param_list()))
     return {"iters": cfg.iters - start_step, "start_step": start_step, "seconds": elapsed,
             "iters_per_s": (cfg.iters - start_step) / elapsed, "psnr_start": psnr0,
@@ -451,7 +623,13 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             # (step, bytes) whenever the per-step exchange volume changed: SH warm-up, refinement
             "allreduce_bytes": exchanged_bytes,
             "render": ("hip graph per view" if cfg.use_graph else "one fused op") if use_fused else "separate ops",
-            "list_overflow_views": overflow_views}
+            "list_overflow_views": overflow_views, "phase_ms_median": phases,
+            "update": "reduce-scatter + sharded Adam + all-gather" if sharded is not None else "all-reduce + Adam", "init": cfg.init,
+            "densify_grad_thresh": (rcfg.densify_grad_thresh if cfg.densify else None)}
+
+
+def _phase_marks(n):
+    return [torch.cuda.Event(enable_timing=True) for _ in range(n)]
 
 
 # the refinement backend (module-level so that CPU tests can substitute stand-ins)

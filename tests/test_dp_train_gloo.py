@@ -23,11 +23,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, sharded=False, views=4):
     for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -38,7 +38,7 @@ def _run(rank, world, port, q):
     from gs_fused import RefineConfig
     from oracle import oracle as O
 
-    O.set_threads(2)
+    O.set_threads(2 if world <= 2 else 1)
     HP.project_gaussians, HP.spherical_harmonics, HP.rasterize_gaussians = (
         SI.project_gaussians, SI.spherical_harmonics, SI.rasterize_gaussians)
     HT._refine = lambda params, moments, stats, rcfg, step, ntd, max_dim, seed: SI.refine_gaussians(
@@ -47,12 +47,12 @@ def _run(rank, world, port, q):
     # 10 and 40, cull only from step 55 on
     rcfg = RefineConfig(warmup_length=9, refine_every=10, reset_alpha_every=3, stop_screen_size_at=30,
                         stop_split_at=55, densify_grad_thresh=GRAD_THRESH, cull_alpha_thresh=0.05)
-    cfg = HT.TrainConfig(num_gaussians=600, init_gaussians=200, width=64, height=48, num_views=4, iters=62,
+    cfg = HT.TrainConfig(num_gaussians=600, init_gaussians=200, width=64, height=48, num_views=views, iters=62,
                          sh_degree=1, sh_degree_interval=10, eval_views=2, densify=True, refine=rcfg,
-                         scene_scale=(0.03, 0.15))
+                         scene_scale=(0.03, 0.15), sharded_adam=sharded)
     res = HT.train(cfg, torch.device("cpu"), rank, world)
     q.put((rank, res["param_checksum"], res["num_gaussians_start"], res["num_gaussians_end"], res["refinements"],
-           res["psnr_start"], res["psnr_end"]))
+           res["psnr_start"], res["psnr_end"], res["allreduce_bytes"], res["update"]))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -78,3 +78,51 @@ def test_two_rank_training_with_refinement_keeps_replicas_identical():
     import math
 
     assert math.isfinite(a[1]) and math.isfinite(a[6])
+
+
+def _launch(world, sharded=False, views=4):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, sharded, views)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=800) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.timeout(900)
+def test_sharded_update_gives_the_same_replicas_as_the_all_reduce():
+    """reduce-scatter -> Adam on this rank's rows -> all-gather (parallel.ShardedAdam) against all-reduce +
+    Adam over every row: at two ranks (a + b) / 2 is the same number whichever collective forms it and
+    Adam is element-wise, so the parameters must be BIT-identical -- through refinements that change N
+    (odd N included: the tail rows are all-reduced) and an opacity reset."""
+    plain = _launch(2, sharded=False)
+    shard = _launch(2, sharded=True)
+    assert shard[0][8].startswith("reduce-scatter") and plain[0][8].startswith("all-reduce")
+    assert shard[0][1] == shard[1][1]                      # replicas identical
+    assert shard[0][4] == plain[0][4] and len(shard[0][4]) >= 2   # same refinement history
+    assert shard[0][1] == plain[0][1], (shard[0][1], plain[0][1])  # same parameters, bit for bit
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("sharded", [False, True])
+def test_eight_rank_training_stand_in(sharded):
+    """BASELINE config 4's shape (8 ranks, per-view data parallel) on the gloo stand-in: eight replicas
+    stay bit-identical through refinement, take the same N history, and report the bytes they exchange
+    per step in every phase (SH warm-up, after each refinement)."""
+    res = _launch(8, sharded=sharded, views=8)
+    sums = {r[1] for r in res}
+    assert len(sums) == 1, sums
+    hist = res[0][4]
+    assert all(r[4] == hist for r in res) and len(hist) >= 2
+    assert all(r[3] == res[0][3] for r in res) and res[0][3] != 200
+    by = res[0][7]
+    assert by and all(b > 0 for _, b in by)
+    if not sharded:
+        # degree 0 (56 B per Gaussian) -> degree 1 (+36 B), then new N after every refinement
+        assert by[0][1] == 200 * 56 and by[1][0] == 10 and by[1][1] == 200 * 92, by
+    assert len(by) >= 3, by

@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--gaussians", "60000", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "2", "--no-pmc"]
+SMALL = ["--train-iters", "0", "--gaussians", "60000", "--width", "640", "--height", "360", "--steps", "4", "--warmup", "2", "--no-pmc"]
 
 
 def _run(extra):

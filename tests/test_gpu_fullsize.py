@@ -46,6 +46,11 @@ def stable_gaussians(amb_pixels, amb_gaussians, xys, radii, W, H):
     return ~(touched | amb_gaussians)
 
 
+# share of the visible Gaussians of config 2 that are decision-stable, i.e. held to 1e-3 relative
+# elementwise: measured value minus 10 % (profiles/r03_config2_stable_fraction.json)
+STABLE_VISIBLE_FLOOR = 0.05
+
+
 def grad_close(mine, ref, abs_sum=None, name="", stable=None):
     """Per-Gaussian gradients are sums over up to ~1e4 pixels with heavy cancellation.
       * STABLE Gaussians (see `stable_gaussians`): north_star's bar, |err| <= 1e-3 |ref|
@@ -56,7 +61,6 @@ def grad_close(mine, ref, abs_sum=None, name="", stable=None):
       * max |err| <= 1e-3 max|ref|  and  ||err||_2 <= 1e-4 ||ref||_2  always."""
     err = np.abs(mine - ref)
     if stable is not None:
-        assert stable.mean() > 0.05, f"{name}: only {stable.mean():.3f} of the Gaussians are stable"
         rel = err[stable] / np.maximum(np.abs(ref[stable]), 1e-4 * np.abs(ref).max())
         assert rel.max() <= 1e-3, f"{name}: stable Gaussians differ by {rel.max():.3e} relative"
     if abs_sum is not None:
@@ -117,6 +121,26 @@ def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
         H, W, 16, vs, bins, gx, gc, rgbs, sc["opacities"], bg, ref_T, ref_idx, v_img, v_alpha,
         with_abs_sums=True, ambig_eps=1e-5)
     stable = stable_gaussians(amb, amb_g, gx, g_radii, W, H)
+    # how many Gaussians carry the 1e-3 claim: the share of the VISIBLE ones (an invisible Gaussian is
+    # trivially stable) that are decision-stable.  Printed, stored next to the profiles, and floored at
+    # the measured value minus 10 % (round 3: see STABLE_VISIBLE_FLOOR)
+    visible = g_radii > 0
+    frac = float((stable & visible).sum()) / float(visible.sum())
+    report = {"gaussians": n, "visible": int(visible.sum()), "stable_visible": int((stable & visible).sum()),
+              "stable_fraction_of_visible": round(frac, 4), "ambiguous_pixels": round(float(amb.mean()), 5),
+              "floor": STABLE_VISIBLE_FLOOR}
+    print("config2 stable Gaussians:", report)
+    try:
+        import json
+        import os
+
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "config2_stable_fraction.json"), "w") as fh:
+            json.dump(report, fh)
+    except OSError:
+        pass
+    assert frac > STABLE_VISIBLE_FLOOR, report
     grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable)
     grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable)
     vsh = O.compute_sh_backward(n, deg, deg, dirs, (vcol * (sh + 0.5 > 0)).astype(np.float32))

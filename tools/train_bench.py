@@ -37,8 +37,16 @@ def main():
     ap.add_argument("--log-every", type=int, default=0)
     ap.add_argument("--fused-render", action="store_true", help="gs_fused.render_gaussians: one autograd node per view")
     ap.add_argument("--graph", action="store_true", help="render -> loss -> backward replayed as one HIP graph per view")
-    ap.add_argument("--scene", default="ball", choices=["ball", "shell"])
+    ap.add_argument("--scene", default="ball", choices=["ball", "shell", "objects"])
+    ap.add_argument("--tex-cell", type=float, default=0.04)
+    ap.add_argument("--objects", type=float, nargs=3, default=[48, 0.18, 0.45], help="spheres: count, r_lo, r_hi")
+    ap.add_argument("--cam-radius", type=float, default=6.0)
+    ap.add_argument("--extent", type=float, default=1.5)
     ap.add_argument("--scene-scale", type=float, nargs=2, default=[0.01, 0.06])
+    ap.add_argument("--init", default="perturbed", choices=["perturbed", "sfm", "random"],
+                    help="model start: the perturbed truth, or the reference's own initialisations (harness.train.seed_model)")
+    ap.add_argument("--means-lr-schedule", action="store_true", help="exponential decay of the means' learning rate")
+    ap.add_argument("--phase-every", type=int, default=0)
     ap.add_argument("--torch-activations", action="store_true", help="A/B: torch ops for exp/normalise/sigmoid/viewdirs")
     ap.add_argument("--cat-sh", action="store_true", help="A/B: torch.cat + spherical_harmonics instead of the split op")
     ap.add_argument("--torch-fused-adam", action="store_true", help="A/B: torch's fused Adam instead of gs_fused.FusedAdam")
@@ -69,7 +77,8 @@ def main():
                       fused_activations=not args.torch_activations, densify=args.densify,
                       init_gaussians=args.init_gaussians, refine=rcfg, log_every=args.log_every,
                       fused_render=args.fused_render, use_graph=args.graph,
-                      scene=args.scene, scene_scale=tuple(args.scene_scale))
+                      scene=args.scene, scene_scale=tuple(args.scene_scale), init=args.init, tex_cell=args.tex_cell, scene_objects=tuple(args.objects), cam_radius=args.cam_radius, scene_extent=args.extent,
+                      means_lr_schedule=args.means_lr_schedule, phase_every=args.phase_every)
     res = train(cfg, dev, rank, world)
     if world > 1:
         cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
