@@ -285,14 +285,21 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
       const size_t pid = (size_t)row * img_w + col;
       const float Tf = final_Ts[pid];
       T[p] = Tf;
-      vr[p] = v_output[3 * pid];
-      vg[p] = v_output[3 * pid + 1];
-      vb[p] = v_output[3 * pid + 2];
+      // T_final == 1 exactly <=> nothing was composited at this pixel (a drawn splat has alpha >= 1/255):
+      // no splat is `valid` there, and its cotangent must not be READ either -- the models' depth image is
+      // `where(alpha > 0, depth / alpha, max)` (vanilla_gs.py:855, depth_gs.py:356), whose backward hands
+      // 0/0 = NaN to exactly these pixels.  The reference's kernel branches on `valid` and never touches
+      // them (backward.cu:133-303); the flat selects below would turn 0 * NaN into NaN sums.
+      const bool drawn = Tf < 1.f;
+      vr[p] = drawn ? v_output[3 * pid] : 0.f;
+      vg[p] = drawn ? v_output[3 * pid + 1] : 0.f;
+      vb[p] = drawn ? v_output[3 * pid + 2] : 0.f;
       // T_final*ra*v_out_alpha - T_final*ra*(bg . v_out) = ra * K
-      if constexpr (RGBD) ve[p] = v_out_extra[pid];
-      K[p] = Tf * ((v_output_alpha ? v_output_alpha[pid] : 0.f) -
-                   (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p] + (RGBD ? bg_extra * ve[p] : 0.f)));
-      binf[p] = final_idx[pid];
+      if constexpr (RGBD) ve[p] = drawn ? v_out_extra[pid] : 0.f;
+      K[p] = !drawn ? 0.f
+                    : Tf * ((v_output_alpha ? v_output_alpha[pid] : 0.f) -
+                            (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p] + (RGBD ? bg_extra * ve[p] : 0.f)));
+      binf[p] = drawn ? final_idx[pid] : -1;
     }
   }
   // last sorted index any pixel of sub-tile p still needs (wave-uniform)

@@ -116,9 +116,16 @@ class GradientExchange:
     ``bytes_last`` holds the bytes exchanged by the last ``finish()``.
     """
 
-    def __init__(self, named_params, average: bool = True, group=None):
+    def __init__(self, named_params, average: bool = True, group=None, flat_small: bool = True):
         self.named = dict(named_params)
         self.average, self.group = average, group
+        # the small tensors (rows of <= 4 floats: means, scales, quats, opacities, features_dc = 56 of
+        # the 236 B per Gaussian) travel as ONE flat message, started when the last of them exists:
+        # five collectives less per step (their latency, not their bytes, is what they cost), at the
+        # price of one packing copy -- the reduced values are handed back as views of the flat buffer
+        self.flat_small = flat_small
+        self._flat_arrived = {}
+        self._flat_started = False
         self.active_rows = {}
         self.pending = []
         self.bytes_last = 0
@@ -150,7 +157,42 @@ class GradientExchange:
         self.named = dict(named_params)
         return self.attach()
 
+    def _is_small(self, name) -> bool:
+        p = self.named[name]
+        return self.flat_small and p.dim() >= 1 and p.shape[0] > 0 and p.numel() // p.shape[0] <= 4 \
+            and self.active_rows.get(name) is None
+
+    def _small_names(self):
+        return [k for k in self.named if self._is_small(k)]
+
+    def _start_flat(self) -> None:
+        names = self._small_names()
+        parts = []
+        for k in names:
+            p = self.named[k]
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            parts.append(p.grad.reshape(-1))
+        flat = torch.cat(parts)
+        op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
+        try:
+            work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        except (RuntimeError, ValueError):
+            if op != dist.ReduceOp.AVG:
+                raise
+            self._avg_in_collective = False
+            op = dist.ReduceOp.SUM
+            work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        self._bytes += flat.numel() * flat.element_size()
+        self.pending.append((work, flat, names, "flat", op))
+        self._flat_started = True
+
     def _start(self, name, p) -> None:
+        if self._is_small(name):
+            self._flat_arrived[name] = True
+            if not self._flat_started and all(self._flat_arrived.get(k) for k in self._small_names()):
+                self._start_flat()
+            return
         g = p.grad
         rows = self.active_rows.get(name)
         stage = None
@@ -195,29 +237,53 @@ class GradientExchange:
         tensors' collectives."""
         if not self.enabled:
             return 0
-        seen = {id(g) for _, _, g, _, _ in self.pending}
+        seen = {id(g) for _, _, g, rows, _ in self.pending if rows != "flat"}
         for name, p in self.named.items():
+            if self._is_small(name):
+                continue
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             if id(p.grad) not in seen and (self.active_rows.get(name) is None or self.active_rows[name] > 0):
                 self._start(name, p)
+        if not self._flat_started and self._small_names():
+            self._start_flat()  # some small parameter received no gradient on this rank: zeros
         for work, buf, g, rows, op in self.pending:
             work.wait()
             if self.average and op != dist.ReduceOp.AVG:
                 buf.div_(self._ws)
-            if rows is not None:
+            if rows == "flat":
+                off = 0
+                for k in g:  # the reduced gradients are views of the flat buffer: no unpacking copy
+                    q = self.named[k]
+                    q.grad = buf[off:off + q.numel()].view_as(q)
+                    off += q.numel()
+            elif rows is not None:
                 g[:, :rows].copy_(buf)
         self.pending = []
+        self._flat_arrived, self._flat_started = {}, False
         self.bytes_last, self._bytes = self._bytes, 0
         return self.bytes_last
 
 
+def single_process_vis_counts(vis_counts: torch.Tensor, first_visible: Optional[torch.Tensor], rank: int) -> None:
+    """`after_train` starts `vis_counts` at ONE for every Gaussian on its first call after a refinement,
+    visible or not, and adds 1 per visible view afterwards (vanilla_gs.py:354-359).  Every rank applies
+    that quirk to its own first view, so the plain sum over ranks is  world + (visible later views),
+    while ONE process seeing the same views -- rank 0's first, then the others' -- would hold
+    1 + (visible later views) + (visible first views of ranks >= 1).  In place, before the sum: a rank
+    >= 1 replaces its "1" by whether its first view really saw the Gaussian."""
+    if rank > 0 and first_visible is not None:
+        vis_counts += first_visible.to(vis_counts.dtype) - 1
+
+
 def allreduce_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tensor,
-                            max_2dsize: torch.Tensor, group=None) -> None:
+                            max_2dsize: torch.Tensor, group=None, first_visible: Optional[torch.Tensor] = None) -> None:
     """Keep the densification statistics (vanilla_gs.py:351-372) identical on
-    every rank: sum, sum, max.  In place."""
+    every rank AND equal to what one process seeing all ranks' views would hold: sum, sum (with
+    `single_process_vis_counts`), max.  In place."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
+    single_process_vis_counts(vis_counts, first_visible, dist.get_rank(group))
     packed = torch.stack([xys_grad_norm, vis_counts.to(xys_grad_norm.dtype)])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
     xys_grad_norm.copy_(packed[0])

@@ -461,6 +461,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             p_.grad = None
 
     phase_marks = []
+    first_pending, first_vis = True, None
     for step in range(start_step, cfg.iters):
         ph = None
         v = view_for_rank(step, rank, world, cfg.num_views)
@@ -534,6 +535,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                     xys_grad_norm += torch.where(visible, gnorm, torch.zeros_like(xys_grad_norm))
                     vis_counts += visible.to(torch.int32)
                     max_2dsize = torch.where(visible, torch.maximum(max_2dsize, size), max_2dsize)
+        if first_pending and world > 1 and rank > 0 and cfg.densify and step < rcfg.stop_split_at:
+            # which Gaussians this rank's FIRST view after a refinement really saw (parallel.single_process_vis_counts)
+            first_vis = (out["radii"] > 0).to(torch.int32)
+        first_pending = False
         stats_first = False
         if world > 1 and sharded is None:
             b = exchange.finish()
@@ -563,7 +568,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                 if use_fused:
                     xys_grad_norm, vis_counts, max_2dsize = fstats.as_tuple()
                 if world > 1 and branch == "densify":
-                    allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize)
+                    allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize, first_visible=first_vis)
                 old = {k: model.gauss[k] for k in PARAM_NAMES}
                 moments = {}
                 for o in optims.values():
@@ -593,6 +598,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                     sharded.bind({k: model.gauss[k] for k in PARAM_NAMES}, new_moments)
             # the statistics restart after every refinement_after past the warm-up (:491-493)
             stats_first = True
+            first_pending, first_vis = True, None
             if use_fused:
                 fstats.restart()
         if cfg.save_every and cfg.checkpoint_dir and step > 0 and step % cfg.save_every == 0 and rank == 0:
@@ -602,7 +608,6 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         if cfg.log_every and step % cfg.log_every == 0:
             losses.append(float(loss.detach()))
     if world > 1:
-        allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize)
         dist.barrier()
     if device.type == "cuda":
         torch.cuda.synchronize(device)

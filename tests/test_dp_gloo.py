@@ -182,3 +182,35 @@ def test_two_rank_hooked_exchange_skips_inactive_sh_bands():
         exp[:, :active] = 1.5
         assert torch.equal(f0, exp)
         assert torch.equal(u0, torch.zeros(n, 2))                 # no gradient anywhere: zeros, exchanged
+
+
+def test_vis_counts_merge_equals_one_process_seeing_all_views():
+    """`after_train`'s "starts at 1" quirk under data parallelism: the per-rank counts, adjusted by
+    `single_process_vis_counts` and summed, equal the counts of ONE process that saw rank 0's views,
+    then rank 1's, ... (vanilla_gs.py:354-359)."""
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness.parallel import single_process_vis_counts
+
+    g = torch.Generator().manual_seed(3)
+    n, world, views_per_rank = 50, 3, 4
+    visible = torch.rand(world, views_per_rank, n, generator=g) > 0.4
+    per_rank, firsts = [], []
+    for r in range(world):
+        c = torch.ones(n, dtype=torch.int32)               # first call: 1 for everybody
+        for v in range(1, views_per_rank):
+            c += visible[r, v].to(torch.int32)             # later calls: +1 where visible
+        per_rank.append(c)
+        firsts.append(visible[r, 0].to(torch.int32))
+    single = torch.ones(n, dtype=torch.int32)
+    for r in range(world):
+        for v in range(views_per_rank):
+            if r == 0 and v == 0:
+                continue
+            single += visible[r, v].to(torch.int32)
+    total = torch.zeros(n, dtype=torch.int32)
+    for r in range(world):
+        c = per_rank[r].clone()
+        single_process_vis_counts(c, firsts[r], r)
+        total += c
+    assert torch.equal(total, single)
+    assert not torch.equal(sum(per_rank), single)  # the plain sum is not

@@ -48,7 +48,7 @@ def stable_gaussians(amb_pixels, amb_gaussians, xys, radii, W, H):
 
 # share of the visible Gaussians of config 2 that are decision-stable, i.e. held to 1e-3 relative
 # elementwise: measured value minus 10 % (profiles/r03_config2_stable_fraction.json)
-STABLE_VISIBLE_FLOOR = 0.05
+STABLE_VISIBLE_FLOOR = 0.049  # measured 0.0547 (9 876 of 180 416 visible Gaussians), round 3
 
 
 def grad_close(mine, ref, abs_sum=None, name="", stable=None):

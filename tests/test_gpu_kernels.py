@@ -760,3 +760,46 @@ def test_deterministic_backward_is_bit_reproducible_and_equals_the_atomic_one(W,
     for x, y, z in zip(e1, e2, b):
         assert torch.equal(x, y)
         assert (x - z.view_as(x)).abs().max().item() <= 2e-5 * z.abs().max().item() + 1e-12
+
+
+@pytest.mark.parametrize("rgbd", [False, True])
+def test_nan_cotangents_at_undrawn_pixels_are_never_read(rgbd):
+    """The models' depth image is `where(alpha > 0, depth / alpha, max)` (vanilla_gs.py:855): its backward
+    hands 0/0 = NaN cotangents to exactly the pixels where nothing was drawn.  The reference's kernel
+    branches on `valid` and never reads them (backward.cu:133-303); neither may the select-based tile16
+    kernels: gradients with NaN there equal the gradients with 0 there, bit for bit (deterministic mode)."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 1500, 192, 128, 16
+    # a sparse scene: most pixels stay undrawn, and every tile with a splat has some of both kinds
+    d = raster_inputs(n, W, H, bw, {}, scale_lo=0.003, scale_hi=0.03)
+    depths = np.random.default_rng(3).uniform(1, 5, n).astype(np.float32)
+    ids, bins = cu(d["vs"]), cu(d["bins"])
+    args = (cu(d["xys"]), cu(d["conics"]), cu(d["colors"]))
+    opac, bg = cu(d["opac"]), cu(d["bg"])
+    if rgbd:
+        f = C.rasterize_forward_rgbd(d["tb"], (W, H, 1), ids, bins, *args, cu(depths), opac, bg, 0.0)
+        Ts, idx = f[2], f[3]
+    else:
+        f = C.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), ids, bins, *args, opac, bg)
+        Ts, idx = f[1], f[2]
+    undrawn = Ts == 1.0
+    assert 0.2 < undrawn.float().mean().item() < 0.98
+    g = torch.Generator(device=DEV).manual_seed(4)
+    v_img = torch.rand(H, W, 3, device=DEV, generator=g) * 2 - 1
+    v_alpha = torch.rand(H, W, device=DEV, generator=g) * 2 - 1
+    v_ext = torch.rand(H, W, device=DEV, generator=g) * 2 - 1
+
+    def run(fill):
+        vi, va, ve = v_img.clone(), v_alpha.clone(), v_ext.clone()
+        vi[undrawn], va[undrawn], ve[undrawn] = fill, fill, fill
+        if rgbd:
+            return C.rasterize_backward_rgbd(H, W, ids, bins, *args, cu(depths), opac, bg, 0.0, Ts, idx, vi, ve, va)
+        return C.rasterize_backward(H, W, bw, ids, bins, *args, opac, bg, Ts, idx, vi, va)
+
+    clean, poisoned = run(0.0), run(float("nan"))
+    for a, b in zip(clean, poisoned):
+        assert torch.isfinite(b).all()
+        scale = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale  # equal up to the order of the float atomics
+    assert sum(float(a.abs().sum()) for a in clean) > 0
