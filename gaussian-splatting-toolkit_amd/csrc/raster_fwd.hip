@@ -168,6 +168,127 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   }
 }
 
+// ------------------------------------------------------------- scan mapping
+// north_star's other mapping ("wave-64 prefix-scan for per-pixel transmittance"), built to be
+// MEASURED against the serial walk above: lanes run over the 64 staged
+// SPLATS, the wave takes the pixels of its 8x8 sub-tile one at a time.  Per (pixel, chunk): every
+// lane evaluates its splat's alpha at that pixel, a multiplicative DPP prefix scan of (1 - alpha)
+// gives every splat its transmittance, the termination rule becomes one ballot (T falls
+// monotonically, so "next_T <= 1e-4" holds for every hit behind the first one that fails), and
+// the colour is a wave-wide sum.  One workgroup per (tile, sub-tile); a pixel's state sits in the
+// lane of the same number.  Same staging, same sigma / alpha expressions as the serial kernel; T is
+// a tree-ordered product instead of a sequential one, so results agree to rounding, not bitwise.
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_WAVE_SHR1 0x138
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_or(float identity, float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(identity), __float_as_uint(v), CTRL, ROWMASK,
+                                                     0xf, false));
+}
+__device__ __forceinline__ float wave_prefix_product(float v) {  // inclusive
+  v *= dpp_or<DPP_ROW_SHR(1), 0xf>(1.f, v);
+  v *= dpp_or<DPP_ROW_SHR(2), 0xf>(1.f, v);
+  v *= dpp_or<DPP_ROW_SHR(4), 0xf>(1.f, v);
+  v *= dpp_or<DPP_ROW_SHR(8), 0xf>(1.f, v);
+  v *= dpp_or<DPP_ROW_BCAST15, 0xa>(1.f, v);
+  v *= dpp_or<DPP_ROW_BCAST31, 0xc>(1.f, v);
+  return v;
+}
+__device__ __forceinline__ float wave_total(float v) {  // the sum, valid in lane 63
+  v += dpp_or<DPP_ROW_SHR(1), 0xf>(0.f, v);
+  v += dpp_or<DPP_ROW_SHR(2), 0xf>(0.f, v);
+  v += dpp_or<DPP_ROW_SHR(4), 0xf>(0.f, v);
+  v += dpp_or<DPP_ROW_SHR(8), 0xf>(0.f, v);
+  v += dpp_or<DPP_ROW_BCAST15, 0xa>(0.f, v);
+  v += dpp_or<DPP_ROW_BCAST31, 0xc>(0.f, v);
+  return v;
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l));
+}
+
+__global__ __launch_bounds__(64) void raster_fwd_scan_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h,
+    const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
+    const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ background, float *__restrict__ out_img,
+    float *__restrict__ final_Ts, int *__restrict__ final_idx, const unsigned base_grid) {
+  __shared__ SplatA sA[kChunk];
+  __shared__ SplatB sB[kChunk];
+  __shared__ SplatC sC[kChunk];
+  const int p = blockIdx.x / base_grid;  // sub-tile; blocks b and b + k base_grid share an XCD
+  const int tile = gsr_xcd_remap(blockIdx.x % base_grid, tiles_x, num_tiles / tiles_x);
+  if (tile < 0) return;
+  const int2 range = tile_bins[tile];
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int lane = threadIdx.x;
+  const int sx0 = tx * 16 + 8 * (p & 1), sy0 = ty * 16 + 8 * (p >> 1);
+  const int col = sx0 + (lane & 7), row = sy0 + (lane >> 3);
+  const bool inside = col < img_w && row < img_h;
+  float T = inside ? 1.f : -1.f, cr = 0.f, cg = 0.f, cb = 0.f;
+  int last = 0;
+  unsigned long long live = __ballot(T > 0.f);
+  for (int base = range.x; base < range.y && live != 0; base += kChunk) {
+    const int sidx = base + lane;
+    const int count = stage_chunk(lane, sidx < range.y, sidx, (float)(tx * 16), (float)(ty * 16), ids_sorted, xys,
+                                  conics, colors, opacities, sA, sB, sC, nullptr, nullptr, nullptr, 1 << p);
+    __syncthreads();
+    const bool have = lane < count;
+    const SplatA A = sA[have ? lane : 0];
+    const SplatB B = sB[have ? lane : 0];
+    const SplatC C = sC[have ? lane : 0];
+    unsigned long long todo = count > 0 ? live : 0ull;
+    while (todo) {
+      const int q = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const float fx = (float)(sx0 + (q & 7)), fy = (float)(sy0 + (q >> 3));
+      const float Tq = lane_value(T, q);
+      const float dx = A.x - fx, dy = A.y - fy;
+      const float sigma = (A.ha * dx * dx + B.hc * dy * dy) + (A.b * dx) * dy;
+      const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
+      const bool hit = have && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+      const float incl = wave_prefix_product(hit ? 1.f - alpha : 1.f);
+      const float excl = dpp_or<DPP_WAVE_SHR1, 0xf>(1.f, incl);
+      const float Tb = Tq * excl, next_T = Tq * incl;
+      const bool go = next_T > GSR_T_EPS;
+      const bool draw = hit && go;
+      const float vis = draw ? alpha * Tb : 0.f;
+      const float sr = wave_total(B.r * vis), sg = wave_total(B.g * vis), sb = wave_total(C.blue * vis);
+      const unsigned long long fail = __ballot(hit && !go), drawn = __ballot(draw);
+      float newT;
+      if (fail) {  // the pixel is finished in front of the first hit that fails: keep T there, negated
+        newT = -lane_value(Tb, __builtin_ctzll(fail));
+        live &= ~(1ull << q);
+      } else {
+        newT = lane_value(next_T, 63);
+      }
+      const int lastq = drawn ? __builtin_amdgcn_readlane(C.sidx, 63 - __builtin_clzll(drawn)) : -1;
+      // (read lane 63 under the FULL exec mask: inside the one-lane branch below the compiler sinks the
+      //  reduction's last add into it, and lane 63's value is then never computed)
+      const float tr = lane_value(sr, 63), tg = lane_value(sg, 63), tbl = lane_value(sb, 63);
+      const bool mine = lane == q;
+      T = mine ? newT : T;
+      cr += mine ? tr : 0.f;
+      cg += mine ? tg : 0.f;
+      cb += mine ? tbl : 0.f;
+      last = (mine && lastq >= 0) ? lastq : last;
+    }
+    __syncthreads();
+  }
+  if (inside) {
+    const size_t pid = (size_t)row * img_w + col;
+    const float Tp = fabsf(T);
+    final_Ts[pid] = Tp;
+    final_idx[pid] = last;
+    out_img[3 * pid] = cr + Tp * background[0];
+    out_img[3 * pid + 1] = cg + Tp * background[1];
+    out_img[3 * pid + 2] = cb + Tp * background[2];
+  }
+}
+
 // ----------------------------------------------------------------- generic
 // One lane per pixel, bw*bw lanes per tile, batches of bw*bw splats in LDS.
 // `channels` (<= CMAX) of the `cstride` interleaved channels starting at the pointers given:
@@ -345,6 +466,26 @@ GSR_EXPORT int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block
                      out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base,
                      out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2));
   GSR_CHECK_LAUNCH("rasterize_forward(tile16)");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_rasterize_forward_scan(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
+                                          const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                                          const float *xys, const float *conics, const float *colors,
+                                          const float *opacities, const float *background, float *out_img,
+                                          float *final_Ts, int32_t *final_idx, gsr_stream_t stream) {
+  int rc = check_common("rasterize_forward_scan", tiles_x, tiles_y, 16, img_width, img_height, 3);
+  if (rc != GSR_OK) return rc;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background && out_img &&
+                  final_Ts && final_idx,
+              "rasterize_forward_scan: null pointer");
+  const int num_tiles = tiles_x * tiles_y;
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  hipLaunchKernelGGL(raster_fwd_scan_kernel, dim3(4 * base), dim3(64), 0, (hipStream_t)stream, tiles_x, num_tiles,
+                     (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
+                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, out_img, final_Ts,
+                     final_idx, base);
+  GSR_CHECK_LAUNCH("rasterize_forward_scan");
   return GSR_OK;
 }
 

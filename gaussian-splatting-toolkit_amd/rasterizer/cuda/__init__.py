@@ -468,6 +468,23 @@ def rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bi
                               conics, colors, opacities, background, nd=False)
 
 
+def rasterize_forward_scan(tile_bounds, img_size, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
+                           background):
+    """`rasterize_forward` through the scan mapping (``gsr_rasterize_forward_scan``; measurement variant,
+    16x16 tiles): lanes over splats, wave prefix product for the transmittance."""
+    _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
+    W, H = int(img_size[0]), int(img_size[1])
+    dev = xys.device
+    with torch.cuda.device(dev):
+        img = torch.empty((H, W, 3), dtype=_f32, device=dev)
+        Ts = torch.empty((H, W), dtype=_f32, device=dev)
+        idx = torch.empty((H, W), dtype=_i32, device=dev)
+        _call("gsr_rasterize_forward_scan", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(W), C.c_uint(H),
+              _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors), _ptr(opacities),
+              _ptr(background), _ptr(img), _ptr(Ts), _ptr(idx), _stream(dev))
+    return img, Ts, idx
+
+
 def nd_rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
                          colors, opacities, background):
     """Generic channel count; replaces ``nd_rasterize_forward_tensor``

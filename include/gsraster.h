@@ -241,6 +241,16 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
  * chip has drained.  Never changes a result (same per-pixel instruction sequence);
  * costs three idle workgroups per tile at launch.  A good value: 1.5x the mean list
  * length, not below 1024 (a split tile costs ~2x the instructions per list entry). */
+/* The other mapping of the same compositing rule (measurement variant, 16x16 tiles, 3 channels):
+ * lanes over the 64 staged splats, a wave-wide multiplicative prefix scan for the per-pixel
+ * transmittance, ballot termination (forward.cu:349-385 is the serial loop it re-maps).  Same
+ * outputs as gsr_rasterize_forward up to the rounding of T (a tree-ordered product). */
+int gsr_rasterize_forward_scan(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
+                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                               const float *xys, const float *conics, const float *colors,
+                               const float *opacities, const float *background, float *out_img,
+                               float *final_Ts, int32_t *final_idx, gsr_stream_t stream);
+
 int gsr_rasterize_forward(int tiles_x, int tiles_y, unsigned block_width,
                           unsigned img_width, unsigned img_height,
                           const int32_t *gaussian_ids_sorted,

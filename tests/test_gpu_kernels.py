@@ -803,3 +803,25 @@ def test_nan_cotangents_at_undrawn_pixels_are_never_read(rgbd):
         scale = a.abs().max().item()
         assert (a - b).abs().max().item() <= 2e-5 * scale  # equal up to the order of the float atomics
     assert sum(float(a.abs().sum()) for a in clean) > 0
+
+
+@pytest.mark.parametrize("n,W,H,ck,kw", [(10_000, 256, 256, {}, dict(scale_lo=0.005, scale_hi=0.05)),
+                                         (4_000, 200, 120, dict(yaw=0.2, pitch=-0.1), dict(scale_lo=0.02, scale_hi=0.3)),
+                                         (20_000, 97, 61, {}, dict(scale_lo=0.01, scale_hi=0.1))])
+def test_scan_mapping_forward_equals_the_serial_walk(n, W, H, ck, kw):
+    """north_star's "wave-64 prefix-scan for per-pixel transmittance" mapping (gsr_rasterize_forward_scan:
+    lanes over splats, DPP prefix product, ballot termination) against the oracle and the serial tile16
+    kernel: image / T 1e-4 abs on decision-stable pixels, final_idx exact there."""
+    import rasterizer.cuda as C
+
+    bw = 16
+    d = raster_inputs(n, W, H, bw, ck, **kw)
+    ref = O.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), d["vs"], d["bins"], d["xys"], d["conics"],
+                              d["colors"], d["opac"], d["bg"], ambig_eps=1e-5)
+    args = (cu(d["vs"]), cu(d["bins"]), cu(d["xys"]), cu(d["conics"]), cu(d["colors"]), cu(d["opac"]), cu(d["bg"]))
+    out, Ts, idx = C.rasterize_forward_scan(d["tb"], (W, H, 1), *args)
+    check_image(npy(out), npy(Ts), ref, ref[3])
+    ok = ~ref[3]
+    assert np.array_equal(npy(idx)[ok], ref[2][ok])
+    out2, Ts2, idx2 = C.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), *args)
+    assert (out - out2).abs()[cu(ok)].max().item() < 2e-6 and (Ts - Ts2).abs()[cu(ok)].max().item() < 2e-6
