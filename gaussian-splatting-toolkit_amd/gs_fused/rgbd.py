@@ -75,8 +75,7 @@ class _RasterizeRGBD(Function):
             bins = torch.zeros(0, 2, dtype=torch.int32, device=dev)
             acc, alpha_out[0] = None, None
         ctx.accumulators = acc
-        ctx.det = _R._bin_cache["value"][3] if (_R.is_deterministic() and num_intersects >= 1 and
-                                                _R._bin_cache["value"] is not None) else None
+        ctx.det = _R.last_list_aux() if (_R.is_deterministic() and num_intersects >= 1) else None
         ctx.set_materialize_grads(False)
         ctx.meta = (img_height, img_width, num_intersects, float(extra_background))
         ctx.save_for_backward(ids, bins, xys, conics, colors, extra, opacity, background, Ts, idx)

@@ -25,7 +25,25 @@ from torch.autograd import Function
 
 import rasterizer.cuda as _C
 
+# One entry, shared by every thread of the process.  Readers take a SNAPSHOT under `_state_lock`
+# and writers replace all four fields under it, so forwards interleaved on one device (an
+# evaluation thread next to the training thread, side streams) each see a consistent entry; what
+# a forward needs later (the deterministic backward's `aux`) travels with the call, in
+# thread-local storage, never through this dictionary.
 _bin_cache = {"key": None, "value": None, "keepalive": None, "reach": None}
+_state_lock = threading.Lock()  # guards the list cache and the sizing dictionaries below
+_tls = threading.local()
+
+
+def _cache_snapshot():
+    with _state_lock:
+        return dict(_bin_cache)
+
+
+def last_list_aux():
+    """(order, cum_sorted, slot_of_entry) of the lists the calling THREAD's last `build_tile_lists`
+    returned (deterministic mode; None otherwise)."""
+    return getattr(_tls, "aux", None)
 
 # Deterministic backward (include/gsraster.h, gsr_rasterize_backward_det): per-(tile, entry)
 # partials summed per Gaussian in a fixed order instead of float atomics -- bit-identical
@@ -35,7 +53,8 @@ _deterministic = {"on": os.environ.get("GSR_DETERMINISTIC", "0") not in ("", "0"
 
 def set_deterministic(flag: bool) -> None:
     _deterministic["on"] = bool(flag)
-    _bin_cache["key"] = None  # cached lists may lack the inverse map
+    with _state_lock:
+        _bin_cache["key"] = None  # cached lists may lack the inverse map
 
 
 def is_deterministic() -> bool:
@@ -58,7 +77,6 @@ def _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, bloc
 _count_hint = {}
 _last_capacity = {}
 _pinned_count = {}
-_state_lock = threading.Lock()  # guards the three dictionaries above and the list cache
 
 
 def _speculation_enabled() -> bool:
@@ -147,13 +165,13 @@ def _producer_signature(t):
     return (type(fn).__name__, id(v), v._version, v.data_ptr(), tuple(v.shape))
 
 
-def _same_reach_inputs(conics, opacity):
+def _same_reach_inputs(conics, opacity, reach):
     """Are `conics` / `opacity` the tensors the cached lists were built from?  True: the same
     storage at the same version, or produced by the same pure op from the same leaf (no
     device work, no sync).  "verify": same shapes but provenance unknown (e.g. a fresh
     `torch.sigmoid` under no_grad) -- the caller uses the cached lists speculatively and
     checks equality on the device, off the critical path.  False: rebuild."""
-    c0, o0, cv, ov, csig, osig = _bin_cache["reach"]
+    c0, o0, cv, ov, csig, osig = reach
     verdict = True
     for t, t0, v0, sig0 in ((conics, c0, cv, csig), (opacity, o0, ov, osig)):
         if t.shape != t0.shape:
@@ -239,21 +257,25 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     exact = block_width == 16
 
     def remember(num_intersects, ids, bins, aux=None):
-        _bin_cache["key"] = key
-        _bin_cache["value"] = (num_intersects, ids, bins, aux)
-        _bin_cache["keepalive"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
-        _bin_cache["reach"] = (conics.detach(), opacity.detach(), conics._version, opacity._version,
-                               _producer_signature(conics), _producer_signature(opacity))
+        entry = {"key": key, "value": (num_intersects, ids, bins, aux),
+                 "keepalive": tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit)),
+                 "reach": (conics.detach(), opacity.detach(), conics._version, opacity._version,
+                           _producer_signature(conics), _producer_signature(opacity))}
+        with _state_lock:
+            _bin_cache.update(entry)
+        _tls.aux = aux
 
-    if _bin_cache["key"] == key:
-        same = _same_reach_inputs(conics, opacity) if exact else True
-        cached = _bin_cache["value"]
+    snap = _cache_snapshot()
+    if snap["key"] == key:
+        same = _same_reach_inputs(conics, opacity, snap["reach"]) if exact else True
+        cached = snap["value"]
         if same is True:
+            _tls.aux = cached[3]
             return cached[:3] + (None,)
         if same == "verify" and cached[0] >= 1:
             # use the cached lists now; compare the values on the device and look at the
             # answer once the compositing is queued (no host wait in front of the GPU work)
-            c0, o0 = _bin_cache["reach"][:2]
+            c0, o0 = snap["reach"][:2]
             differ = ((conics != c0).any() | (opacity != o0).any()).to(torch.int32).reshape(1)
             check = _PendingCount(xys.device)
             _C.publish_int32(differ, check.buf)
@@ -261,6 +283,7 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
 
             def verify():
                 if not check.resolve():
+                    _tls.aux = cached[3]
                     return cached[:3] + (False,)
                 n, ids, bins, fin = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds,
                                                  block_width, exact, remember)
@@ -410,8 +433,7 @@ class _RasterizeGaussians(Function):
         ctx.img_width = img_width
         ctx.img_height = img_height
         # deterministic backward: (order, cum_sorted, slot_of_entry) of the lists just used
-        ctx.det = _bin_cache["value"][3] if (_deterministic["on"] and num_intersects >= 1 and
-                                             colors.shape[-1] == 3 and _bin_cache["value"] is not None) else None
+        ctx.det = last_list_aux() if (_deterministic["on"] and num_intersects >= 1 and colors.shape[-1] == 3) else None
         ctx.num_intersects = num_intersects
         ctx.block_width = block_width
         ctx.accumulators = acc  # cleared by the forward launch; used (once) by the backward

@@ -934,3 +934,58 @@ def test_gradcheck_central_differences_through_the_three_ops():
         return (img.double() * w_img).sum() + (alpha.double() * w_alpha).sum()
 
     _directional_check(f_all, [cu(means), cu(scales), cu(quats), cu(coeffs), opac], h=2e-3, tol=1e-3, tangent=(2,))
+
+
+def test_interleaved_forwards_from_two_threads_keep_their_own_lists():
+    """The one-entry list cache is shared by the process: an evaluation thread rendering next to the
+    training thread (the toolkit holds a `train_lock`; nothing in this package requires one) must
+    never hand its lists -- or the deterministic backward's inverse map -- to the other thread's
+    autograd node.  Two threads, two different scenes, deterministic mode: every gradient equals the
+    single-threaded one bit for bit."""
+    import threading
+
+    from rasterizer import project_gaussians, rasterize_gaussians
+    from rasterizer import rasterize as R
+
+    W, H = 208, 144
+    cam = S.make_camera(W, H)
+    camt = CameraTensors.from_numpy(cam, DEV)
+    scenes = [S.make_scene(n, cam, sh_degree=0, seed=sd, scale_lo=0.01, scale_hi=0.08) for n, sd in ((4000, 1), (2500, 2))]
+    v_img = cu(np.random.default_rng(0).uniform(-1, 1, (H, W, 3)).astype(np.float32))
+
+    def run(sc):
+        p = {k: cu(v, True) for k, v in sc.items() if k != "sh_coeffs"}
+        col = cu(np.ascontiguousarray(sc["sh_coeffs"][:, 0, :]) * 0.28 + 0.5)
+        xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
+            p["means3d"], p["scales"], 1.0, p["quats"], camt.viewmat, camt.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+            H, W, 16)
+        img = rasterize_gaussians(xys, depths, radii, conics, tiles, col, p["opacities"], H, W, 16,
+                                  cu(np.zeros(3, np.float32)))
+        img.backward(v_img)
+        torch.cuda.synchronize()
+        return [p[k].grad.clone() for k in ("means3d", "scales", "quats", "opacities")]
+
+    R.set_deterministic(True)
+    try:
+        want = [run(sc) for sc in scenes]
+        got, errors = [[], []], []
+
+        def worker(i):
+            try:
+                for _ in range(12):
+                    got[i].append(run(scenes[i]))
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errors, errors
+        for i in range(2):
+            for grads in got[i]:
+                for a, b in zip(grads, want[i]):
+                    assert torch.equal(a, b)
+    finally:
+        R.set_deterministic(False)
