@@ -195,8 +195,15 @@ def train_only(args):
     from harness.train import train
 
     cfg = config3(args.train_iters)
+    if args.train_small:  # tests only: the same code path on a scene that trains in seconds
+        from gs_fused import RefineConfig
+
+        cfg.num_gaussians, cfg.init_gaussians, cfg.width, cfg.height, cfg.num_views = 40_000, 8_000, 320, 180, 8
+        cfg.scene_objects, cfg.scene_scale, cfg.sh_degree_interval, cfg.phase_every = (12, 0.3, 0.6), (0.01, 0.03), 40, 10
+        cfg.refine = RefineConfig(warmup_length=30, refine_every=20, reset_alpha_every=6, stop_screen_size_at=200)
+        cfg.log_every = 10
     res = train(cfg, dev, rank, world)
-    res1m = train(fixed_1m(), dev, rank, world) if args.train_iters >= 1000 else None
+    res1m = train(fixed_1m(), dev, rank, world) if (args.train_iters >= 1000 and not args.train_small) else None
     if world > 1:
         cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
         lo, hi = cs.clone(), cs.clone()
@@ -254,7 +261,7 @@ def train_record(args, world):
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                         "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "GROUP_WORLD_SIZE") and not k.startswith("TORCHELASTIC")}
     cmd = [sys.executable, os.path.abspath(__file__), "--train-only", "--gpus", str(world), "--train-iters",
-           str(args.train_iters), "--backend", args.backend]
+           str(args.train_iters), "--backend", args.backend] + (["--train-small"] if args.train_small else [])
     t0 = time.perf_counter()
     try:
         out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=args.train_timeout)
@@ -399,6 +406,7 @@ def main():
                     help="iterations of the config-3 training record (BASELINE metric, second half); 0: skip it")
     ap.add_argument("--train-timeout", type=int, default=900)
     ap.add_argument("--train-only", action="store_true", help="run only the config-3 training leg and print its record")
+    ap.add_argument("--train-small", action="store_true", help=argparse.SUPPRESS)  # tests: a scene that trains in seconds
     args = ap.parse_args()
 
     if not torch.cuda.is_available():

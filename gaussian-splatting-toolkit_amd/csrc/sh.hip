@@ -17,6 +17,8 @@
 // write-bound at 2.2-2.4 TB/s either way.
 #include "gsr_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 #define C0 0.28209479177387814f
@@ -104,12 +106,15 @@ __device__ __forceinline__ void sh_basis(unsigned deg, float dx, float dy, float
 // Gaussians (576 MB): forward 4.36 -> 5.18 TB/s, backward 2.2 -> 5.4 TB/s.
 constexpr int kShRow = 13;  // float4 per Gaussian row in LDS (12 + 1 padding)
 
-__global__ __launch_bounds__(256) void sh16_fwd_kernel(
+// WAVES per workgroup: the waves never talk to each other (each transposes its own 64 rows), so the
+// workgroup size only sets the LDS granule of the scheduler: 13 KB per wave.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sh16_fwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
     const float4 *__restrict__ coeffs, float *__restrict__ colors) {
-  __shared__ float4 lds[4][64 * kShRow];
+  __shared__ float4 lds[WAVES][64 * kShRow];
   const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned g0 = (blockIdx.x * 4 + w) * 64;  // first Gaussian of this wave
+  const unsigned g0 = (blockIdx.x * WAVES + w) * 64;  // first Gaussian of this wave
   const unsigned navail = g0 < n ? (n - g0 < 64 ? n - g0 : 64) * 12 : 0;
   const float4 *src = coeffs + (size_t)g0 * 12;
   float4 q[12];
@@ -151,12 +156,13 @@ __global__ __launch_bounds__(256) void sh16_fwd_kernel(
   colors[3 * g + 2] = b;
 }
 
-__global__ __launch_bounds__(256) void sh16_bwd_kernel(
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sh16_bwd_kernel(
     const unsigned n, const unsigned deg_use, const float *__restrict__ viewdirs,
     const float *__restrict__ v_colors, float4 *__restrict__ v_coeffs) {
-  __shared__ float4 lds[4][64 * kShRow];
+  __shared__ float4 lds[WAVES][64 * kShRow];
   const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const unsigned g0 = (blockIdx.x * 4 + w) * 64;
+  const unsigned g0 = (blockIdx.x * WAVES + w) * 64;
   const unsigned g = g0 + lane;
   if (g < n) {
     float B[16];
@@ -440,6 +446,16 @@ GSR_EXPORT int gsr_sh_backward_split(unsigned num_points, unsigned degree, unsig
   return GSR_OK;
 }
 
+// A/B knob: waves per workgroup of the K = 16 kernels (GSR_SH_WAVES = 1 / 2 / 4)
+static int sh16_waves() {
+  static const int v = [] {
+    const char *e = getenv("GSR_SH_WAVES");
+    const int w = e ? atoi(e) : 4;
+    return (w == 1 || w == 2) ? w : 4;
+  }();
+  return v;
+}
+
 GSR_EXPORT int gsr_sh_forward(unsigned num_points, unsigned degree, unsigned degrees_to_use,
                               const float *viewdirs, const float *coeffs, float *colors,
                               gsr_stream_t stream) {
@@ -454,10 +470,18 @@ GSR_EXPORT int gsr_sh_forward(unsigned num_points, unsigned degree, unsigned deg
     case 1: hipLaunchKernelGGL(sh_fwd_kernel<4>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors); break;
     case 2: hipLaunchKernelGGL(sh_fwd_kernel<9>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors); break;
     case 3:
-      if (aligned16(coeffs))
-        hipLaunchKernelGGL(sh16_fwd_kernel, grd, blk, 0, s, num_points, degrees_to_use, viewdirs,
-                           reinterpret_cast<const float4 *>(coeffs), colors);
-      else
+      if (aligned16(coeffs)) {
+        const int wv = sh16_waves();
+        if (wv == 1)
+          hipLaunchKernelGGL(sh16_fwd_kernel<1>, dim3(gsr_cdiv(num_points, 64)), dim3(64), 0, s, num_points,
+                             degrees_to_use, viewdirs, reinterpret_cast<const float4 *>(coeffs), colors);
+        else if (wv == 2)
+          hipLaunchKernelGGL(sh16_fwd_kernel<2>, dim3(gsr_cdiv(num_points, 128)), dim3(128), 0, s, num_points,
+                             degrees_to_use, viewdirs, reinterpret_cast<const float4 *>(coeffs), colors);
+        else
+          hipLaunchKernelGGL(sh16_fwd_kernel<4>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs,
+                             reinterpret_cast<const float4 *>(coeffs), colors);
+      } else
         hipLaunchKernelGGL(sh_fwd_kernel<16>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors);
       break;
     default: hipLaunchKernelGGL(sh_fwd_kernel<25>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, coeffs, colors); break;
@@ -480,10 +504,18 @@ GSR_EXPORT int gsr_sh_backward(unsigned num_points, unsigned degree, unsigned de
     case 1: hipLaunchKernelGGL(sh_bwd_kernel<4>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs); break;
     case 2: hipLaunchKernelGGL(sh_bwd_kernel<9>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs); break;
     case 3:
-      if (aligned16(v_coeffs))
-        hipLaunchKernelGGL(sh16_bwd_kernel, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors,
-                           reinterpret_cast<float4 *>(v_coeffs));
-      else
+      if (aligned16(v_coeffs)) {
+        const int wv = sh16_waves();
+        if (wv == 1)
+          hipLaunchKernelGGL(sh16_bwd_kernel<1>, dim3(gsr_cdiv(num_points, 64)), dim3(64), 0, s, num_points,
+                             degrees_to_use, viewdirs, v_colors, reinterpret_cast<float4 *>(v_coeffs));
+        else if (wv == 2)
+          hipLaunchKernelGGL(sh16_bwd_kernel<2>, dim3(gsr_cdiv(num_points, 128)), dim3(128), 0, s, num_points,
+                             degrees_to_use, viewdirs, v_colors, reinterpret_cast<float4 *>(v_coeffs));
+        else
+          hipLaunchKernelGGL(sh16_bwd_kernel<4>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors,
+                             reinterpret_cast<float4 *>(v_coeffs));
+      } else
         hipLaunchKernelGGL(sh_bwd_kernel<16>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs);
       break;
     default: hipLaunchKernelGGL(sh_bwd_kernel<25>, grd, blk, 0, s, num_points, degrees_to_use, viewdirs, v_colors, v_coeffs); break;

@@ -67,3 +67,28 @@ def test_the_drivers_torchrun_form():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0
+
+
+def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks():
+    """The second half of BASELINE's metric: `train` in the ONE JSON line, produced by a fresh process (its own
+    process group) after the raster timing -- at N = 1, and at N = 2 self-spawned twice over (the bench's ranks,
+    then the training leg's).  `--train-small` swaps config 3's scene for one that trains in seconds; the code
+    path is the same."""
+    d = _run(["--no-cpu-baseline"])
+    assert d["train"] is None  # SMALL carries --train-iters 0
+    base = [a for a in SMALL if a not in ("--train-iters", "0")]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for extra in ([], ["--gpus", "2", "--backend", "gloo"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base + extra +
+                             ["--train-small", "--train-iters", "160", "--no-cpu-baseline"], capture_output=True,
+                             text=True, timeout=900, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        t = json.loads(lines[0])["train"]
+        assert t and "error" not in t, t
+        assert t["iters"] == 160 and t["iters_per_s"] > 0 and t["n_gpus"] == (2 if extra else 1)
+        assert t["gaussians"]["start"] == 8000 and t["refinements"] >= 2
+        assert t["psnr"]["end"] > t["psnr"]["start"] + 2.0, t
+        if extra:
+            assert t["replicas_identical"] is True and t["allreduce_bytes_step_bytes"], t

@@ -21,7 +21,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, mode="plain"):
     import torch.distributed as dist
 
     for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd")):
@@ -37,10 +37,17 @@ def _run(rank, world, port, q):
     rcfg = RefineConfig(warmup_length=30, refine_every=15, reset_alpha_every=4, stop_screen_size_at=120,
                         stop_split_at=150, densify_grad_thresh=0.0004)
     cfg = HT.TrainConfig(num_gaussians=12_000, init_gaussians=3_000, width=256, height=160, num_views=6, iters=140,
-                         sh_degree=2, sh_degree_interval=40, eval_views=2, densify=True, refine=rcfg)
+                         sh_degree=2, sh_degree_interval=40, eval_views=2, densify=True, refine=rcfg, log_every=10)
+    if mode in ("det", "det+sharded"):
+        from rasterizer import rasterize as R
+
+        R.set_deterministic(True)  # bit-reproducible compositing backward: runs become comparable bit for bit
+        cfg.sharded_adam = mode == "det+sharded"
+    if mode == "graph":
+        cfg.use_graph = True
     res = HT.train(cfg, torch.device("cuda", 0), rank, world)
     q.put((rank, res["param_checksum"], res["num_gaussians_start"], res["num_gaussians_end"], res["refinements"],
-           res["psnr_start"], res["psnr_end"], res["allreduce_bytes"][:3]))
+           res["psnr_start"], res["psnr_end"], res["allreduce_bytes"][:3], res["losses"], res["update"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,3 +71,44 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas_through_refinement():
     assert a[1] == b[1] and math.isfinite(a[1]), (a[1], b[1])  # bit-identical parameters
     assert math.isfinite(a[5]) and math.isfinite(a[6])      # (an opacity reset sits right before the end: no PSNR claim)
     assert a[7] and all((x[-1] if isinstance(x, (tuple, list)) else x) > 0 for x in a[7])  # gradients were exchanged
+
+
+def _launch(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+@pytest.mark.timeout(900)
+def test_sharded_adam_equals_the_all_reduce_path_bit_for_bit_on_the_hip_path():
+    """reduce-scatter -> FusedAdam on this rank's rows -> all-gather (parallel.ShardedAdam) against all-reduce +
+    FusedAdam over every row, both with the deterministic compositing backward so that two runs are
+    comparable: same refinement history, bit-identical parameters (two ranks: (a + b) / 2 is the same number
+    whichever collective forms it; Adam is element-wise)."""
+    plain, shard = _launch("det"), _launch("det+sharded")
+    assert plain[0][1] == plain[1][1] and shard[0][1] == shard[1][1]
+    assert shard[0][9].startswith("reduce-scatter") and plain[0][9].startswith("all-reduce")
+    assert plain[0][4] == shard[0][4] and len(plain[0][4]) >= 3, (plain[0][4], shard[0][4])
+    assert plain[0][1] == shard[0][1], (plain[0][1], shard[0][1])
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_graph_replay_exchanges_each_gradient_once():
+    """HIP-graph replay under data parallelism: no hook may fire during the warm-up
+    backwards or be captured into the graph -- the exchange is started after the replay, once.  Replicas stay
+    identical, and the loss falls like the eager run's (gradients reduced twice, or summed and never divided,
+    would double the step)."""
+    eager, graph = _launch("plain"), _launch("graph")
+    assert graph[0][1] == graph[1][1] and math.isfinite(graph[0][1])
+    assert graph[0][4] and [s_ for s_, _ in graph[0][4]] == [s_ for s_, _ in eager[0][4]]
+    le, lg = eager[0][8], graph[0][8]
+    assert lg[-1] < 0.8 * lg[0]
+    assert abs(lg[3] - le[3]) < 0.15 * le[3] and abs(lg[-1] - le[-1]) < 0.25 * le[-1], (le, lg)
