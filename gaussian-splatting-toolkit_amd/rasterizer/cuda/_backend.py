@@ -52,6 +52,7 @@ SYMBOLS = (
     "gsr_sh_forward_split",
     "gsr_sh_backward_split",
     "gsr_rasterize_forward_rgbd",
+    "gsr_rasterize_forward_scan",
     "gsr_rasterize_backward_rgbd",
     "gsr_activate_forward",
     "gsr_activate_backward",
