@@ -618,8 +618,10 @@ def main():
                 if fs is not None and ws is not None:
                     stage_traffic[st] = to_bytes(fs, ws)  # all launches of the stage, per step
             q = pmc_pass(["SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], sub)
-            qi, _ = pmc_stage(q, dominant, "SQ_INSTS_VALU", sub_steps)
-            qa, _ = pmc_stage(q, dominant, "GRBM_GUI_ACTIVE", sub_steps)
+            # both counters over ALL launches of the stage (a two-pass step launches the kernel twice with
+            # different work): instructions and resident cycles of the same set of launches
+            _, qi = pmc_stage(q, dominant, "SQ_INSTS_VALU", 1)
+            _, qa = pmc_stage(q, dominant, "GRBM_GUI_ACTIVE", 1)
             if qi is not None and qa:
                 # the compositing kernels are VALU-issue bound, not HBM bound:
                 # wave64 VALU instructions x 4 cycles / SIMD-cycles the kernel was resident

@@ -391,14 +391,42 @@ __global__ __launch_bounds__(256) void sh_split_bwd_kernel(
   split_rows_from_lds<K, VEC>(v_rest + (size_t)g0 * R, cnt, lane, lds[w]);
 }
 
+// degree 0 (K = 1, `rest` is [n, 0, 3]): colours = C0 dc + shift, same -0.0 marking of clamped channels
+__global__ __launch_bounds__(256) void sh_dc_fwd_kernel(const unsigned n3, const float *__restrict__ dc,
+                                                        float *__restrict__ colors, const float shift,
+                                                        const int clamp_zero) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n3) return;
+  // product and sum rounded separately, like the degree-0 kernel followed by the models' `+ 0.5`
+  float v = __fadd_rn(__fmul_rn(C0, dc[i]), shift);
+  if (clamp_zero) v = v < 0.f ? -0.f : v + 0.f;
+  colors[i] = v;
+}
+__global__ __launch_bounds__(256) void sh_dc_bwd_kernel(const unsigned n3, const float *__restrict__ v_colors,
+                                                        const float *__restrict__ clamped_colors,
+                                                        float *__restrict__ v_dc) {
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n3) return;
+  const bool cut = clamped_colors && __float_as_uint(clamped_colors[i]) == 0x80000000u;
+  v_dc[i] = cut ? 0.f : C0 * v_colors[i];
+}
+
 GSR_EXPORT int gsr_sh_forward_split(unsigned num_points, unsigned degree, unsigned degrees_to_use,
                                     const float *viewdirs, const float *dc, const float *rest,
                                     float *colors, float shift, int clamp_zero, gsr_stream_t stream) {
-  GSR_REQUIRE(degree >= 1 && degree <= 3, "sh_forward_split: degree must be in [1,3]");
+  GSR_REQUIRE(degree <= 3, "sh_forward_split: degree must be in [0,3]");
   GSR_REQUIRE(degrees_to_use <= degree, "sh_forward_split: degrees_to_use > degree");
   if (num_points == 0) return GSR_OK;
-  GSR_REQUIRE(viewdirs && dc && rest && colors, "sh_forward_split: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (degree == 0) {  // the DC band only: no direction, no `rest`
+    GSR_REQUIRE(dc && colors, "sh_forward_split: null pointer");
+    GSR_REQUIRE(num_points < (1u << 30), "sh_forward_split: too many points");
+    hipLaunchKernelGGL(sh_dc_fwd_kernel, dim3(gsr_cdiv(3 * num_points, 256)), dim3(256), 0, s, 3 * num_points, dc,
+                       colors, shift, clamp_zero);
+    GSR_CHECK_LAUNCH("sh_forward_split");
+    return GSR_OK;
+  }
+  GSR_REQUIRE(viewdirs && dc && rest && colors, "sh_forward_split: null pointer");
   const dim3 blk(256), grd(gsr_cdiv(num_points, 256));
   const bool vec = aligned16(rest);
 #define GSR_SPLIT_FWD(KK)                                                                                  \
@@ -422,11 +450,19 @@ GSR_EXPORT int gsr_sh_backward_split(unsigned num_points, unsigned degree, unsig
                                      const float *viewdirs, const float *v_colors,
                                      const float *clamped_colors, float *v_dc, float *v_rest,
                                      gsr_stream_t stream) {
-  GSR_REQUIRE(degree >= 1 && degree <= 3, "sh_backward_split: degree must be in [1,3]");
+  GSR_REQUIRE(degree <= 3, "sh_backward_split: degree must be in [0,3]");
   GSR_REQUIRE(degrees_to_use <= degree, "sh_backward_split: degrees_to_use > degree");
   if (num_points == 0) return GSR_OK;
-  GSR_REQUIRE(viewdirs && v_colors && v_dc && v_rest, "sh_backward_split: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (degree == 0) {
+    GSR_REQUIRE(v_colors && v_dc, "sh_backward_split: null pointer");
+    GSR_REQUIRE(num_points < (1u << 30), "sh_backward_split: too many points");
+    hipLaunchKernelGGL(sh_dc_bwd_kernel, dim3(gsr_cdiv(3 * num_points, 256)), dim3(256), 0, s, 3 * num_points,
+                       v_colors, clamped_colors, v_dc);
+    GSR_CHECK_LAUNCH("sh_backward_split");
+    return GSR_OK;
+  }
+  GSR_REQUIRE(viewdirs && v_colors && v_dc && v_rest, "sh_backward_split: null pointer");
   const dim3 blk(256), grd(gsr_cdiv(num_points, 256));
   const bool vec = aligned16(v_rest);
 #define GSR_SPLIT_BWD(KK)                                                                                  \

@@ -20,7 +20,7 @@ caller's job: `ListCapacity` below keeps a running estimate and checks the real 
 view later), which makes the whole view -- forward, loss, backward -- capturable in a HIP
 graph (`ViewGraph`).  Same values as the separate ops (tests/test_gpu_render.py): images
 bit-identical, gradients equal up to the order of the float atomics.
-fp32 CUDA tensors; 16x16 tiles; SH degree 1-3 storage (K = 4, 9, 16).
+fp32 CUDA tensors; 16x16 tiles; SH degree 0-3 storage (K = 1, 4, 9, 16).
 """
 import ctypes as C
 from dataclasses import dataclass, field
@@ -85,7 +85,7 @@ class _Render(Function):
         dev = means.device
         H, W = spec.height, spec.width
         tb = spec.tile_bounds
-        degree = {4: 1, 9: 2, 16: 3}[features_rest.shape[1] + 1]
+        degree = {1: 0, 4: 1, 9: 2, 16: 3}[features_rest.shape[1] + 1]
         with torch.cuda.device(dev):
             scales = torch.empty_like(log_scales)
             quats = torch.empty_like(raw_quats)
@@ -190,8 +190,8 @@ def render_gaussians(means: Tensor, log_scales: Tensor, raw_quats: Tensor, opaci
     the result is incomplete: render again with a larger capacity (`ListCapacity`).
     ``count_out`` may be a caller-owned int32[1] (device, or pinned host memory)."""
     n = means.shape[0]
-    if features_dc.shape != (n, 3) or features_rest.dim() != 3 or features_rest.shape[1] + 1 not in (4, 9, 16):
-        raise ValueError("features_dc [N,3] and features_rest [N,K-1,3] with K in (4, 9, 16) expected")
+    if features_dc.shape != (n, 3) or features_rest.dim() != 3 or features_rest.shape[1] + 1 not in (1, 4, 9, 16):
+        raise ValueError("features_dc [N,3] and features_rest [N,K-1,3] with K in (1, 4, 9, 16) expected")
     if log_scales.shape != (n, 3) or raw_quats.shape != (n, 4) or opacity_logits.numel() != n:
         raise ValueError("expected scales [N,3], quats [N,4], opacities [N,1]")
     if capacity < 1:

@@ -433,7 +433,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         dist.barrier()
     t0 = time.perf_counter()
     use_fused = (cfg.fused_render or cfg.use_graph) and device.type == "cuda" and cfg.split_sh and cfg.fused_loss \
-        and cfg.sh_degree in (1, 2, 3)
+        and cfg.sh_degree in (0, 1, 2, 3)
     fstats = caps = vgraph = vkey = None
     generation = 0
     overflow_views = 0

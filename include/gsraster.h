@@ -388,8 +388,8 @@ int gsr_depth_l1_backward(long long num_pixels, const float *upstream,
  * higher bands as two parameters (features_dc [n,3], features_rest [n,K-1,3])
  * and torch.cat them before every render (gs_toolkit/models/vanilla_gs.py:809,
  * `colors_crop = torch.cat(...)`): no concatenated copy is made, the gradients
- * are written straight into v_dc [n,3] and v_rest [n,K-1,3].  degree in [1,3]
- * (K = (degree+1)^2).  Optional epilogue of the models (vanilla_gs.py:826,
+ * are written straight into v_dc [n,3] and v_rest [n,K-1,3].  degree in [0,3]
+ * (K = (degree+1)^2; degree 0: the DC band only, viewdirs / rest / v_rest may be NULL).  Optional epilogue of the models (vanilla_gs.py:826,
  * `torch.clamp(rgbs + 0.5, min=0.0)`): colors = sh + shift, cut at 0 when
  * clamp_zero != 0 -- a channel that was cut is stored as -0.0, so that the backward,
  * which takes those colours (clamped_colors, NULL if not clamped), blocks the gradient

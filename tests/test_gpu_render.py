@@ -13,7 +13,7 @@ DEV = "cuda:0"
 def _model(n, K, seed):
     from harness.train import blob_scene
 
-    raw = blob_scene(n, seed=seed, sh_degree={4: 1, 9: 2, 16: 3}[K])
+    raw = blob_scene(n, seed=seed, sh_degree={1: 0, 4: 1, 9: 2, 16: 3}[K])
     return {k: torch.from_numpy(v).to(DEV).requires_grad_(True) for k, v in raw.items()}
 
 
@@ -35,7 +35,8 @@ def _separate_ops(p, cam, bg, deg, render_depth):
                        fused_depth=True)
 
 
-@pytest.mark.parametrize("K,deg,render_depth", [(16, 3, False), (16, 1, True), (4, 1, False), (9, 2, True)])
+@pytest.mark.parametrize("K,deg,render_depth", [(16, 3, False), (16, 1, True), (4, 1, False), (9, 2, True),
+                                                  (1, 0, False), (1, 0, True)])  # K = 1: BASELINE config 1 (SH degree 0)
 def test_render_gaussians_equals_the_separate_ops(K, deg, render_depth):
     from gs_fused import DensifyStats, ViewSpec, densify_stats_, render_gaussians
 

@@ -3,7 +3,7 @@
 # -> gpurun_out/bench_<tag>_*.json (copy the ones to keep into profiles/).  The default line
 # runs first and in full (PMC passes + CPU baseline); the others skip both.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -21,13 +21,14 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
 }
-Q="--no-pmc --no-cpu-baseline"
+Q="--no-pmc --no-cpu-baseline --train-iters 0"
+P="--no-cpu-baseline --train-iters 0"   # with the counter passes (roofline.traffic, per-stage traffic)
 DENSE="--scale-lo 0.005 --scale-hi 0.05"
 run default
 run dense $Q $DENSE
 run config1 $Q $DENSE --gaussians 10000 --width 256 --height 256 --sh-degree 0
 run config2 $Q $DENSE --gaussians 200000
-run config5 $Q $DENSE --gaussians 3000000 --width 3840 --height 2160 --render-depth --steps 20 --warmup 5
-run config5_fused_depth $Q $DENSE --gaussians 3000000 --width 3840 --height 2160 --render-depth --fused-depth --steps 20 --warmup 5
+run config5 $P $DENSE --gaussians 3000000 --width 3840 --height 2160 --render-depth --steps 20 --warmup 5
+run config5_fused_depth $P $DENSE --gaussians 3000000 --width 3840 --height 2160 --render-depth --fused-depth --steps 20 --warmup 5
 run longtail $Q --scene longtail
 run deterministic $Q --deterministic

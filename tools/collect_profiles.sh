@@ -7,12 +7,12 @@
 #    MI355X_MICROARCH.md HBM section)
 # PMC passes never combine with other trace domains (only --kernel-trace).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --event-every 0"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-pmc --train-iters 0 --event-every 0"
 
 rm -rf /tmp/prof_kt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $BENCH --steps 25 --warmup 5 > "$OUT/prof_kt.log" 2>&1
