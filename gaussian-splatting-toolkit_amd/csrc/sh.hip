@@ -395,10 +395,13 @@ __global__ __launch_bounds__(256) void sh_split_bwd_kernel(
 __global__ __launch_bounds__(256) void sh_dc_fwd_kernel(const unsigned n3, const float *__restrict__ dc,
                                                         float *__restrict__ colors, const float shift,
                                                         const int clamp_zero) {
+  // product and sum rounded separately, like the degree-0 kernel followed by the models' `+ 0.5`
+  // (HIP's __fmul_rn / __fadd_rn are plain operators the compiler may still contract: the pragma is what holds)
+#pragma clang fp contract(off)
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n3) return;
-  // product and sum rounded separately, like the degree-0 kernel followed by the models' `+ 0.5`
-  float v = __fadd_rn(__fmul_rn(C0, dc[i]), shift);
+  float v = C0 * dc[i];
+  v = v + shift;
   if (clamp_zero) v = v < 0.f ? -0.f : v + 0.f;
   colors[i] = v;
 }

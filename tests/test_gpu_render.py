@@ -72,6 +72,9 @@ def test_render_gaussians_equals_the_separate_ops(K, deg, render_depth):
     torch.autograd.backward([out["rgb"], out["alpha"]], [v_img, v_alpha])
     for k in pa:
         a, b = pa[k].grad, pb[k].grad
+        if a.numel() == 0:  # features_rest of an SH-degree-0 model is [N, 0, 3]
+            assert b.shape == a.shape
+            continue
         assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-12, k
     for a, b in zip(stats_ref.as_tuple(), stats.as_tuple()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-9)
