@@ -1,0 +1,92 @@
+// view.hip -- a whole view as ONE call into the library (forward) and one more (backward).
+//
+// gs_fused.render_gaussians chains the native calls of a view -- activations, projection, SH
+// (+0.5, clamp), reach records, depth order, device-sized tile lists, compositing; and back --
+// from Python: ~12 + ~6 ctypes calls of 8-10 us of host time each.  On a small scene (BASELINE
+// config 1: 10 k Gaussians at 256 x 256) or a forward-only viewer frame the GPU work is shorter
+// than that.  These two entry points run the same sequence of the same exported functions from C:
+// the caller allocates every buffer (no allocation in here, as everywhere in this library), fills
+// one descriptor and makes one call.  What they replace on the reference's side is the body of
+// GaussianSplattingModel.get_outputs between the raw parameters and the images
+// (gs_toolkit/models/vanilla_gs.py:765-857) and its autograd backward.
+#include "gsr_common.h"
+
+namespace {
+#define GSR_TRY(expr)          \
+  do {                         \
+    const int rc_ = (expr);    \
+    if (rc_ != GSR_OK) return rc_; \
+  } while (0)
+}  // namespace
+
+GSR_EXPORT int gsr_view_forward(const gsr_view_desc *v, gsr_stream_t stream) {
+  GSR_REQUIRE(v != nullptr, "view_forward: null descriptor");
+  const int n = v->num_points;
+  GSR_REQUIRE(n >= 0 && v->capacity >= 1, "view_forward: bad sizes");
+  GSR_REQUIRE(v->sh_degree >= 0 && v->sh_degree <= 3 && v->sh_degree_to_use <= v->sh_degree, "view_forward: SH degree");
+  const int tiles_x = (v->img_width + 15) / 16, tiles_y = (v->img_height + 15) / 16;
+  GSR_TRY(gsr_activate_forward(n, v->means, v->log_scales, v->raw_quats, v->logits, v->campos, v->scales, v->quats,
+                               v->opac, v->dirs, stream));
+  GSR_TRY(gsr_project_forward(n, v->means, v->scales, v->glob_scale, v->quats, v->viewmat, v->projmat, v->fx, v->fy,
+                              v->cx, v->cy, (unsigned)v->img_height, (unsigned)v->img_width, 16, v->clip_thresh,
+                              v->cov3d, v->xys, v->depths, v->radii, v->conics, v->comp, v->tiles, stream));
+  GSR_TRY(gsr_sh_forward_split((unsigned)n, (unsigned)v->sh_degree, (unsigned)v->sh_degree_to_use, v->dirs,
+                               v->features_dc, v->features_rest, v->colors, 0.5f, 1, stream));
+  // lists: with counts (short lists: single-pass scatter) or without (two-level partition), as the caller
+  // decided with gsr_bin_sorted_needs_counts when it sized the buffers
+  GSR_TRY(gsr_count_reach(n, v->xys, v->radii, v->conics, v->opac, tiles_x, tiles_y, 1, v->counts, v->reach_records,
+                          stream));
+  GSR_TRY(gsr_depth_order(n, v->depths, v->radii, v->counts, 1, v->order, v->counts ? v->cum : nullptr, v->sort_ws,
+                          v->sort_ws_bytes, stream));
+  GSR_TRY(gsr_bin_sorted_dev(n, v->capacity, v->order, v->counts ? v->cum : nullptr, v->xys, v->radii,
+                             v->reach_records, tiles_x, tiles_y, 16, 1, v->ids, v->tile_bins, v->count_out, nullptr,
+                             v->bin_ws, v->bin_ws_bytes, stream));
+  if (v->render_depth) {
+    GSR_REQUIRE(v->out_depth != nullptr, "view_forward: render_depth without out_depth");
+    GSR_TRY(gsr_rasterize_forward_rgbd(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
+                                       v->tile_bins, v->xys, v->conics, v->colors, v->depths, v->opac, v->background,
+                                       0.f, v->out_img, v->out_depth, v->final_Ts, v->final_idx,
+                                       v->deep_tile_threshold, v->out_alpha, v->zero_ptr, v->zero_bytes, stream));
+  } else {
+    GSR_TRY(gsr_rasterize_forward_ex(tiles_x, tiles_y, 16, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
+                                     v->tile_bins, v->xys, v->conics, v->colors, v->opac, v->background, v->out_img,
+                                     v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
+                                     v->zero_bytes, stream));
+  }
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_view_backward(const gsr_view_desc *v, const gsr_view_grads *g, gsr_stream_t stream) {
+  GSR_REQUIRE(v != nullptr && g != nullptr, "view_backward: null descriptor");
+  const int n = v->num_points;
+  const size_t N = (size_t)n;
+  // accumulators laid out as the Python binding lays them out: v_xy | v_conic | v_colors | v_opacity [| v_extra]
+  float *acc = g->accumulators;
+  GSR_REQUIRE(acc != nullptr && g->v_img != nullptr, "view_backward: null pointer");
+  float *v_xy = acc, *v_conic = acc + 2 * N, *v_colors = acc + 5 * N, *v_opac = acc + 8 * N, *v_extra = acc + 9 * N;
+  if (v->render_depth) {
+    GSR_REQUIRE(g->v_depth != nullptr, "view_backward: render_depth without its cotangent");
+    GSR_TRY(gsr_rasterize_backward_rgbd((unsigned)v->img_height, (unsigned)v->img_width, n, v->ids, v->tile_bins,
+                                        v->xys, v->conics, v->colors, v->depths, v->opac, v->background, 0.f,
+                                        v->final_Ts, v->final_idx, g->v_img, g->v_depth, g->v_alpha, v_xy, v_conic,
+                                        v_colors, v_extra, v_opac, v->deep_tile_threshold, g->accumulators_zeroed,
+                                        stream));
+  } else {
+    GSR_TRY(gsr_rasterize_backward_ex((unsigned)v->img_height, (unsigned)v->img_width, 16, n, v->ids, v->tile_bins,
+                                      v->xys, v->conics, v->colors, v->opac, v->background, v->final_Ts,
+                                      v->final_idx, g->v_img, g->v_alpha, v_xy, v_conic, v_colors, v_opac,
+                                      v->deep_tile_threshold, g->accumulators_zeroed, stream));
+  }
+  if (g->stats_first != nullptr)
+    GSR_TRY(gsr_densify_stats_dev(n, v_xy, v->radii, g->stats_inv_size, g->stats_first, g->xys_grad_norm,
+                                  g->vis_counts, g->max_2dsize, stream));
+  GSR_TRY(gsr_sh_backward_split((unsigned)n, (unsigned)v->sh_degree, (unsigned)v->sh_degree_to_use, v->dirs, v_colors,
+                                v->colors, g->v_dc, g->v_rest, stream));
+  GSR_TRY(gsr_project_backward(n, v->means, v->scales, v->glob_scale, v->quats, v->viewmat, v->projmat, v->fx, v->fy,
+                               v->cx, v->cy, (unsigned)v->img_height, (unsigned)v->img_width, v->cov3d, v->radii,
+                               v->conics, v->comp, v_xy, v->render_depth ? v_extra : nullptr, v_conic, nullptr,
+                               g->tmp_v_cov2d, g->tmp_v_cov3d, g->v_means, g->tmp_v_scales, g->tmp_v_quats, stream));
+  GSR_TRY(gsr_activate_backward(n, v->raw_quats, v->scales, v->quats, v->opac, g->tmp_v_scales, g->tmp_v_quats, v_opac,
+                                g->v_log_scales, g->v_raw_quats, g->v_logits, stream));
+  return GSR_OK;
+}

@@ -37,6 +37,47 @@ _f32, _i32 = torch.float32, torch.int32
 BLOCK = 16
 
 
+class _ViewDesc(C.Structure):  # gsr_view_desc (include/gsraster.h)
+    _fields_ = ([(k, C.c_int) for k in ("num_points", "sh_degree", "sh_degree_to_use", "render_depth", "img_height",
+                                        "img_width")]
+                + [(k, C.c_float) for k in ("fx", "fy", "cx", "cy", "glob_scale", "clip_thresh")]
+                + [(k, C.c_int) for k in ("capacity", "deep_tile_threshold")]
+                + [(k, C.c_void_p) for k in ("means", "log_scales", "raw_quats", "logits", "features_dc", "features_rest",
+                                             "viewmat", "projmat", "campos", "background", "scales", "quats", "opac",
+                                             "dirs", "cov3d", "xys", "depths", "radii", "conics", "comp", "tiles",
+                                             "colors", "reach_records", "counts", "order", "cum", "ids", "tile_bins",
+                                             "count_out", "sort_ws")]
+                + [("sort_ws_bytes", C.c_size_t), ("bin_ws", C.c_void_p), ("bin_ws_bytes", C.c_size_t)]
+                + [(k, C.c_void_p) for k in ("out_img", "out_depth", "final_Ts", "final_idx", "out_alpha", "zero_ptr")]
+                + [("zero_bytes", C.c_size_t)])
+
+
+class _ViewGrads(C.Structure):  # gsr_view_grads
+    _fields_ = ([(k, C.c_void_p) for k in ("v_img", "v_alpha", "v_depth", "accumulators")]
+                + [("accumulators_zeroed", C.c_int), ("stats_first", C.c_void_p), ("stats_inv_size", C.c_float)]
+                + [(k, C.c_void_p) for k in ("xys_grad_norm", "vis_counts", "max_2dsize", "tmp_v_cov2d", "tmp_v_cov3d",
+                                             "tmp_v_scales", "tmp_v_quats", "v_means", "v_log_scales", "v_raw_quats",
+                                             "v_logits", "v_dc", "v_rest")])
+
+
+_ws_bytes_cache = {}
+
+
+def _workspace_bytes(n, capacity, tb):
+    key = (n, capacity, tb[0], tb[1])
+    v = _ws_bytes_cache.get(key)
+    if v is None:
+        lib = _C._lib()
+        v = (int(lib.gsr_depth_order_workspace_bytes(C.c_int(n), C.c_int(1))),
+             int(lib.gsr_bin_sorted_workspace_bytes(C.c_int(n), C.c_int(capacity), C.c_int(tb[0]), C.c_int(tb[1]))),
+             int(lib.gsr_reach_record_bytes()),
+             not _C.lists_need_counts(n, capacity, tb, device_sized=True))
+        if len(_ws_bytes_cache) > 64:
+            _ws_bytes_cache.clear()
+        _ws_bytes_cache[key] = v
+    return v
+
+
 @dataclass(frozen=True)
 class ViewSpec:
     """The per-view scalars (baked into a captured graph: one graph per distinct spec)."""
@@ -87,45 +128,38 @@ class _Render(Function):
         tb = spec.tile_bounds
         degree = {1: 0, 4: 1, 9: 2, 16: 3}[features_rest.shape[1] + 1]
         with torch.cuda.device(dev):
-            scales = torch.empty_like(log_scales)
-            quats = torch.empty_like(raw_quats)
-            opac = torch.empty_like(logits)
-            dirs = torch.empty((n, 3), dtype=_f32, device=dev)
-            _call("gsr_activate_forward", C.c_int(n), _ptr(means), _ptr(log_scales), _ptr(raw_quats), _ptr(logits),
-                  _ptr(campos), _ptr(scales), _ptr(quats), _ptr(opac), _ptr(dirs), _stream(dev))
-            cov3d, xys, depths, radii, conics, comp, tiles = _C.project_gaussians_forward(
-                n, means, scales, spec.glob_scale, quats, viewmat, projmat, spec.fx, spec.fy, spec.cx, spec.cy, H, W,
-                BLOCK, spec.clip_thresh)
-            colors = torch.empty((n, 3), dtype=_f32, device=dev)
-            _call("gsr_sh_forward_split", C.c_uint(n), C.c_uint(degree), C.c_uint(spec.sh_degree_to_use), _ptr(dirs),
-                  _ptr(features_dc), _ptr(features_rest), _ptr(colors), C.c_float(0.5), C.c_int(1), _stream(dev))
-            # (long lists go through the two-level partition, which counts its entries itself: no
-            #  per-Gaussian counts, no scan -- include/gsraster.h "Lists without counts")
-            lean = not _C.lists_need_counts(n, capacity, tb, device_sized=True)
-            counts, recs = _C.count_reach(xys, radii, conics, opac, tb, counts=not lean)
-            order, cum = _C.depth_order(depths, radii, counts)
-            ids, bins = _C.bin_sorted(n, capacity, order, cum, xys, radii, tb, BLOCK, recs, device_sized=True,
-                                      count_out=count_out)
-            acc, alpha = None, None
+            e = lambda shape, dt=_f32: torch.empty(shape, dtype=dt, device=dev)
+            scales, quats, opac, dirs = e((n, 3)), e((n, 4)), torch.empty_like(logits), e((n, 3))
+            cov3d, xys, depths, radii = e((n, 6)), e((n, 2)), e((n,)), e((n,), _i32)
+            conics, comp, tiles, colors = e((n, 3)), e((n,)), e((n,), _i32), e((n, 3))
+            sort_b, bin_b, rec_b, lean = _workspace_bytes(n, capacity, tb)
+            recs = e((n, rec_b), torch.uint8)
+            counts = None if lean else e((n,), _i32)
+            cum = None if lean else e((n,), _i32)
+            order, ids, bins = e((n,), _i32), e((capacity,), _i32), e((tb[0] * tb[1], 2), _i32)
+            sort_ws, bin_ws = e((max(sort_b, 1),), torch.uint8), e((max(bin_b, 1),), torch.uint8)
+            img, Ts, idx, alpha = e((H, W, 3)), e((H, W)), e((H, W), _i32), e((H, W))
+            dep = e((H, W)) if spec.render_depth else None
             # alpha = 1 - T and the backward's cleared accumulators come out of the compositing launch
-            if any(ctx.needs_input_grad[:6]):
-                acc = _C.backward_accumulators(n, 4 if spec.render_depth else 3, dev)
-            if spec.render_depth:
-                img, dep, Ts, idx, alpha = _C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, xys, conics, colors,
-                                                                     depths, opac, background, 0.0, want_alpha=True,
-                                                                     zero=acc)
-            else:
-                img, Ts, idx, alpha = _C.rasterize_forward_ex(tb, (BLOCK, BLOCK, 1), (W, H, 1), ids, bins, xys, conics,
-                                                              colors, opac, background, want_alpha=True, zero=acc)
-                dep = None
+            acc = _C.backward_accumulators(n, 4 if spec.render_depth else 3, dev) if any(ctx.needs_input_grad[:6]) else None
+            p = lambda t: None if t is None else t.data_ptr()
+            desc = _ViewDesc(n, degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy, spec.cx,
+                             spec.cy, spec.glob_scale, spec.clip_thresh, capacity,
+                             _C.deep_tile_threshold(capacity, tb[0] * tb[1]),
+                             p(means), p(log_scales), p(raw_quats), p(logits), p(features_dc), p(features_rest),
+                             p(viewmat), p(projmat), p(campos), p(background), p(scales), p(quats), p(opac), p(dirs),
+                             p(cov3d), p(xys), p(depths), p(radii), p(conics), p(comp), p(tiles), p(colors), p(recs),
+                             p(counts), p(order), p(cum), p(ids), p(bins), p(count_out), p(sort_ws), sort_b,
+                             p(bin_ws), bin_b, p(img), p(dep), p(Ts), p(idx), p(alpha), p(acc),
+                             0 if acc is None else acc.numel() * 4)
+            _call("gsr_view_forward", C.byref(desc), _stream(dev))
         ctx.spec, ctx.stats, ctx.degree = spec, stats, degree
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means, raw_quats, features_dc, features_rest, viewmat, projmat, background, scales, quats,
                               opac, dirs, cov3d, xys, depths, radii, conics, comp, colors, ids, bins, Ts, idx)
         ctx.mark_non_differentiable(radii)
         ctx.accumulators = acc
-        if alpha is None:
-            alpha = 1 - Ts
+        ctx.capacity = capacity
         if dep is None:
             return img, alpha, radii
         return img, alpha, radii, dep
@@ -138,41 +172,39 @@ class _Render(Function):
         n = means.shape[0]
         dev = means.device
         H, W = spec.height, spec.width
+        tb = spec.tile_bounds
         with torch.cuda.device(dev):
             if v_img is None:
                 v_img = torch.zeros(H, W, 3, device=dev)
+            v_img = v_img.contiguous()
             v_a = None if v_alpha is None else v_alpha.contiguous()
             if spec.render_depth:
-                if v_dep is None:
-                    v_dep = torch.zeros(H, W, device=dev)
-                acc, ctx.accumulators = ctx.accumulators, None
-                v_xy, v_conic, v_colors, v_depths, v_opac = _C.rasterize_backward_rgbd(
-                    H, W, ids, bins, xys, conics, colors, depths, opac, background, 0.0, Ts, idx, v_img, v_dep, v_a,
-                    accumulators=acc)
-            else:
-                acc, ctx.accumulators = ctx.accumulators, None
-                v_xy, v_conic, v_colors, v_opac = _C.rasterize_backward(
-                    H, W, BLOCK, ids, bins, xys, conics, colors, opac, background, Ts, idx, v_img, v_a,
-                    accumulators=acc)
-                v_depths = None
-            if stats is not None and stats.enabled:
-                _call("gsr_densify_stats_dev", C.c_int(n), _ptr(v_xy), _ptr(radii), C.c_float(1.0 / stats.max_dim),
-                      _ptr(stats.first), _ptr(stats.xys_grad_norm), _ptr(stats.vis_counts), _ptr(stats.max_2dsize),
-                      _stream(dev))
+                v_dep = torch.zeros(H, W, device=dev) if v_dep is None else v_dep.contiguous()
+            acc, ctx.accumulators = ctx.accumulators, None
+            zeroed = acc is not None
+            if acc is None:  # a second backward (retain_graph): the kernels clear their own
+                acc = _C.backward_accumulators(n, 4 if spec.render_depth else 3, dev)
+            e = lambda shape: torch.empty(shape, dtype=_f32, device=dev)
+            t_cov2d, t_cov3d, t_vs, t_vq = e((n, 3)), e((n, 6)), e((n, 3)), e((n, 4))
+            v_means, g_s, g_q, g_o = e((n, 3)), e((n, 3)), e((n, 4)), torch.empty_like(opac)
+            v_dc, v_rest = torch.empty_like(features_dc), torch.empty_like(features_rest)
+            use_stats = stats is not None and stats.enabled
+            p = lambda t: None if t is None else t.data_ptr()
+            desc = _ViewDesc(n, ctx.degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy,
+                             spec.cx, spec.cy, spec.glob_scale, spec.clip_thresh, ctx.capacity,
+                             _C.deep_tile_threshold(ctx.capacity, tb[0] * tb[1]),
+                             p(means), None, p(raw_quats), None, p(features_dc), p(features_rest), p(viewmat),
+                             p(projmat), None, p(background), p(scales), p(quats), p(opac), p(dirs), p(cov3d), p(xys),
+                             p(depths), p(radii), p(conics), p(comp), None, p(colors), None, None, None, None, p(ids),
+                             p(bins), None, None, 0, None, 0, None, None, p(Ts), p(idx), None, None, 0)
+            grads = _ViewGrads(p(v_img), p(v_a), p(v_dep) if spec.render_depth else None, p(acc), int(zeroed),
+                               p(stats.first) if use_stats else None, (1.0 / stats.max_dim) if use_stats else 0.0,
+                               p(stats.xys_grad_norm) if use_stats else None, p(stats.vis_counts) if use_stats else None,
+                               p(stats.max_2dsize) if use_stats else None, p(t_cov2d), p(t_cov3d), p(t_vs), p(t_vq),
+                               p(v_means), p(g_s), p(g_q), p(g_o), p(v_dc), p(v_rest))
+            _call("gsr_view_backward", C.byref(desc), C.byref(grads), _stream(dev))
+            if use_stats:
                 stats.first.zero_()
-            v_dc = torch.empty_like(features_dc)
-            v_rest = torch.empty_like(features_rest)
-            _call("gsr_sh_backward_split", C.c_uint(n), C.c_uint(ctx.degree), C.c_uint(spec.sh_degree_to_use),
-                  _ptr(dirs), _ptr(v_colors), _ptr(colors), _ptr(v_dc), _ptr(v_rest), _stream(dev))
-            _, _, v_means, v_scales, v_quats = _C.project_gaussians_backward(
-                n, means, scales, spec.glob_scale, quats, viewmat, projmat, spec.fx, spec.fy, spec.cx, spec.cy, H, W,
-                cov3d, radii, conics, comp, v_xy, v_depths, v_conic, None)
-            g_s = torch.empty_like(scales)
-            g_q = torch.empty_like(quats)
-            g_o = torch.empty_like(opac)
-            _call("gsr_activate_backward", C.c_int(n), _ptr(raw_quats), _ptr(scales), _ptr(quats), _ptr(opac),
-                  _ptr(v_scales), _ptr(v_quats), _ptr(v_opac.view_as(opac)), _ptr(g_s), _ptr(g_q), _ptr(g_o),
-                  _stream(dev))
         return (v_means, g_s, g_q, g_o, v_dc, v_rest) + (None,) * 8
 
 

@@ -53,6 +53,8 @@ SYMBOLS = (
     "gsr_sh_backward_split",
     "gsr_rasterize_forward_rgbd",
     "gsr_rasterize_forward_scan",
+    "gsr_view_forward",
+    "gsr_view_backward",
     "gsr_rasterize_backward_rgbd",
     "gsr_activate_forward",
     "gsr_activate_backward",

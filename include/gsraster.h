@@ -440,6 +440,65 @@ int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
                                 float *v_opacity, int deep_tile_threshold,
                                 int accumulators_zeroed, gsr_stream_t stream);
 
+/* ---- a whole view as ONE call (host-bound scenes and viewer frames) -----
+ * The body of GaussianSplattingModel.get_outputs between the raw parameters and the images
+ * (gs_toolkit/models/vanilla_gs.py:765-857: activations, project_gaussians, SH + 0.5 clamped,
+ * tile lists, compositing -- with the depth image from the same pass when render_depth) and its
+ * autograd backward, as two calls instead of ~18: the same exported functions in the same order,
+ * run from C.  Nothing is allocated in here: every pointer is a caller-owned DEVICE buffer of the
+ * size the per-stage function documents (n = num_points, P = H x W, T = tiles, 16 x 16 tiles).
+ *   counts / cum      both NULL: lists without counts (gsr_bin_sorted_needs_counts() == 0 for
+ *                     (n, capacity, grid, device_sized = 1)); else i32[n] each
+ *   sort_ws / bin_ws  gsr_depth_order_workspace_bytes(n, 1) / gsr_bin_sorted_workspace_bytes(n, capacity, ..)
+ *   count_out         i32[1], device or pinned host memory: entries the view needs (> capacity: cut)
+ *   out_depth         [P], required iff render_depth;  out_alpha [P] nullable
+ *   zero_ptr/bytes    the backward's accumulators (6 + 3 + render_depth floats per Gaussian), cleared
+ *                     by the compositing launch; NULL: none */
+typedef struct gsr_view_desc {
+  int num_points, sh_degree, sh_degree_to_use, render_depth;
+  int img_height, img_width;
+  float fx, fy, cx, cy, glob_scale, clip_thresh;
+  int capacity, deep_tile_threshold;
+  const float *means, *log_scales, *raw_quats, *logits, *features_dc, *features_rest;
+  const float *viewmat, *projmat, *campos, *background;
+  float *scales, *quats, *opac, *dirs, *cov3d, *xys, *depths;
+  int32_t *radii;
+  float *conics, *comp;
+  int32_t *tiles;
+  float *colors;
+  void *reach_records;
+  int32_t *counts, *order, *cum, *ids, *tile_bins, *count_out;
+  void *sort_ws;
+  size_t sort_ws_bytes;
+  void *bin_ws;
+  size_t bin_ws_bytes;
+  float *out_img, *out_depth, *final_Ts;
+  int32_t *final_idx;
+  float *out_alpha;
+  void *zero_ptr;
+  size_t zero_bytes;
+} gsr_view_desc;
+
+/* cotangents in, parameter gradients out.  accumulators: (9 + render_depth) n floats laid out
+ * v_xy | v_conic | v_colors | v_opacity [| v_depths]; accumulators_zeroed != 0 when the forward's
+ * launch cleared them (zero_ptr).  stats_first != NULL: also after_train's statistics
+ * (gsr_densify_stats_dev).  tmp_*: scratch of [n,3] [n,6] [n,3] [n,4] floats. */
+typedef struct gsr_view_grads {
+  const float *v_img, *v_alpha, *v_depth; /* v_alpha / v_depth nullable (v_depth required iff render_depth) */
+  float *accumulators;
+  int accumulators_zeroed;
+  const int32_t *stats_first;
+  float stats_inv_size;
+  float *xys_grad_norm;
+  int32_t *vis_counts;
+  float *max_2dsize;
+  float *tmp_v_cov2d, *tmp_v_cov3d, *tmp_v_scales, *tmp_v_quats;
+  float *v_means, *v_log_scales, *v_raw_quats, *v_logits, *v_dc, *v_rest;
+} gsr_view_grads;
+
+int gsr_view_forward(const gsr_view_desc *view, gsr_stream_t stream);
+int gsr_view_backward(const gsr_view_desc *view, const gsr_view_grads *grads, gsr_stream_t stream);
+
 /* ---- per-Gaussian activations (caller-side glue) ----------
  * exp(scales), quats / |quats|, sigmoid(opacities) and the normalised view
  * directions means - camera_position of GaussianSplattingModel.get_outputs
