@@ -364,7 +364,8 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             //   = T * (rgb . v_out) + ra * (K - buffer . v_out);
             // K[p] carries  T_final*(v_out_alpha - bg.v_out) - buffer.v_out  (a scalar per
             // pixel instead of the reference's 3-channel running buffer)
-            const float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p] + (RGBD ? C.extra * ve[p] : 0.f);
+            float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
+            if constexpr (RGBD) d += C.extra * ve[p];  // (a literal "+ 0.f" in the 3-channel case is a real v_add: -0 semantics)
             const float v_alpha = Tn * d + ra * K[p];
             const float w = valid ? vis * v_alpha : 0.f;
             const float fac = valid ? alpha * Tn : 0.f;
