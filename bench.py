@@ -204,6 +204,13 @@ def train_only(args):
         cfg.log_every = 10
     res = train(cfg, dev, rank, world)
     res1m = train(fixed_1m(), dev, rank, world) if (args.train_iters >= 1000 and not args.train_small) else None
+    res_one = None
+    if args.train_iters >= 1000 and not args.train_small:
+        # the same configuration through gs_fused.render_gaussians: one autograd node and one native call per view
+        # instead of the models' op-by-op sequence (optional API; the headline figure above is the public ops)
+        cfg_one = config3(args.train_iters)
+        cfg_one.fused_render = True
+        res_one = train(cfg_one, dev, rank, world)
     if world > 1:
         cs = torch.tensor([res["param_checksum"]], dtype=torch.float64, device=dev)
         lo, hi = cs.clone(), cs.clone()
@@ -242,6 +249,12 @@ def train_only(args):
             "parallelism": (f"dp{world} per-view, {backend}" if world > 1 else "single"),
             "update": res["update"],
         }
+        if res_one is not None:
+            rec["one_op_path"] = {"what": "config 3 through gs_fused.render_gaussians (one native call per view, statistics "
+                                          "from its backward)", "iters_per_s": round(res_one["iters_per_s"], 1),
+                                  "gaussians_end": res_one["num_gaussians_end"],
+                                  "psnr": [round(res_one["psnr_start"], 2), round(res_one["psnr_end"], 2)],
+                                  "list_overflow_views": res_one["list_overflow_views"]}
         if res1m is not None:
             rec["fixed_1m"] = {"workload": "1 M Gaussians at 1920x1080, N fixed (no refinement), full training iteration",
                                "iters_per_s": round(res1m["iters_per_s"], 1), "views_per_s": round(res1m["views_per_s"], 1),
