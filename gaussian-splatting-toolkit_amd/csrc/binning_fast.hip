@@ -557,3 +557,122 @@ GSR_EXPORT int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *o
                          tiles_y, block_width, num_bands, gaussian_ids_sorted, tile_bins, count_out, slot_of_entry,
                          workspace, workspace_bytes, stream);
 }
+
+// ---- two-round lists ---------------------------------------------------
+// The lists of the nearest Gaussians are a prefix of every tile's list.  After a first compositing round
+// over such prefix lists (gsr_rasterize_forward_round(1)) the tiles whose every pixel has finished need
+// nothing more; a Gaussian of the remaining depth range whose tile box holds no unfinished tile can
+// therefore be dropped BEFORE the second round's lists are built -- per Gaussian, with one summed-area
+// lookup, without any per-tile mask inside the partition.
+namespace {
+// sat[(y + 1) * (tiles_x + 1) + (x + 1)] = number of flagged tiles in [0, x] x [0, y]; one workgroup
+__global__ __launch_bounds__(1024) void tile_flag_sat_kernel(const int tiles_x, const int tiles_y,
+                                                             const int *__restrict__ flags, int *__restrict__ sat,
+                                                             int *__restrict__ flagged_out) {
+  const int W = tiles_x + 1;
+  for (int i = threadIdx.x; i < W; i += 1024) sat[i] = 0;
+  for (int y = threadIdx.x; y < tiles_y; y += 1024) {
+    int run = 0;
+    sat[(y + 1) * W] = 0;
+    for (int x = 0; x < tiles_x; ++x) {
+      run += flags[y * tiles_x + x] != 0;
+      sat[(y + 1) * W + x + 1] = run;
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < tiles_x; x += 1024) {
+    int run = 0;
+    for (int y = 0; y < tiles_y; ++y) {
+      run += sat[(y + 1) * W + x + 1];
+      sat[(y + 1) * W + x + 1] = run;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && flagged_out) *flagged_out = sat[tiles_y * W + tiles_x];
+}
+
+__global__ __launch_bounds__(256) void saturation_filter_kernel(const int count, const int *__restrict__ order,
+                                                                SplatRec *__restrict__ recs, const int tiles_x,
+                                                                const int *__restrict__ sat,
+                                                                int *__restrict__ survivors) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  bool keep = false;
+  if (i < count) {
+    const int g = order[i];
+    const unsigned b0 = recs[g].box0, b1 = recs[g].box1;
+    const int w = (int)(b1 & 0xffffu), h = (int)(b1 >> 16);
+    if (w > 0 && h > 0) {
+      const int x0 = (int)(b0 & 0xffffu), y0 = (int)(b0 >> 16), W = tiles_x + 1;
+      const int c = sat[(y0 + h) * W + x0 + w] - sat[y0 * W + x0 + w] - sat[(y0 + h) * W + x0] + sat[y0 * W + x0];
+      keep = c > 0;
+      if (!keep) recs[g].box1 = 0u;  // culled: no tile of its box is still unfinished
+    }
+  }
+  if (survivors) {
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(survivors, __popcll(m));
+  }
+}
+}  // namespace
+
+GSR_EXPORT size_t gsr_saturation_filter_workspace_bytes(int tiles_x, int tiles_y) {
+  if (tiles_x <= 0 || tiles_y <= 0) return 0;
+  return sizeof(int) * (size_t)(tiles_x + 1) * (size_t)(tiles_y + 1);
+}
+
+GSR_EXPORT int gsr_saturation_filter(int count, const int32_t *order, void *reach_records, const int32_t *tile_flags,
+                                     int tiles_x, int tiles_y, void *workspace, size_t workspace_bytes,
+                                     int32_t *stats_out, gsr_stream_t stream) {
+  GSR_REQUIRE(count >= 0 && tiles_x > 0 && tiles_y > 0 && tiles_x <= 65535 && tiles_y <= 65535,
+              "saturation_filter: bad sizes");
+  GSR_REQUIRE(tile_flags && workspace && workspace_bytes >= gsr_saturation_filter_workspace_bytes(tiles_x, tiles_y),
+              "saturation_filter: null pointer or workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int *sat = static_cast<int *>(workspace);
+  // stats_out (nullable, int32[2], device-accessible): [0] = unfinished tiles, [1] = Gaussians kept; zeroed here
+  if (stats_out)
+    if (int zrc = gsr_zero_async(stats_out, 2 * sizeof(int32_t), s)) return zrc;
+  hipLaunchKernelGGL(tile_flag_sat_kernel, dim3(1), dim3(1024), 0, s, tiles_x, tiles_y, tile_flags, sat,
+                     stats_out ? stats_out : (int *)nullptr);
+  if (count > 0) {
+    GSR_REQUIRE(order && reach_records, "saturation_filter: null pointer");
+    hipLaunchKernelGGL(saturation_filter_kernel, dim3(gsr_cdiv(count, 256)), dim3(256), 0, s, count, order,
+                       static_cast<SplatRec *>(reach_records), tiles_x, (const int *)sat,
+                       stats_out ? stats_out + 1 : (int *)nullptr);
+  }
+  GSR_CHECK_LAUNCH("saturation_filter");
+  return GSR_OK;
+}
+
+// The two-level partition over a SUB-RANGE of the depth order (`order` points at its first element): lists of
+// those `count` Gaussians only, tile_bins relative to gaussian_ids_sorted.  Count-free (reach records required).
+GSR_EXPORT int gsr_tile_lists_subrange(int count, int capacity, const int32_t *order, const void *reach_records,
+                                       int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                                       int32_t *count_out, void *workspace, size_t workspace_bytes,
+                                       gsr_stream_t stream) {
+  GSR_REQUIRE(count >= 0 && capacity >= 1, "tile_lists_subrange: bad sizes");
+  GSR_REQUIRE(tile_bins && gaussian_ids_sorted, "tile_lists_subrange: null pointer");
+  GSR_REQUIRE(gsr_tile_partition2_supported(tiles_x, tiles_y), "tile_lists_subrange: tile grid not supported");
+  hipStream_t s = (hipStream_t)stream;
+  if (count == 0) {
+    const int num_tiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
+                       reinterpret_cast<int2 *>(tile_bins));
+    if (count_out)
+      if (int zrc = gsr_zero_async(count_out, sizeof(int32_t), s)) return zrc;
+    GSR_CHECK_LAUNCH("tile_lists_subrange(clear)");
+    return GSR_OK;
+  }
+  GSR_REQUIRE(order && reach_records && workspace, "tile_lists_subrange: null pointer");
+  if (tiles_x > 256) {  // (the two-level partition finishes tile_bins itself only for rows of up to 256 tiles)
+    const int num_tiles = tiles_x * tiles_y;
+    hipLaunchKernelGGL(tile_bins_clear_kernel, dim3(gsr_cdiv(num_tiles, 256)), dim3(256), 0, s, num_tiles,
+                       reinterpret_cast<int2 *>(tile_bins));
+  }
+  return gsr_tile_partition2(count, capacity, order, reach_records, tiles_x, tiles_y, gaussian_ids_sorted, tile_bins,
+                             count_out, workspace, workspace_bytes, s);
+}
+
+GSR_EXPORT size_t gsr_tile_lists_subrange_workspace_bytes(int count, int capacity, int tiles_x, int tiles_y) {
+  return gsr_tile_partition2_workspace_bytes(count, capacity, tiles_x, tiles_y);
+}

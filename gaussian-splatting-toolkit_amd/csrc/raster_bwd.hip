@@ -250,7 +250,10 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     float *__restrict__ v_conic, float *__restrict__ v_colors, float *__restrict__ v_opacity,
     const float *__restrict__ extra, const float bg_extra, const float *__restrict__ v_out_extra,
     float *__restrict__ v_extra, const int deep_threshold, const unsigned base_grid,
-    float *__restrict__ partials, unsigned char *__restrict__ pflags) {
+    float *__restrict__ partials, unsigned char *__restrict__ pflags, const int2 *__restrict__ tile_bins2,
+    const int idx_base2) {
+  // tile_bins2 (two-round lists, gsr_rasterize_forward_round): a tile's list is its range in tile_bins followed by
+  // its range in tile_bins2 (relative to idx_base2 in ids_sorted): walked back to front, second segment first.
   static_assert(!RGBD || G == 4, "the 10-component butterfly exists for groups of 4");
   constexpr int NC = RGBD ? 10 : 9;
   __shared__ SplatA sA[kChunk];
@@ -263,7 +266,13 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile, allowed = job.allowed;  // allowed: the sub-tiles this wave owns (raster_common.h)
   if (tile < 0) return;
-  if (range.y <= range.x) return;
+  int2 range2 = make_int2(0, 0);
+  if (tile_bins2) {
+    range2 = tile_bins2[tile];
+    range2.x += idx_base2;
+    range2.y += idx_base2;
+  }
+  if (range.y <= range.x && range2.y <= range2.x) return;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
   const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
@@ -306,8 +315,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   int topp[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) topp[p] = __builtin_amdgcn_readfirstlane(wave_max(binf[p]));
-  const int top = min(range.y - 1, max(max(topp[0], topp[1]), max(topp[2], topp[3])));
-  if (top < range.x) return;
+  const int max_top = max(max(topp[0], topp[1]), max(topp[2], topp[3]));
 
   // lane-constant destination of the `main` value
   const int comp = BF::comp_of_lane(lane);
@@ -321,6 +329,9 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   const float sel_one = comp >= 5 ? 1.f : 0.f;
 
   unsigned long long *const staged = g_bwd_staged;
+  for (int seg = tile_bins2 ? 1 : 0; seg >= 0; --seg) {
+  if (seg) range = range2; else if (tile_bins2) range = tile_bins[tile];  // (tile_job left the first segment in `range`)
+  const int top = min(range.y - 1, max_top);
   for (int hi = top; hi >= range.x; hi -= kChunk) {
     // back to front: lane l fetches sorted index hi - l; kept splats stay in that order
     const int sidx_l = hi - lane;
@@ -440,6 +451,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
       }
     }
     __syncthreads();
+  }
   }
 }
 
@@ -683,7 +695,7 @@ GSR_EXPORT int gsr_rasterize_backward_ex(
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,  \
                      final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,        \
                      v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep, base, \
-                     (float *)nullptr, (unsigned char *)nullptr)
+                     (float *)nullptr, (unsigned char *)nullptr, (const int2 *)nullptr, 0)
   if (group == 8) GSR_LAUNCH_T16(8);
   else GSR_LAUNCH_T16(4);
 #undef GSR_LAUNCH_T16
@@ -720,8 +732,54 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics,
                      colors, opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic,
                      v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra, deep, base, (float *)nullptr,
-                     (unsigned char *)nullptr);
+                     (unsigned char *)nullptr, (const int2 *)nullptr, 0);
   GSR_CHECK_LAUNCH("rasterize_backward_rgbd");
+  return GSR_OK;
+}
+
+// ---- two-round lists: a tile's list = its range in tile_bins, then its range in tile_bins2 (+ idx_base2) ----
+GSR_EXPORT int gsr_rasterize_backward_two(
+    unsigned img_height, unsigned img_width, int num_points, const int32_t *gaussian_ids_sorted,
+    const int32_t *tile_bins, const int32_t *tile_bins2, int idx_base2, const float *xys, const float *conics,
+    const float *colors, const float *extra, const float *opacities, const float *background, float extra_background,
+    const float *final_Ts, const int32_t *final_idx, const float *v_output, const float *v_output_extra,
+    const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_extra, float *v_opacity,
+    int deep_tile_threshold, int accumulators_zeroed, gsr_stream_t stream) {
+  GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward_two: empty image");
+  GSR_REQUIRE(num_points >= 0 && idx_base2 >= 0, "rasterize_backward_two: negative size");
+  if (num_points == 0) return GSR_OK;
+  const bool rgbd = extra != nullptr;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && tile_bins2 && xys && conics && colors && opacities && background &&
+                  final_Ts && final_idx && v_output && v_xy && v_conic && v_colors && v_opacity &&
+                  (!rgbd || (v_output_extra && v_extra)),
+              "rasterize_backward_two: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulators_zeroed) {
+    int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
+    if (rc != GSR_OK) return rc;
+    if (rgbd)
+      if (int zrc = gsr_zero_async(v_extra, sizeof(float) * (size_t)num_points, s)) return zrc;
+  }
+  const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
+  const int num_tiles = tiles_x * tiles_y;
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const dim3 grd(deep ? 4 * base : base), blk(64);
+  if (rgbd)
+    hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, true>), grd, blk, 0, s, tiles_x, num_tiles, (int)img_width,
+                       (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
+                       reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, final_Ts, final_idx,
+                       v_output, v_output_alpha, v_xy, v_conic, v_colors, v_opacity, extra, extra_background,
+                       v_output_extra, v_extra, deep, base, (float *)nullptr, (unsigned char *)nullptr,
+                       reinterpret_cast<const int2 *>(tile_bins2), idx_base2);
+  else
+    hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, false>), grd, blk, 0, s, tiles_x, num_tiles, (int)img_width,
+                       (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
+                       reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, final_Ts, final_idx,
+                       v_output, v_output_alpha, v_xy, v_conic, v_colors, v_opacity, (const float *)nullptr, 0.f,
+                       (const float *)nullptr, (float *)nullptr, deep, base, (float *)nullptr, (unsigned char *)nullptr,
+                       reinterpret_cast<const int2 *>(tile_bins2), idx_base2);
+  GSR_CHECK_LAUNCH("rasterize_backward_two");
   return GSR_OK;
 }
 
@@ -766,7 +824,7 @@ GSR_EXPORT int gsr_rasterize_backward_det(
                        (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
                        reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, final_Ts, final_idx,
                        v_output, v_output_alpha, v_xy, v_conic, v_colors, v_opacity, extra, extra_background,
-                       v_output_extra, v_extra, 0, base, partials, pflags);
+                       v_output_extra, v_extra, 0, base, partials, pflags, (const int2 *)nullptr, 0);
     hipLaunchKernelGGL(reduce_partials_kernel<true>, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, num_points,
                        num_bands, list_capacity, order, cum_sorted, slot_of_entry, (const float *)partials,
                        (const unsigned char *)pflags, v_xy, v_conic, v_colors, v_opacity, v_extra);
@@ -775,7 +833,7 @@ GSR_EXPORT int gsr_rasterize_backward_det(
                        (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
                        reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, final_Ts, final_idx,
                        v_output, v_output_alpha, v_xy, v_conic, v_colors, v_opacity, (const float *)nullptr, 0.f,
-                       (const float *)nullptr, (float *)nullptr, 0, base, partials, pflags);
+                       (const float *)nullptr, (float *)nullptr, 0, base, partials, pflags, (const int2 *)nullptr, 0);
     hipLaunchKernelGGL(reduce_partials_kernel<false>, dim3(gsr_cdiv(num_points, 256)), dim3(256), 0, s, num_points,
                        num_bands, list_capacity, order, cum_sorted, slot_of_entry, (const float *)partials,
                        (const unsigned char *)pflags, v_xy, v_conic, v_colors, v_opacity, (float *)nullptr);

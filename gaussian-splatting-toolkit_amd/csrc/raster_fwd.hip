@@ -56,7 +56,15 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const float *__restrict__ background, float *__restrict__ out_img,
     float *__restrict__ final_Ts, int *__restrict__ final_idx, const float *__restrict__ extra,
     const float bg_extra, float *__restrict__ out_extra, const int deep_threshold, const unsigned base_grid,
-    float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr, const unsigned zero_words) {
+    float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr, const unsigned zero_words,
+    const int round, int *__restrict__ tile_flags, const int idx_base) {
+  // Two-round compositing (gsr_rasterize_forward_round): the lists of the nearest
+  // Gaussians are a PREFIX of every tile's list.  round 1 composites such prefix lists and leaves the per-pixel
+  // state RAW -- final_Ts = signed T (< 0: finished), out_img / out_extra = C without background, final_idx --
+  // plus tile_flags[tile] = 1 where a pixel is still live; round 2 RESUMES every tile from that state over the
+  // lists of the remaining Gaussians (tile_bins relative to idx_base in ids_sorted) and finalises all pixels.
+  // The per-pixel instruction sequence is that of one walk over the concatenated list: bit-identical results.
+  // round 0: the single walk.
   // (gsr_rasterize_forward_ex) the launch also clears `zero_words` words at `zero_ptr` -- the gradient
   // accumulators of the coming backward: 36 MB of stores that vanish inside this VALU-bound kernel
   // instead of a bandwidth-bound launch of their own -- every workgroup its slice, before any exit
@@ -73,6 +81,8 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile, allowed = job.allowed;
   if (tile < 0) return;
+  range.x += idx_base;
+  range.y += idx_base;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
   const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
@@ -85,10 +95,20 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   int last[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const bool inside = (qx + 8 * (p & 1)) < img_w && (qy + 8 * (p >> 1)) < img_h && ((allowed >> p) & 1);
+    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+    const bool inside = col < img_w && row < img_h && ((allowed >> p) & 1);
     T[p] = inside ? 1.f : -1.f;
     cr[p] = cg[p] = cb[p] = ce[p] = 0.f;
     last[p] = 0;
+    if (round == 2 && inside) {  // resume from the raw state round 1 left
+      const size_t pid = (size_t)row * img_w + col;
+      T[p] = final_Ts[pid];
+      cr[p] = out_img[3 * pid];
+      cg[p] = out_img[3 * pid + 1];
+      cb[p] = out_img[3 * pid + 2];
+      if constexpr (RGBD) ce[p] = out_extra[pid];
+      last[p] = final_idx[pid];
+    }
   }
 
   // sub-tiles that still have a live pixel (wave-uniform)
@@ -149,6 +169,23 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     live = live_subtiles();
   }
 
+  if (round == 1) {  // raw state + "a pixel of this tile is still live"
+    if (live_subtiles() != 0 && lane == 0) tile_flags[tile] = 1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+      if (col < img_w && row < img_h && ((allowed >> p) & 1)) {
+        const size_t pid = (size_t)row * img_w + col;
+        final_Ts[pid] = T[p];
+        final_idx[pid] = last[p];
+        out_img[3 * pid] = cr[p];
+        out_img[3 * pid + 1] = cg[p];
+        out_img[3 * pid + 2] = cb[p];
+        if constexpr (RGBD) out_extra[pid] = ce[p];
+      }
+    }
+    return;
+  }
   // wave-uniform -> scalar loads
   const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
 #pragma unroll
@@ -464,7 +501,7 @@ GSR_EXPORT int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
                      out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base,
-                     out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2));
+                     out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0);
   GSR_CHECK_LAUNCH("rasterize_forward(tile16)");
   return GSR_OK;
 }
@@ -513,8 +550,48 @@ GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img
                      reinterpret_cast<const int2 *>(tile_bins),
                      reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,
                      out_img, final_Ts, final_idx, extra, extra_background, out_extra, deep, base,
-                     out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2));
+                     out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0);
   GSR_CHECK_LAUNCH("rasterize_forward_rgbd");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, unsigned img_width,
+                                           unsigned img_height, const int32_t *gaussian_ids_sorted,
+                                           const int32_t *tile_bins, int idx_base, const float *xys,
+                                           const float *conics, const float *colors, const float *extra,
+                                           const float *opacities, const float *background, float extra_background,
+                                           float *out_img, float *out_extra, float *final_Ts, int32_t *final_idx,
+                                           int32_t *tile_flags, int deep_tile_threshold, float *out_alpha,
+                                           void *zero_ptr, size_t zero_bytes, gsr_stream_t stream) {
+  int rc = check_common("rasterize_forward_round", tiles_x, tiles_y, 16, img_width, img_height, 3);
+  if (rc != GSR_OK) return rc;
+  GSR_REQUIRE(round == 1 || round == 2, "rasterize_forward_round: round must be 1 or 2");
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background && out_img &&
+                  final_Ts && final_idx,
+              "rasterize_forward_round: null pointer");
+  GSR_REQUIRE((extra == nullptr) == (out_extra == nullptr), "rasterize_forward_round: extra and out_extra go together");
+  GSR_REQUIRE(round == 2 || tile_flags != nullptr, "rasterize_forward_round: round 1 needs tile_flags");
+  GSR_REQUIRE(idx_base >= 0, "rasterize_forward_round: idx_base < 0");
+  GSR_REQUIRE(zero_ptr == nullptr || ((zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0 &&
+                                      zero_bytes < ((size_t)1 << 34)),
+              "rasterize_forward_round: zero_ptr / zero_bytes must be multiples of 4 (and below 16 GB)");
+  const int num_tiles = tiles_x * tiles_y;
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const dim3 grd(deep ? 4 * base : base), blk(64);
+  if (extra)
+    hipLaunchKernelGGL(raster_fwd_tile16_kernel<true>, grd, blk, 0, (hipStream_t)stream, tiles_x, num_tiles,
+                       (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
+                       reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, out_img, final_Ts,
+                       final_idx, extra, extra_background, out_extra, deep, base, out_alpha,
+                       static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), round, tile_flags, idx_base);
+  else
+    hipLaunchKernelGGL(raster_fwd_tile16_kernel<false>, grd, blk, 0, (hipStream_t)stream, tiles_x, num_tiles,
+                       (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),
+                       reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, out_img, final_Ts,
+                       final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base, out_alpha,
+                       static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), round, tile_flags, idx_base);
+  GSR_CHECK_LAUNCH("rasterize_forward_round");
   return GSR_OK;
 }
 

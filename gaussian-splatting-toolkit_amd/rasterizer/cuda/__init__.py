@@ -375,6 +375,101 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     return ids, tile_bins
 
 
+# ---- two-round lists (include/gsraster.h "two-round lists for deep scenes") -----------------------------
+def tile_lists_subrange(order_sub: Tensor, capacity: int, reach_records: Tensor, tile_bounds, ids_out: Tensor,
+                        count_out: Optional[Tensor] = None) -> Tensor:
+    """``gsr_tile_lists_subrange``: the two-level partition over ``order_sub`` (a contiguous slice of the depth
+    order) into ``ids_out`` (int32[capacity], e.g. a slice of the combined array) -> tile_bins i32[T,2] relative
+    to ``ids_out``; ``count_out`` (int32[1], device or pinned) receives the uncut length."""
+    _check(order_sub, "order", _i32)
+    _check(ids_out, "ids_out", _i32)
+    if ids_out.numel() < int(capacity):
+        raise RuntimeError("tile_lists_subrange: ids_out is smaller than the capacity")
+    n = order_sub.numel()
+    nt = int(tile_bounds[0]) * int(tile_bounds[1])
+    dev = ids_out.device
+    with torch.cuda.device(dev):
+        bins = torch.empty((nt, 2), dtype=_i32, device=dev)
+        nbytes = int(_lib().gsr_tile_lists_subrange_workspace_bytes(C.c_int(n), C.c_int(int(capacity)),
+                                                                   C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _call("gsr_tile_lists_subrange", C.c_int(n), C.c_int(int(capacity)), _ptr(order_sub), _ptr(reach_records),
+              C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(ids_out), _ptr(bins),
+              _ptr(count_out) if count_out is not None else None, _ptr(ws), C.c_size_t(nbytes), _stream(dev))
+    return bins
+
+
+def saturation_filter(order_sub: Tensor, reach_records: Tensor, tile_flags: Tensor, tile_bounds,
+                      stats_out: Optional[Tensor] = None) -> None:
+    """``gsr_saturation_filter``: culls (in ``reach_records``) every Gaussian of ``order_sub`` whose tile box
+    holds no flagged tile.  ``tile_flags`` int32[T]; ``stats_out`` int32[2]: flagged tiles, Gaussians kept."""
+    _check(order_sub, "order", _i32)
+    _check(tile_flags, "tile_flags", _i32)
+    dev = tile_flags.device
+    with torch.cuda.device(dev):
+        nbytes = int(_lib().gsr_saturation_filter_workspace_bytes(C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _call("gsr_saturation_filter", C.c_int(order_sub.numel()), _ptr(order_sub), _ptr(reach_records),
+              _ptr(tile_flags), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(ws), C.c_size_t(nbytes),
+              _ptr(stats_out) if stats_out is not None else None, _stream(dev))
+
+
+def rasterize_forward_round(rnd: int, tile_bounds, img_size, gaussian_ids_sorted, tile_bins, idx_base: int, xys, conics,
+                            colors, extra, opacities, background, extra_background: float, out_img, out_extra, final_Ts,
+                            final_idx, tile_flags, out_alpha=None, zero=None) -> None:
+    """``gsr_rasterize_forward_round``: round 1 composites the prefix lists into RAW state (``final_Ts`` signed,
+    ``out_img`` / ``out_extra`` without background) and flags the tiles with a live pixel; round 2 resumes over the
+    second lists (``tile_bins`` relative to ``idx_base``) and finalises.  All outputs are caller-owned tensors."""
+    W, H = int(img_size[0]), int(img_size[1])
+    dev = xys.device
+    nt = tile_bounds[0] * tile_bounds[1]
+    with torch.cuda.device(dev):
+        _call("gsr_rasterize_forward_round", C.c_int(int(rnd)), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
+              C.c_uint(W), C.c_uint(H), _ptr(gaussian_ids_sorted), _ptr(tile_bins), C.c_int(int(idx_base)), _ptr(xys),
+              _ptr(conics), _ptr(colors), _ptr(extra) if extra is not None else None, _ptr(opacities),
+              _ptr(background), C.c_float(extra_background), _ptr(out_img),
+              _ptr(out_extra) if out_extra is not None else None, _ptr(final_Ts), _ptr(final_idx),
+              _ptr(tile_flags) if tile_flags is not None else None,
+              C.c_int(deep_tile_threshold(tile_bins.shape[0] * 400, nt)),
+              _ptr(out_alpha) if out_alpha is not None else None, _ptr(zero) if zero is not None else None,
+              C.c_size_t(zero.numel() * 4 if zero is not None else 0), _stream(dev))
+
+
+def rasterize_backward_two(img_height, img_width, gaussian_ids_sorted, tile_bins, tile_bins2, idx_base2: int, xys,
+                           conics, colors, extra, opacities, background, extra_background: float, final_Ts, final_idx,
+                           v_output, v_output_extra, v_output_alpha, accumulators: Optional[Tensor] = None):
+    """``gsr_rasterize_backward_two``: the backward over two-round lists -> (v_xy, v_conic, v_colors, v_opacity)
+    or, with ``extra``, (v_xy, v_conic, v_colors, v_extra, v_opacity)."""
+    v_output = _check(v_output.contiguous(), "v_output", _f32)
+    if v_output_alpha is not None:
+        v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
+    if extra is not None:
+        v_output_extra = _check(v_output_extra.contiguous(), "v_output_extra", _f32)
+    n = xys.size(0)
+    k = 10 if extra is not None else 9
+    dev = xys.device
+    with torch.cuda.device(dev):
+        zeroed = accumulators is not None
+        if zeroed and (accumulators.numel() != n * k or accumulators.dtype != _f32 or not accumulators.is_contiguous()):
+            raise RuntimeError("rasterize_backward_two: accumulators must be backward_accumulators(n, 3 or 4, device)")
+        flat = accumulators if zeroed else torch.empty((n * k,), dtype=_f32, device=dev)
+        v_xy, v_conic = flat[: 2 * n].view(n, 2), flat[2 * n: 5 * n].view(n, 3)
+        v_colors, v_opacity = flat[5 * n: 8 * n].view(n, 3), flat[8 * n: 9 * n].view(n, 1)
+        v_extra = flat[9 * n:] if extra is not None else None
+        nt = ((img_width + 15) // 16) * ((img_height + 15) // 16)
+        _call("gsr_rasterize_backward_two", C.c_uint(img_height), C.c_uint(img_width), C.c_int(n),
+              _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(tile_bins2), C.c_int(int(idx_base2)), _ptr(xys),
+              _ptr(conics), _ptr(colors), _ptr(extra) if extra is not None else None, _ptr(opacities),
+              _ptr(background), C.c_float(extra_background), _ptr(final_Ts), _ptr(final_idx), _ptr(v_output),
+              _ptr(v_output_extra) if extra is not None else None,
+              _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
+              _ptr(v_extra) if v_extra is not None else None, _ptr(v_opacity),
+              C.c_int(deep_tile_threshold(tile_bins.shape[0] * 400, nt)), C.c_int(1 if zeroed else 0), _stream(dev))
+    if extra is not None:
+        return v_xy, v_conic, v_colors, v_extra, v_opacity
+    return v_xy, v_conic, v_colors, v_opacity
+
+
 def _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background):
     _check(gaussian_ids_sorted, "gaussian_ids_sorted", _i32)
     _check(tile_bins, "tile_bins", _i32)

@@ -53,6 +53,12 @@ SYMBOLS = (
     "gsr_sh_backward_split",
     "gsr_rasterize_forward_rgbd",
     "gsr_rasterize_forward_scan",
+    "gsr_tile_lists_subrange_workspace_bytes",
+    "gsr_tile_lists_subrange",
+    "gsr_saturation_filter_workspace_bytes",
+    "gsr_saturation_filter",
+    "gsr_rasterize_forward_round",
+    "gsr_rasterize_backward_two",
     "gsr_view_forward",
     "gsr_view_backward",
     "gsr_rasterize_backward_rgbd",
@@ -95,6 +101,8 @@ def _load():
     lib.gsr_depth_order_workspace_bytes.restype = C.c_size_t
     lib.gsr_bin_sorted_workspace_bytes.restype = C.c_size_t
     lib.gsr_refine_workspace_bytes.restype = C.c_size_t
+    lib.gsr_tile_lists_subrange_workspace_bytes.restype = C.c_size_t
+    lib.gsr_saturation_filter_workspace_bytes.restype = C.c_size_t
     lib.gsr_rasterize_backward_det_workspace_bytes.restype = C.c_size_t
     return lib
 

@@ -440,6 +440,54 @@ int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
                                 float *v_opacity, int deep_tile_threshold,
                                 int accumulators_zeroed, gsr_stream_t stream);
 
+/* ---- two-round lists for deep scenes (block_width 16) --------------------
+ * replaces, like gsr_bin_sorted + gsr_rasterize_forward / _backward, the list construction of
+ * rasterizer/utils.py:106-182 and the walks of forward.cu:278-395 / backward.cu:133-303 -- with the SAME
+ * results: on a scene whose tiles saturate early (3 M Gaussians at 4K: 97.7 M list entries built, 4.1 M ever
+ * read) almost every entry lies behind the depth at which its tile's pixels have all finished.  The lists of
+ * the NEAREST Gaussians (a prefix of the depth order) are a prefix of every tile's list:
+ *   1. gsr_tile_lists_subrange over order[0 : n1]            -> lists 1 (ids at gaussian_ids_sorted + 0)
+ *   2. gsr_rasterize_forward_round(1, lists 1)               -> raw per-pixel state + tile_flags (1 = a pixel
+ *                                                               of the tile is still live; zero them first)
+ *   3. gsr_saturation_filter over order[n1 : n]              -> culls (in reach_records) every remaining Gaussian
+ *                                                               whose tile box holds no flagged tile
+ *   4. gsr_tile_lists_subrange over order[n1 : n]            -> lists 2 (ids at gaussian_ids_sorted + idx_base,
+ *                                                               tile_bins2 relative to idx_base)
+ *   5. gsr_rasterize_forward_round(2, lists 2, idx_base)     -> resumes every tile, finalises every pixel
+ *   6. gsr_rasterize_backward_two(tile_bins, tile_bins2, idx_base)
+ * A tile's list is its range in tile_bins followed by its range in tile_bins2; per pixel the instruction
+ * sequence is that of one walk over the concatenation, so images, final_Ts and final_idx (an index into
+ * gaussian_ids_sorted, as always) are bit-identical to the single walk over the full lists, gradients equal up to
+ * the order of the float atomics.  extra / out_extra / v_output_extra / v_extra: the fourth channel of the
+ * _rgbd calls, all NULL for three channels.  stats_out (nullable, int32[2], device-accessible): flagged tiles,
+ * Gaussians kept. */
+size_t gsr_tile_lists_subrange_workspace_bytes(int count, int capacity, int tiles_x, int tiles_y);
+int gsr_tile_lists_subrange(int count, int capacity, const int32_t *order, const void *reach_records,
+                            int tiles_x, int tiles_y, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                            int32_t *count_out, void *workspace, size_t workspace_bytes,
+                            gsr_stream_t stream);
+size_t gsr_saturation_filter_workspace_bytes(int tiles_x, int tiles_y);
+int gsr_saturation_filter(int count, const int32_t *order, void *reach_records, const int32_t *tile_flags,
+                          int tiles_x, int tiles_y, void *workspace, size_t workspace_bytes,
+                          int32_t *stats_out, gsr_stream_t stream);
+int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, unsigned img_width,
+                                unsigned img_height, const int32_t *gaussian_ids_sorted,
+                                const int32_t *tile_bins, int idx_base, const float *xys,
+                                const float *conics, const float *colors, const float *extra,
+                                const float *opacities, const float *background, float extra_background,
+                                float *out_img, float *out_extra, float *final_Ts, int32_t *final_idx,
+                                int32_t *tile_flags, int deep_tile_threshold, float *out_alpha,
+                                void *zero_ptr, size_t zero_bytes, gsr_stream_t stream);
+int gsr_rasterize_backward_two(unsigned img_height, unsigned img_width, int num_points,
+                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                               const int32_t *tile_bins2, int idx_base2, const float *xys,
+                               const float *conics, const float *colors, const float *extra,
+                               const float *opacities, const float *background, float extra_background,
+                               const float *final_Ts, const int32_t *final_idx, const float *v_output,
+                               const float *v_output_extra, const float *v_output_alpha, float *v_xy,
+                               float *v_conic, float *v_colors, float *v_extra, float *v_opacity,
+                               int deep_tile_threshold, int accumulators_zeroed, gsr_stream_t stream);
+
 /* ---- a whole view as ONE call (host-bound scenes and viewer frames) -----
  * The body of GaussianSplattingModel.get_outputs between the raw parameters and the images
  * (gs_toolkit/models/vanilla_gs.py:765-857: activations, project_gaussians, SH + 0.5 clamped,

@@ -825,3 +825,87 @@ def test_scan_mapping_forward_equals_the_serial_walk(n, W, H, ck, kw):
     assert np.array_equal(npy(idx)[ok], ref[2][ok])
     out2, Ts2, idx2 = C.rasterize_forward(d["tb"], (bw, bw, 1), (W, H, 1), *args)
     assert (out - out2).abs()[cu(ok)].max().item() < 2e-6 and (Ts - Ts2).abs()[cu(ok)].max().item() < 2e-6
+
+
+@pytest.mark.parametrize("n,W,H,lo,hi,frac,rgbd", [
+    (60_000, 320, 208, 0.02, 0.12, 0.15, False),    # dense: every tile saturates inside the prefix lists
+    (60_000, 320, 208, 0.02, 0.12, 0.15, True),
+    (20_000, 317, 203, 0.004, 0.03, 0.3, False),    # sparse: background shows, most tiles stay unfinished
+    (150_000, 640, 360, 0.01, 0.06, 0.05, True),    # a short prefix: many tiles need the second round
+    (3_000, 160, 96, 0.01, 0.1, 0.5, False),
+])
+def test_two_round_lists_equal_the_single_walk(n, W, H, lo, hi, frac, rgbd):
+    """Prefix lists + saturation filter + second-round lists + resumed compositing (include/gsraster.h "two-round
+    lists") against ONE walk over the full lists: image, final T (and the depth channel) bit-identical, the last
+    contributing Gaussian of every drawn pixel the same, gradients equal up to the order of the float atomics --
+    whatever the prefix length."""
+    import rasterizer.cuda as C
+
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=11, scale_lo=lo, scale_hi=hi)
+    cov3d, xys, depths, radii, conics, comp, tiles = (cu(a) for a in project_cpu(cam, sc, 16))
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    nt = tb[0] * tb[1]
+    opac = cu(sc["opacities"])
+    rng = np.random.default_rng(5)
+    colors = cu(rng.uniform(0, 1, (n, 3)).astype(np.float32))
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    v_img = cu(rng.uniform(-1, 1, (H, W, 3)).astype(np.float32))
+    v_alpha = cu(rng.uniform(-1, 1, (H, W)).astype(np.float32))
+    v_ext = cu(rng.uniform(-1, 1, (H, W)).astype(np.float32))
+    extra = depths if rgbd else None
+
+    # ---- the single walk over the full (exact) lists
+    counts, recs = C.count_reach(xys, radii, conics, opac, tb)
+    order, cum = C.depth_order(depths, radii, counts)
+    I = int(cum[-1].item())
+    ids, bins = C.bin_sorted(n, I, order, cum, xys, radii, tb, 16, recs)
+    if rgbd:
+        f = C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, xys, conics, colors, depths, opac, bg, 0.0)
+        img0, ext0, T0, idx0 = f[0], f[1], f[2], f[3]
+        g0 = C.rasterize_backward_rgbd(H, W, ids, bins, xys, conics, colors, depths, opac, bg, 0.0, T0, idx0, v_img, v_ext,
+                                       v_alpha)
+    else:
+        img0, T0, idx0 = C.rasterize_forward(tb, (16, 16, 1), (W, H, 1), ids, bins, xys, conics, colors, opac, bg)
+        ext0 = None
+        g0 = C.rasterize_backward(H, W, 16, ids, bins, xys, conics, colors, opac, bg, T0, idx0, v_img, v_alpha)
+
+    # ---- two rounds
+    _, recs2 = C.count_reach(xys, radii, conics, opac, tb, counts=False)
+    n_culled = int((radii <= 0).sum())            # culled Gaussians sit at the FRONT of the depth order (key 0)
+    n1 = n_culled + max(1, int(frac * (n - n_culled)))
+    cap1, cap2 = I + 16, I + 16
+    both = torch.empty(cap1 + cap2, dtype=torch.int32, device=DEV)
+    c1, c2 = (torch.zeros(1, dtype=torch.int32, device=DEV) for _ in range(2))
+    bins1 = C.tile_lists_subrange(order[:n1], cap1, recs2, tb, both[:cap1], c1)
+    flags = torch.zeros(nt, dtype=torch.int32, device=DEV)
+    img = torch.empty(H, W, 3, device=DEV)
+    ext = torch.empty(H, W, device=DEV) if rgbd else None
+    Ts = torch.empty(H, W, device=DEV)
+    idx = torch.empty(H, W, dtype=torch.int32, device=DEV)
+    C.rasterize_forward_round(1, tb, (W, H, 1), both, bins1, 0, xys, conics, colors, extra, opac, bg, 0.0, img, ext, Ts, idx,
+                              flags)
+    stats = torch.zeros(2, dtype=torch.int32, device=DEV)
+    C.saturation_filter(order[n1:], recs2, flags, tb, stats)
+    bins2 = C.tile_lists_subrange(order[n1:], cap2, recs2, tb, both[cap1:], c2)
+    C.rasterize_forward_round(2, tb, (W, H, 1), both, bins2, cap1, xys, conics, colors, extra, opac, bg, 0.0, img, ext, Ts, idx,
+                              None)
+    torch.cuda.synchronize()
+    k1, k2 = int(c1[0]), int(c2[0])
+    assert 0 < k1 <= I and k1 + k2 <= I, (k1, k2, I)   # the filter only ever drops entries
+    assert int(stats[0]) == int(flags.sum()) and 0 <= int(stats[1]) <= n - n1
+    assert torch.equal(img, img0) and torch.equal(Ts, T0)
+    if rgbd:
+        assert torch.equal(ext, ext0)
+    drawn = T0 < 1.0
+    assert torch.equal(both[idx.long()][drawn], ids[idx0.long()][drawn])
+    g = C.rasterize_backward_two(H, W, both, bins1, bins2, cap1, xys, conics, colors, extra, opac, bg, 0.0, Ts, idx, v_img,
+                                 v_ext if rgbd else None, v_alpha)
+    assert len(g) == len(g0)
+    for a, b in zip(g0, g):
+        scale = a.abs().max().item()
+        assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-12
+    # a dense scene: far fewer entries are built than the full lists hold
+    if frac == 0.15:
+        assert k1 + k2 < 0.6 * I, (k1, k2, I)
+    print(f"two rounds: {k1} + {k2} of {I} entries built, {int(stats[0])} of {nt} tiles unfinished after round 1")
