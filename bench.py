@@ -46,6 +46,10 @@ KERNELS = (
     ("count_reach", "count_reach"),
     ("depth_order", "depth_order"),
     ("bin_sorted", "bin_sorted"),
+    ("tile_lists_subrange", "bin_sorted"),       # two-round lists (deep scenes): both partitions and the filter
+    ("saturation_filter", "bin_sorted"),
+    ("rasterize_forward_round", "raster_fwd"),   # ... both compositing rounds
+    ("rasterize_backward_two", "raster_bwd"),
     ("rasterize_forward", "raster_fwd"),
     ("rasterize_forward_ex", "raster_fwd"),
     ("rasterize_forward_rgbd", "raster_fwd"),
@@ -323,7 +327,7 @@ STAGE_KERNELS = {
     "project_fwd": ("project_fwd_kernel",), "sh_fwd": ("sh16_fwd_kernel", "sh_fwd_kernel", "sh_split_fwd_kernel"),
     "count_reach": ("reach_records_kernel", "tile_rows_kernel<false>"),
     "depth_order": ("gsr_sort::", "depth_keys_kernel"),
-    "bin_sorted": ("gsr_p2::", "gsr_ts::", "tile_rows_kernel<true>", "publish_int_kernel"),
+    "bin_sorted": ("gsr_p2::", "gsr_ts::", "tile_rows_kernel<true>", "publish_int_kernel", "tile_flag_", "saturation_filter_kernel"),
     "raster_fwd": ("raster_fwd_tile16_kernel", "raster_fwd_generic_kernel"),
     "raster_bwd": ("raster_bwd_tile16_kernel", "raster_bwd_generic_kernel", "reduce_partials_kernel"),
     "sh_bwd": ("sh16_bwd_kernel", "sh_bwd_kernel", "sh_split_bwd_kernel"), "project_bwd": ("project_bwd_kernel",),
@@ -523,6 +527,12 @@ def main():
     from rasterizer import rasterize as _R
     list_entries = int(_R._bin_cache["value"][0])  # what the kernels walk (dead pairs left out)
     n_visible = int((out["radii"] > 0).sum().item())
+    _aux = _R._bin_cache["value"][3]
+    two_round = None
+    if isinstance(_aux, tuple) and _aux and _aux[0] == "two":  # deep scene: lists in two segments
+        _th = next(iter(_R._two_hint.values()), {})
+        two_round = {"prefix_fraction": round(_th.get("f_used", 0.0), 4), "entries_round1": _th.get("count1"),
+                     "entries_round2": _th.get("count2"), "tiles_unfinished_after_round1": _th.get("unfinished")}
     _bins = _R._bin_cache["value"][2]
     _lens = (_bins[:, 1] - _bins[:, 0]).float().cpu().numpy()
     tile_hist = {"p50": int(np.percentile(_lens, 50)), "p90": int(np.percentile(_lens, 90)),
@@ -691,7 +701,7 @@ def main():
                 "gaussians": N, "visible": n_visible, "intersections": num_intersects,
                 "list_entries": list_entries,
                 "mean_gaussians_per_tile": round(num_intersects / tiles, 1),
-                "tile_list_length": tile_hist, "scene": args.scene,
+                "tile_list_length": tile_hist, "scene": args.scene, "two_round_lists": two_round,
                 "parallelism": (f"dp{world} (per-view; per-parameter all-reduce started from autograd hooks, overlapping "
                                 f"the backward; active SH bands only; "
                                 + ("averaged in the collective, RCCL)" if args.backend == "nccl" else

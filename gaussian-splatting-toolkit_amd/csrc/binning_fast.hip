@@ -565,48 +565,76 @@ GSR_EXPORT int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *o
 // therefore be dropped BEFORE the second round's lists are built -- per Gaussian, with one summed-area
 // lookup, without any per-tile mask inside the partition.
 namespace {
-// sat[(y + 1) * (tiles_x + 1) + (x + 1)] = number of flagged tiles in [0, x] x [0, y]; one workgroup
-__global__ __launch_bounds__(1024) void tile_flag_sat_kernel(const int tiles_x, const int tiles_y,
-                                                             const int *__restrict__ flags, int *__restrict__ sat,
+// sat[(y + 1) * (tiles_x + 1) + (x + 1)] = number of flagged tiles in [0, x] x [0, y]
+// pass 1: one workgroup per tile row, running sums along the row (+ the zero border)
+__global__ __launch_bounds__(256) void tile_flag_rows_kernel(const int tiles_x, const int *__restrict__ flags,
+                                                             int *__restrict__ sat) {
+  __shared__ int wsum[4];
+  __shared__ int carry;
+  const int y = blockIdx.x, tid = threadIdx.x, W = tiles_x + 1;
+  if (tid == 0) carry = 0;
+  if (y == 0)
+    for (int i = tid; i < W; i += 256) sat[i] = 0;
+  if (tid == 0) sat[(y + 1) * W] = 0;
+  __syncthreads();
+  for (int base = 0; base < tiles_x; base += 256) {
+    const int x = base + tid;
+    const int v = x < tiles_x ? (flags[y * tiles_x + x] != 0) : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int k = 0; k < (tid >> 6); ++k) before += wsum[k];
+    if (x < tiles_x) sat[(y + 1) * W + x + 1] = before + incl;
+    __syncthreads();
+    if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+// pass 2: one thread per column, running sums down the rows (coalesced across the threads)
+__global__ __launch_bounds__(256) void tile_flag_cols_kernel(const int tiles_x, const int tiles_y, int *__restrict__ sat,
                                                              int *__restrict__ flagged_out) {
-  const int W = tiles_x + 1;
-  for (int i = threadIdx.x; i < W; i += 1024) sat[i] = 0;
-  for (int y = threadIdx.x; y < tiles_y; y += 1024) {
-    int run = 0;
-    sat[(y + 1) * W] = 0;
-    for (int x = 0; x < tiles_x; ++x) {
-      run += flags[y * tiles_x + x] != 0;
-      sat[(y + 1) * W + x + 1] = run;
-    }
+  const int x = blockIdx.x * 256 + threadIdx.x, W = tiles_x + 1;
+  if (x >= tiles_x) return;
+  int run = 0;
+  for (int y0 = 0; y0 < tiles_y; y0 += 8) {  // eight independent loads in flight per step of the running sum
+    int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = y0 + k < tiles_y ? sat[(y0 + k + 1) * W + x + 1] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (y0 + k < tiles_y) {
+        run += v[k];
+        sat[(y0 + k + 1) * W + x + 1] = run;
+      }
   }
-  __syncthreads();
-  for (int x = threadIdx.x; x < tiles_x; x += 1024) {
-    int run = 0;
-    for (int y = 0; y < tiles_y; ++y) {
-      run += sat[(y + 1) * W + x + 1];
-      sat[(y + 1) * W + x + 1] = run;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && flagged_out) *flagged_out = sat[tiles_y * W + tiles_x];
+  if (x == tiles_x - 1 && flagged_out) *flagged_out = run;
 }
 
+// order_out[i] = order[i] if a tile of the Gaussian's box is still flagged, else `dummy` (the index of a culled
+// record): coalesced, nothing is written into the records.
 __global__ __launch_bounds__(256) void saturation_filter_kernel(const int count, const int *__restrict__ order,
-                                                                SplatRec *__restrict__ recs, const int tiles_x,
-                                                                const int *__restrict__ sat,
+                                                                const SplatRec *__restrict__ recs, const int tiles_x,
+                                                                const int *__restrict__ sat, const int dummy,
+                                                                int *__restrict__ order_out,
                                                                 int *__restrict__ survivors) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   bool keep = false;
   if (i < count) {
     const int g = order[i];
-    const unsigned b0 = recs[g].box0, b1 = recs[g].box1;
-    const int w = (int)(b1 & 0xffffu), h = (int)(b1 >> 16);
+    const uint2 box = *reinterpret_cast<const uint2 *>(&recs[g].box0);
+    const int w = (int)(box.y & 0xffffu), h = (int)(box.y >> 16);
     if (w > 0 && h > 0) {
-      const int x0 = (int)(b0 & 0xffffu), y0 = (int)(b0 >> 16), W = tiles_x + 1;
+      const int x0 = (int)(box.x & 0xffffu), y0 = (int)(box.x >> 16), W = tiles_x + 1;
       const int c = sat[(y0 + h) * W + x0 + w] - sat[y0 * W + x0 + w] - sat[(y0 + h) * W + x0] + sat[y0 * W + x0];
       keep = c > 0;
-      if (!keep) recs[g].box1 = 0u;  // culled: no tile of its box is still unfinished
     }
+    order_out[i] = keep ? g : dummy;
   }
   if (survivors) {
     const unsigned long long m = __ballot(keep);
@@ -620,24 +648,25 @@ GSR_EXPORT size_t gsr_saturation_filter_workspace_bytes(int tiles_x, int tiles_y
   return sizeof(int) * (size_t)(tiles_x + 1) * (size_t)(tiles_y + 1);
 }
 
-GSR_EXPORT int gsr_saturation_filter(int count, const int32_t *order, void *reach_records, const int32_t *tile_flags,
-                                     int tiles_x, int tiles_y, void *workspace, size_t workspace_bytes,
-                                     int32_t *stats_out, gsr_stream_t stream) {
-  GSR_REQUIRE(count >= 0 && tiles_x > 0 && tiles_y > 0 && tiles_x <= 65535 && tiles_y <= 65535,
+GSR_EXPORT int gsr_saturation_filter(int count, const int32_t *order, const void *reach_records, int dummy_index,
+                                     const int32_t *tile_flags, int tiles_x, int tiles_y, int32_t *order_out,
+                                     void *workspace, size_t workspace_bytes, int32_t *stats_out, gsr_stream_t stream) {
+  GSR_REQUIRE(count >= 0 && tiles_x > 0 && tiles_y > 0 && tiles_x <= 65535 && tiles_y <= 65535 && dummy_index >= 0,
               "saturation_filter: bad sizes");
   GSR_REQUIRE(tile_flags && workspace && workspace_bytes >= gsr_saturation_filter_workspace_bytes(tiles_x, tiles_y),
               "saturation_filter: null pointer or workspace too small");
   hipStream_t s = (hipStream_t)stream;
   int *sat = static_cast<int *>(workspace);
-  // stats_out (nullable, int32[2], device-accessible): [0] = unfinished tiles, [1] = Gaussians kept; zeroed here
+  // stats_out (nullable, int32[2], device memory): [0] = flagged tiles, [1] = Gaussians kept; zeroed here
   if (stats_out)
     if (int zrc = gsr_zero_async(stats_out, 2 * sizeof(int32_t), s)) return zrc;
-  hipLaunchKernelGGL(tile_flag_sat_kernel, dim3(1), dim3(1024), 0, s, tiles_x, tiles_y, tile_flags, sat,
+  hipLaunchKernelGGL(tile_flag_rows_kernel, dim3(tiles_y), dim3(256), 0, s, tiles_x, tile_flags, sat);
+  hipLaunchKernelGGL(tile_flag_cols_kernel, dim3(gsr_cdiv(tiles_x, 256)), dim3(256), 0, s, tiles_x, tiles_y, sat,
                      stats_out ? stats_out : (int *)nullptr);
   if (count > 0) {
-    GSR_REQUIRE(order && reach_records, "saturation_filter: null pointer");
+    GSR_REQUIRE(order && reach_records && order_out, "saturation_filter: null pointer");
     hipLaunchKernelGGL(saturation_filter_kernel, dim3(gsr_cdiv(count, 256)), dim3(256), 0, s, count, order,
-                       static_cast<SplatRec *>(reach_records), tiles_x, (const int *)sat,
+                       static_cast<const SplatRec *>(reach_records), tiles_x, (const int *)sat, dummy_index, order_out,
                        stats_out ? stats_out + 1 : (int *)nullptr);
   }
   GSR_CHECK_LAUNCH("saturation_filter");

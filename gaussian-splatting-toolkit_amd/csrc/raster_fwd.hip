@@ -60,11 +60,12 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int round, int *__restrict__ tile_flags, const int idx_base) {
   // Two-round compositing (gsr_rasterize_forward_round): the lists of the nearest
   // Gaussians are a PREFIX of every tile's list.  round 1 composites such prefix lists and leaves the per-pixel
-  // state RAW -- final_Ts = signed T (< 0: finished), out_img / out_extra = C without background, final_idx --
-  // plus tile_flags[tile] = 1 where a pixel is still live; round 2 RESUMES every tile from that state over the
-  // lists of the remaining Gaussians (tile_bins relative to idx_base in ids_sorted) and finalises all pixels.
-  // The per-pixel instruction sequence is that of one walk over the concatenated list: bit-identical results.
-  // round 0: the single walk.
+  // state of a wave that still has a live pixel RAW -- final_Ts = signed T (< 0: finished), out_img / out_extra = C
+  // without background, final_idx -- and sets that wave's sub-tile bits in tile_flags[tile] (zeroed by the caller);
+  // a wave whose pixels have all finished writes its final values as the single walk does.  round 2 RESUMES the
+  // flagged sub-tiles from that state over the lists of the remaining Gaussians (tile_bins relative to idx_base
+  // in ids_sorted) and finalises them; unflagged tiles cost it one load.  The per-pixel instruction sequence is
+  // that of one walk over the concatenated list: bit-identical results.  round 0: the single walk.
   // (gsr_rasterize_forward_ex) the launch also clears `zero_words` words at `zero_ptr` -- the gradient
   // accumulators of the coming backward: 36 MB of stores that vanish inside this VALU-bound kernel
   // instead of a bandwidth-bound launch of their own -- every workgroup its slice, before any exit
@@ -79,8 +80,13 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
 
   int2 range = make_int2(0, 0);
   const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
-  const int tile = job.tile, allowed = job.allowed;
+  const int tile = job.tile;
+  int allowed = job.allowed;
   if (tile < 0) return;
+  if (round == 2) {  // only the sub-tiles round 1 left raw
+    allowed &= tile_flags[tile];
+    if (allowed == 0) return;
+  }
   range.x += idx_base;
   range.y += idx_base;
   const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     live = live_subtiles();
   }
 
-  if (round == 1) {  // raw state + "a pixel of this tile is still live"
-    if (live_subtiles() != 0 && lane == 0) tile_flags[tile] = 1;
+  if (round == 1 && live_subtiles() != 0) {  // a pixel of this wave is still live: raw state, flag its sub-tiles
+    if (lane == 0) atomicOr(&tile_flags[tile], allowed);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
@@ -570,7 +576,7 @@ GSR_EXPORT int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, 
                   final_Ts && final_idx,
               "rasterize_forward_round: null pointer");
   GSR_REQUIRE((extra == nullptr) == (out_extra == nullptr), "rasterize_forward_round: extra and out_extra go together");
-  GSR_REQUIRE(round == 2 || tile_flags != nullptr, "rasterize_forward_round: round 1 needs tile_flags");
+  GSR_REQUIRE(tile_flags != nullptr, "rasterize_forward_round: tile_flags is required");
   GSR_REQUIRE(idx_base >= 0, "rasterize_forward_round: idx_base < 0");
   GSR_REQUIRE(zero_ptr == nullptr || ((zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0 &&
                                       zero_bytes < ((size_t)1 << 34)),

@@ -38,8 +38,6 @@ class _RasterizeRGBD(Function):
 
         n = xys.size(0)
         tile_bounds = ((img_width + BLOCK - 1) // BLOCK, (img_height + BLOCK - 1) // BLOCK, 1)
-        num_intersects, ids, bins, finish = build_tile_lists(
-            xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, BLOCK)
         dev = xys.device
 
         from rasterizer import rasterize as _R
@@ -56,13 +54,46 @@ class _RasterizeRGBD(Function):
                 extra_background, want_alpha=True, zero=acc)
             return img_, ext_, Ts_, idx_
 
+        # deep scenes: lists in two segments, compositing in two rounds (rasterizer/rasterize.py, "two-round lists")
+        state = []
+
+        def round1(ids_, bins1, flags):
+            with torch.cuda.device(dev):
+                state[:] = [torch.empty((img_height, img_width, 3), dtype=torch.float32, device=dev),
+                            torch.empty((img_height, img_width), dtype=torch.float32, device=dev),
+                            torch.empty((img_height, img_width), dtype=torch.float32, device=dev),
+                            torch.empty((img_height, img_width), dtype=torch.int32, device=dev), flags]
+                alpha_out[0] = torch.empty((img_height, img_width), dtype=torch.float32, device=dev)
+            _C.rasterize_forward_round(1, tile_bounds, (img_width, img_height, 1), ids_, bins1, 0, xys, conics, colors,
+                                       extra, opacity, background, extra_background, state[0], state[1], state[2],
+                                       state[3], flags, out_alpha=alpha_out[0], zero=acc)
+
+        def round2(ids_, aux):
+            _C.rasterize_forward_round(2, tile_bounds, (img_width, img_height, 1), ids_, aux[1], aux[2], xys, conics,
+                                       colors, extra, opacity, background, extra_background, state[0], state[1], state[2],
+                                       state[3], state[4], out_alpha=alpha_out[0])
+            return state[0], state[1], state[2], state[3]
+
+        def both_rounds(ids_, bins1, aux):
+            flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=dev)
+            round1(ids_, bins1, flags)
+            return round2(ids_, aux)
+
+        is_two = lambda a: isinstance(a, tuple) and len(a) == 3 and a[0] == "two"
+        num_intersects, ids, bins, finish = build_tile_lists(
+            xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, BLOCK, round1=round1)
+        two_aux = _R.last_list_aux() if is_two(_R.last_list_aux()) else None
         if finish is not None:  # lists sized from the previous view: composite, then check the count
-            img, ext, Ts, idx = composite(ids, bins)
+            if two_aux is not None:
+                img, ext, Ts, idx = round2(ids, two_aux) if state else both_rounds(ids, bins, two_aux)
+            else:
+                img, ext, Ts, idx = composite(ids, bins)
             num_intersects, ids, bins, rebuilt = finish()
             if rebuilt:
-                img, ext, Ts, idx = composite(ids, bins)
+                two_aux = _R.last_list_aux() if is_two(_R.last_list_aux()) else None
+                img, ext, Ts, idx = both_rounds(ids, bins, two_aux) if two_aux is not None else composite(ids, bins)
         elif num_intersects >= 1:
-            img, ext, Ts, idx = composite(ids, bins)
+            img, ext, Ts, idx = both_rounds(ids, bins, two_aux) if two_aux is not None else composite(ids, bins)
         if num_intersects < 1:
             img = torch.ones(img_height, img_width, 3, device=dev) * background
             ext = torch.full((img_height, img_width), float(extra_background), device=dev)
@@ -76,6 +107,7 @@ class _RasterizeRGBD(Function):
             acc, alpha_out[0] = None, None
         ctx.accumulators = acc
         ctx.det = _R.last_list_aux() if (_R.is_deterministic() and num_intersects >= 1) else None
+        ctx.two = (two_aux[1], two_aux[2]) if (two_aux is not None and num_intersects >= 1) else None
         ctx.set_materialize_grads(False)
         ctx.meta = (img_height, img_width, num_intersects, float(extra_background))
         ctx.save_for_backward(ids, bins, xys, conics, colors, extra, opacity, background, Ts, idx)
@@ -92,7 +124,12 @@ class _RasterizeRGBD(Function):
             return (z(xys), None, None, z(conics), None, z(colors), z(extra), z(opacity)) + (None,) * 4
         v_img = torch.zeros(H, W, 3, device=dev) if v_img is None else v_img
         v_ext = torch.zeros(H, W, device=dev) if v_ext is None else v_ext
-        if ctx.det is not None:  # fixed summation order (rasterizer.rasterize.set_deterministic)
+        if ctx.two is not None:
+            acc, ctx.accumulators = ctx.accumulators, None
+            v_xy, v_conic, v_colors, v_extra, v_opacity = _C.rasterize_backward_two(
+                H, W, ids, bins, ctx.two[0], ctx.two[1], xys, conics, colors, extra, opacity, background, ebg, Ts, idx,
+                v_img, v_ext, v_alpha, accumulators=acc)
+        elif ctx.det is not None:  # fixed summation order (rasterizer.rasterize.set_deterministic)
             v_xy, v_conic, v_colors, v_extra, v_opacity = _C.rasterize_backward_det(
                 H, W, ids, bins, xys, conics, colors, opacity, background, Ts, idx, v_img, v_alpha, *ctx.det,
                 extra=extra, extra_background=ebg, v_output_extra=v_ext)

@@ -299,7 +299,8 @@ def publish_int32(src: Tensor, dst: Tensor) -> None:
 
 
 def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
-                tile_bounds: Tuple[int, int, int], bands: int = 1, counts: bool = True) -> Tuple[Optional[Tensor], Tensor]:
+                tile_bounds: Tuple[int, int, int], bands: int = 1, counts: bool = True,
+                extra_rows: int = 0) -> Tuple[Optional[Tensor], Tensor]:
     """``gsr_count_reach``: per Gaussian, the number of 16x16 tiles of its bounding
     box in which it can reach alpha >= 1/255 -> (counts i32[bands*N], band-major, summing to
     <= num_tiles_hit per Gaussian; opaque per-Gaussian records for :func:`bin_sorted`).
@@ -316,7 +317,9 @@ def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
     dev = xys.device
     with torch.cuda.device(dev):
         cnt = torch.empty((int(bands) * n,), dtype=_i32, device=dev) if counts else None
-        recs = torch.empty((n, int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
+        recs = torch.empty((n + int(extra_rows), int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
+        if extra_rows:
+            recs[n:].zero_()  # all-zero records are culled ones (empty tile box): `saturation_filter`'s dummy
         _call("gsr_count_reach", C.c_int(n), _ptr(xys), _ptr(radii), _ptr(conics), _ptr(opacities),
               C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_int(int(bands)),
               _ptr(cnt) if cnt is not None else None, _ptr(recs), _stream(dev))
@@ -399,19 +402,22 @@ def tile_lists_subrange(order_sub: Tensor, capacity: int, reach_records: Tensor,
     return bins
 
 
-def saturation_filter(order_sub: Tensor, reach_records: Tensor, tile_flags: Tensor, tile_bounds,
-                      stats_out: Optional[Tensor] = None) -> None:
-    """``gsr_saturation_filter``: culls (in ``reach_records``) every Gaussian of ``order_sub`` whose tile box
-    holds no flagged tile.  ``tile_flags`` int32[T]; ``stats_out`` int32[2]: flagged tiles, Gaussians kept."""
+def saturation_filter(order_sub: Tensor, reach_records: Tensor, dummy_index: int, tile_flags: Tensor, tile_bounds,
+                      stats_out: Optional[Tensor] = None) -> Tensor:
+    """``gsr_saturation_filter``: -> a copy of ``order_sub`` in which every Gaussian whose tile box holds no flagged
+    tile is replaced by ``dummy_index`` (the row of a culled record, see ``count_reach(extra_rows=1)``).
+    ``tile_flags`` int32[T]; ``stats_out`` int32[2] on the device: flagged tiles, Gaussians kept."""
     _check(order_sub, "order", _i32)
     _check(tile_flags, "tile_flags", _i32)
     dev = tile_flags.device
     with torch.cuda.device(dev):
+        out = torch.empty_like(order_sub)
         nbytes = int(_lib().gsr_saturation_filter_workspace_bytes(C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         _call("gsr_saturation_filter", C.c_int(order_sub.numel()), _ptr(order_sub), _ptr(reach_records),
-              _ptr(tile_flags), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(ws), C.c_size_t(nbytes),
-              _ptr(stats_out) if stats_out is not None else None, _stream(dev))
+              C.c_int(int(dummy_index)), _ptr(tile_flags), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(out),
+              _ptr(ws), C.c_size_t(nbytes), _ptr(stats_out) if stats_out is not None else None, _stream(dev))
+    return out
 
 
 def rasterize_forward_round(rnd: int, tile_bounds, img_size, gaussian_ids_sorted, tile_bins, idx_base: int, xys, conics,
@@ -419,7 +425,8 @@ def rasterize_forward_round(rnd: int, tile_bounds, img_size, gaussian_ids_sorted
                             final_idx, tile_flags, out_alpha=None, zero=None) -> None:
     """``gsr_rasterize_forward_round``: round 1 composites the prefix lists into RAW state (``final_Ts`` signed,
     ``out_img`` / ``out_extra`` without background) and flags the tiles with a live pixel; round 2 resumes over the
-    second lists (``tile_bins`` relative to ``idx_base``) and finalises.  All outputs are caller-owned tensors."""
+    second lists (``tile_bins`` relative to ``idx_base``) and finalises.  All outputs are caller-owned tensors;
+    ``tile_flags`` (int32[T], zeroed before round 1) and ``out_alpha`` go to BOTH rounds."""
     W, H = int(img_size[0]), int(img_size[1])
     dev = xys.device
     nt = tile_bounds[0] * tile_bounds[1]
@@ -429,8 +436,7 @@ def rasterize_forward_round(rnd: int, tile_bounds, img_size, gaussian_ids_sorted
               _ptr(conics), _ptr(colors), _ptr(extra) if extra is not None else None, _ptr(opacities),
               _ptr(background), C.c_float(extra_background), _ptr(out_img),
               _ptr(out_extra) if out_extra is not None else None, _ptr(final_Ts), _ptr(final_idx),
-              _ptr(tile_flags) if tile_flags is not None else None,
-              C.c_int(deep_tile_threshold(tile_bins.shape[0] * 400, nt)),
+              _ptr(tile_flags), C.c_int(deep_tile_threshold(tile_bins.shape[0] * 400, nt)),
               _ptr(out_alpha) if out_alpha is not None else None, _ptr(zero) if zero is not None else None,
               C.c_size_t(zero.numel() * 4 if zero is not None else 0), _stream(dev))
 

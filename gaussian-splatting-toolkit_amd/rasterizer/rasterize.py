@@ -112,6 +112,119 @@ def _speculative_capacity(device, num_points, tile_bounds, exact):
     return cap
 
 
+# ---- two-round lists for deep scenes (include/gsraster.h) ---------------------
+# When the previous view's lists were deep (mean entries per tile above GSR_TWO_ROUND_DEPTH, default 1500) almost
+# every entry lies behind the depth at which its tile saturates.  Then: lists of the nearest Gaussians only (a
+# prefix of the depth order, sized for ~GSR_TWO_ROUND_LEN = 400 entries per tile), a first compositing round, a
+# per-Gaussian filter that drops what can only land in finished tiles, lists of the rest, a second round that
+# resumes.  Bit-identical images; GSR_TWO_ROUND=0 switches it off, =1 forces it (once a count is known).
+_two_hint = {}
+
+
+def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
+    mode = os.environ.get("GSR_TWO_ROUND", "auto")
+    if mode in ("0", "off") or not exact or _deterministic["on"] or not _speculation_enabled():
+        return None
+    if os.environ.get("GSR_TILE_SORT", "")[:1] in ("s", "b"):
+        return None
+    hint = _count_hint.get((device, tile_bounds))
+    if hint is None or hint[0] < 1 or hint[1] < 1:
+        return None
+    key = (device, tile_bounds)
+    th = _two_hint.setdefault(key, {})
+    if th.get("cooldown", 0) > 0:  # the filter dropped too little last time: single rounds for a while
+        th["cooldown"] -= 1
+        return None
+    n_last, count_last = hint
+    tiles = tile_bounds[0] * tile_bounds[1]
+    full = count_last * (num_points / n_last)
+    min_depth = float(os.environ.get("GSR_TWO_ROUND_DEPTH", "1500"))
+    if mode != "1" and (full / tiles < min_depth or num_points < 100_000):
+        return None
+    target = float(os.environ.get("GSR_TWO_ROUND_LEN", "500"))
+    f = th.get("f")
+    if f is None:
+        # the nearest Gaussians are the largest on screen: they hold ~3x their share of the entries
+        f = target * tiles / full / 3.0
+    f = min(0.5, max(0.02, f))
+    th["views"] = th.get("views", 0) + 1
+    if "culled_frac" not in th or th["views"] % 32 == 0:
+        # culled Gaussians sit at the FRONT of the depth order (key 0): the prefix has to start behind them.  Known
+        # read back on the first two-round view and every 32nd after it (one sync)
+        if radii is None:
+            return None
+        th["culled_frac"] = float((radii <= 0).sum().item()) / max(num_points, 1)
+    culled = int(th["culled_frac"] * num_points)
+    n1 = culled + int(f * (num_points - culled))
+    n1 = min(max(256, (n1 + 255) & ~255), num_points)
+    if n1 >= num_points:
+        return None
+    mi = 1 << 20
+    c1, c2 = th.get("count1"), th.get("count2")
+    cap1 = int(1.3 * c1 * (f / th["f_used"])) + (mi >> 2) if (c1 and th.get("f_used")) else int(3.0 * f * full) + mi
+    cap2 = int(1.5 * c2) + mi if c2 is not None else int(1.1 * full) + mi
+    cap1, cap2 = ((cap1 + mi - 1) // mi) * mi, ((cap2 + mi - 1) // mi) * mi
+    # keep the buffer sizes stable from view to view (the caching allocator then hands back the same blocks):
+    # no shrinking unless the need halves
+    last = th.get("caps")
+    if last:
+        if cap1 < last[0] <= 2 * cap1:
+            cap1 = last[0]
+        if cap2 < last[1] <= 2 * cap2:
+            cap2 = last[1]
+    th["caps"] = (cap1, cap2)
+    if cap1 + cap2 >= 2**31 - 1:
+        return None
+    return {"n1": n1, "cap1": cap1, "cap2": cap2, "f": f, "full": full, "target": target, "tiles": tiles, "key": key}
+
+
+def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, plan, remember,
+                     round1):
+    """-> (None, ids, bins1, finish); `round1(ids, bins1, tile_flags)` composites the prefix lists (raw state)."""
+    dev = xys.device
+    n, n1, cap1, cap2 = xys.size(0), plan["n1"], plan["cap1"], plan["cap2"]
+    _, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False, extra_rows=1)
+    order, _ = _C.depth_order(depths, radii, None)
+    with torch.cuda.device(dev):
+        ids = torch.empty((cap1 + cap2,), dtype=torch.int32, device=dev)
+        flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=dev)
+    p1, p2, p4 = (_PendingCount(dev) for _ in range(3))
+    bins1 = _C.tile_lists_subrange(order[:n1], cap1, records, tile_bounds, ids[:cap1], p1.buf)
+    round1(ids, bins1, flags)
+    with torch.cuda.device(dev):
+        stats = torch.empty((2,), dtype=torch.int32, device=dev)
+    order2 = _C.saturation_filter(order[n1:], records, n, flags, tile_bounds, stats)  # row n: the culled dummy record
+    bins2 = _C.tile_lists_subrange(order2, cap2, records, tile_bounds, ids[cap1:], p2.buf)
+    _C.publish_int32(stats[:1], p4.buf)  # tiles with a live pixel after round 1
+    p4.mark()
+    p1.event = p2.event = p4.event
+    aux = ("two", bins2, cap1)
+    _tls.aux = aux
+
+    def finish():
+        c1, c2, unfinished = p1.resolve(), p2.resolve(), p4.resolve()
+        th = _two_hint.setdefault(plan["key"], {})
+        th.update(count1=c1, count2=c2, f_used=plan["f"], unfinished=unfinished)
+        # The filter works per Gaussian: one unfinished tile keeps every Gaussian whose box holds it, so a few per
+        # cent of unfinished tiles keep most of a scene of large splats.  Lengthen the prefix until (almost) no tile
+        # is left; otherwise steer it towards `target` entries per tile in round 1.
+        if unfinished > 0.003 * plan["tiles"]:
+            th["f"] = min(0.5, 1.5 * plan["f"])
+            if plan["f"] >= 0.5 and c2 > 0.5 * max(plan["full"] - c1, 1.0):
+                th["cooldown"] = 50  # the scene does not saturate behind any prefix: single rounds for a while
+        else:
+            th["f"] = max(0.02, plan["f"] * min(1.25, max(0.8, plan["target"] * plan["tiles"] / max(c1, 1))))
+        if c1 > cap1 or c2 > cap2:  # a guess was too small: this view falls back to one exact round
+            th.pop("count1", None), th.pop("count2", None)
+            nn, i2, b2, _ = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width,
+                                         True, remember, speculate=False, round1=None)
+            return nn, i2, b2, True
+        remember(c1 + c2, ids, bins1, aux)
+        return c1 + c2, ids, bins1, False
+
+    return None, ids, bins1, finish
+
+
 class _PendingCount:
     """The real number of list entries on its way to the host: a kernel of
     `gsr_bin_sorted_dev` writes it straight into pinned (device-mapped) host memory
@@ -236,7 +349,8 @@ def rasterize_gaussians(
     )
 
 
-def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width):
+def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width,
+                     round1=None):
     """The per-tile depth-sorted lists every compositing call walks.
 
     -> ``(num_intersects, gaussian_ids_sorted, tile_bins, finish)``.  Either the count is
@@ -245,7 +359,13 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     and ``num_intersects is None``: enqueue the compositing, then call ``finish()`` ->
     ``(num_intersects, gaussian_ids_sorted, tile_bins, rebuilt)``; with ``rebuilt`` the
     guess was too small, the lists were built again and the compositing must be repeated.
-    The result is cached for the next call with the same geometry (the depth pass)."""
+    The result is cached for the next call with the same geometry (the depth pass).
+
+    ``round1(ids, bins1, tile_flags)`` (optional): the caller can composite in two rounds
+    (``_C.rasterize_forward_round``).  On deep scenes the lists then come in two segments: ``bins`` is the
+    first, ``last_list_aux()`` returns ``("two", bins2, idx_base)``, and ``round1`` has already been called
+    on the first segment when this function returns -- the caller runs round 2 (and, for lists from the
+    cache, both rounds)."""
     num_points = xys.size(0)
     tile_bounds = ((img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width, 1)
     key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
@@ -286,18 +406,25 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
                     _tls.aux = cached[3]
                     return cached[:3] + (False,)
                 n, ids, bins, fin = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds,
-                                                 block_width, exact, remember)
+                                                 block_width, exact, remember, round1=None)
                 if fin is not None:
                     n, ids, bins, _ = fin()
                 return n, ids, bins, True
 
+            _tls.aux = cached[3]
             return None, cached[1], cached[2], verify
-    return _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember)
+    return _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember,
+                        round1=round1)
 
 
 def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember,
-                 speculate=True):
+                 speculate=True, round1=None):
     num_points = xys.size(0)
+    if round1 is not None and speculate:
+        plan = _two_round_plan(xys.device, num_points, tile_bounds, exact, radii)
+        if plan is not None:
+            return _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, plan,
+                                    remember, round1)
     # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
     # compute_cumulative_intersects + bin_and_sort_gaussians (bit for bit
     # when not `exact`: tests/test_gpu_kernels.py::
@@ -401,6 +528,7 @@ class _RasterizeGaussians(Function):
         if fused and any(ctx.needs_input_grad[i] for i in (0, 3, 5, 6)) and not _deterministic["on"]:
             acc = _C.backward_accumulators(xys.size(0), 3, xys.device)
         alpha_out = [None]
+        state = []  # two-round compositing: the caller-owned raw state both rounds work on
 
         def composite(ids, bins):
             if not fused:
@@ -410,13 +538,50 @@ class _RasterizeGaussians(Function):
                                                                  zero=acc)
             return img, Ts, idx
 
+        def round1(ids, bins1, flags):
+            dev = xys.device
+            with torch.cuda.device(dev):
+                state[:] = [torch.empty((img_height, img_width, 3), dtype=torch.float32, device=dev),
+                            torch.empty((img_height, img_width), dtype=torch.float32, device=dev),
+                            torch.empty((img_height, img_width), dtype=torch.int32, device=dev), flags]
+                alpha_out[0] = torch.empty((img_height, img_width), dtype=torch.float32, device=dev) if return_alpha else None
+            _C.rasterize_forward_round(1, tile_bounds, img_size, ids, bins1, 0, xys, conics, colors, None, opacity,
+                                       background, 0.0, state[0], None, state[1], state[2], flags, out_alpha=alpha_out[0],
+                                       zero=acc)
+
+        def round2(ids, aux):
+            _C.rasterize_forward_round(2, tile_bounds, img_size, ids, aux[1], aux[2], xys, conics, colors, None, opacity,
+                                       background, 0.0, state[0], None, state[1], state[2], state[3],
+                                       out_alpha=alpha_out[0])
+            return state[0], state[1], state[2]
+
+        def is_two(aux):
+            return isinstance(aux, tuple) and len(aux) == 3 and aux[0] == "two"
+
         num_intersects, gaussian_ids_sorted, tile_bins, finish = build_tile_lists(
-            xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width)
+            xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width,
+            round1=round1 if fused else None)
+        two = is_two(last_list_aux()) and fused
+        two_aux = last_list_aux() if two else None
         if finish is not None:
-            out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
+            if two and state:      # round 1 ran inside build_tile_lists
+                out_img, final_Ts, final_idx = round2(gaussian_ids_sorted, two_aux)
+            elif two:              # cached two-segment lists used speculatively
+                flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=xys.device)
+                round1(gaussian_ids_sorted, tile_bins, flags)
+                out_img, final_Ts, final_idx = round2(gaussian_ids_sorted, two_aux)
+            else:
+                out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
             num_intersects, gaussian_ids_sorted, tile_bins, rebuilt = finish()
             if rebuilt:
-                out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
+                two = is_two(last_list_aux()) and fused
+                two_aux = last_list_aux() if two else None
+                if two:
+                    flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=xys.device)
+                    round1(gaussian_ids_sorted, tile_bins, flags)
+                    out_img, final_Ts, final_idx = round2(gaussian_ids_sorted, two_aux)
+                else:
+                    out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
 
         if num_intersects < 1:
             # nothing on screen: background everywhere (rasterize.py:119-127)
@@ -427,13 +592,19 @@ class _RasterizeGaussians(Function):
             final_idx = torch.zeros(img_height, img_width, device=xys.device)
             acc, alpha_out[0] = None, None
         elif finish is None:
-            out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
+            if two:  # two-segment lists from the cache (the depth pass of a view)
+                flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=xys.device)
+                round1(gaussian_ids_sorted, tile_bins, flags)
+                out_img, final_Ts, final_idx = round2(gaussian_ids_sorted, two_aux)
+            else:
+                out_img, final_Ts, final_idx = composite(gaussian_ids_sorted, tile_bins)
 
         ctx.set_materialize_grads(False)
         ctx.img_width = img_width
         ctx.img_height = img_height
         # deterministic backward: (order, cum_sorted, slot_of_entry) of the lists just used
         ctx.det = last_list_aux() if (_deterministic["on"] and num_intersects >= 1 and colors.shape[-1] == 3) else None
+        ctx.two = (two_aux[1], two_aux[2]) if (two and num_intersects >= 1) else None
         ctx.num_intersects = num_intersects
         ctx.block_width = block_width
         ctx.accumulators = acc  # cleared by the forward launch; used (once) by the backward
@@ -460,7 +631,13 @@ class _RasterizeGaussians(Function):
             v_colors = torch.zeros_like(colors)
             v_opacity = torch.zeros_like(opacity)
         else:
-            if ctx.det is not None:
+            if ctx.two is not None:
+                acc, ctx.accumulators = ctx.accumulators, None
+                v_xy, v_conic, v_colors, v_opacity = _C.rasterize_backward_two(
+                    ctx.img_height, ctx.img_width, gaussian_ids_sorted, tile_bins, ctx.two[0], ctx.two[1], xys, conics,
+                    colors, None, opacity, background, 0.0, final_Ts, final_idx, v_out_img, None, v_out_alpha,
+                    accumulators=acc)
+            elif ctx.det is not None:
                 v_xy, v_conic, v_colors, v_opacity = _C.rasterize_backward_det(
                     ctx.img_height, ctx.img_width, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity,
                     background, final_Ts, final_idx, v_out_img, v_out_alpha, *ctx.det)

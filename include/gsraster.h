@@ -447,13 +447,16 @@ int gsr_rasterize_backward_rgbd(unsigned img_height, unsigned img_width,
  * read) almost every entry lies behind the depth at which its tile's pixels have all finished.  The lists of
  * the NEAREST Gaussians (a prefix of the depth order) are a prefix of every tile's list:
  *   1. gsr_tile_lists_subrange over order[0 : n1]            -> lists 1 (ids at gaussian_ids_sorted + 0)
- *   2. gsr_rasterize_forward_round(1, lists 1)               -> raw per-pixel state + tile_flags (1 = a pixel
- *                                                               of the tile is still live; zero them first)
- *   3. gsr_saturation_filter over order[n1 : n]              -> culls (in reach_records) every remaining Gaussian
- *                                                               whose tile box holds no flagged tile
+ *   2. gsr_rasterize_forward_round(1, lists 1)               -> final values where every pixel has finished, raw
+ *                                                               per-pixel state + tile_flags (bit p: sub-tile p
+ *                                                               holds raw state; zero them first) elsewhere
+ *   3. gsr_saturation_filter over order[n1 : n]              -> order_out: the same ids, with `dummy_index` (the
+ *                                                               index of a culled record, e.g. one appended row)
+ *                                                               in place of every Gaussian whose tile box holds
+ *                                                               no flagged tile
  *   4. gsr_tile_lists_subrange over order[n1 : n]            -> lists 2 (ids at gaussian_ids_sorted + idx_base,
  *                                                               tile_bins2 relative to idx_base)
- *   5. gsr_rasterize_forward_round(2, lists 2, idx_base)     -> resumes every tile, finalises every pixel
+ *   5. gsr_rasterize_forward_round(2, lists 2, idx_base)     -> resumes and finalises the flagged sub-tiles
  *   6. gsr_rasterize_backward_two(tile_bins, tile_bins2, idx_base)
  * A tile's list is its range in tile_bins followed by its range in tile_bins2; per pixel the instruction
  * sequence is that of one walk over the concatenation, so images, final_Ts and final_idx (an index into
@@ -467,9 +470,10 @@ int gsr_tile_lists_subrange(int count, int capacity, const int32_t *order, const
                             int32_t *count_out, void *workspace, size_t workspace_bytes,
                             gsr_stream_t stream);
 size_t gsr_saturation_filter_workspace_bytes(int tiles_x, int tiles_y);
-int gsr_saturation_filter(int count, const int32_t *order, void *reach_records, const int32_t *tile_flags,
-                          int tiles_x, int tiles_y, void *workspace, size_t workspace_bytes,
-                          int32_t *stats_out, gsr_stream_t stream);
+int gsr_saturation_filter(int count, const int32_t *order, const void *reach_records, int dummy_index,
+                          const int32_t *tile_flags, int tiles_x, int tiles_y, int32_t *order_out,
+                          void *workspace, size_t workspace_bytes, int32_t *stats_out,
+                          gsr_stream_t stream);
 int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, unsigned img_width,
                                 unsigned img_height, const int32_t *gaussian_ids_sorted,
                                 const int32_t *tile_bins, int idx_base, const float *xys,

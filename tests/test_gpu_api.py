@@ -989,3 +989,55 @@ def test_interleaved_forwards_from_two_threads_keep_their_own_lists():
                     assert torch.equal(a, b)
     finally:
         R.set_deterministic(False)
+
+
+@pytest.mark.parametrize("render_depth,fused_depth", [(False, False), (True, False), (True, True)])
+def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monkeypatch):
+    """Deep scenes composite in two rounds (prefix lists, saturation filter, resumed walk): through
+    `rasterize_gaussians` (and its cached depth pass, and the one-pass RGB + depth op) images are bit-identical to the
+    single walk and gradients equal up to the order of the float atomics -- on the first two-round view and on the
+    ones that size their lists from it."""
+    from rasterizer import rasterize as R
+
+    W, H, n = 400, 240, 120_000
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=1, seed=3, scale_lo=0.02, scale_hi=0.1)
+    camt = CameraTensors.from_numpy(cam, DEV)
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    g = torch.Generator(device=DEV).manual_seed(2)
+    v_img = torch.rand(H, W, 3, device=DEV, generator=g) * 2 - 1
+    v_alpha = torch.rand(H, W, 1, device=DEV, generator=g) * 2 - 1
+    v_dep = torch.rand(H, W, 1, device=DEV, generator=g) * 2 - 1
+
+    def run():
+        p = {k: cu(v, True) for k, v in sc.items()}
+        out = render_view(p["means3d"], p["scales"], p["quats"], p["opacities"], p["sh_coeffs"], camt, bg, 1,
+                          clamp_rgb=False, render_depth=render_depth, fused_depth=fused_depth)
+        outs, cots = [out["rgb"], out["alpha"]], [v_img, v_alpha]
+        if render_depth:
+            outs.append(out["depth"])
+            cots.append(v_dep * (out["alpha"] > 0))
+        torch.autograd.backward(outs, cots)
+        torch.cuda.synchronize()
+        return out, [p[k].grad.clone() for k in ("means3d", "scales", "quats", "opacities", "sh_coeffs")]
+
+    monkeypatch.setenv("GSR_TWO_ROUND", "0")
+    R._bin_cache["key"] = None
+    run()                      # first view: exact sizing, leaves the count hint
+    ref, gref = run()
+    monkeypatch.setenv("GSR_TWO_ROUND", "1")
+    R._two_hint.clear()
+    seen = []
+    orig = R._build_two_round
+    monkeypatch.setattr(R, "_build_two_round", lambda *a, **k: (seen.append(1), orig(*a, **k))[1])
+    for view in range(3):
+        R._bin_cache["key"] = None
+        out, grads = run()
+        assert torch.equal(out["rgb"], ref["rgb"]) and torch.equal(out["alpha"], ref["alpha"]), view
+        if render_depth:
+            assert torch.equal(out["depth"], ref["depth"]), view
+        for a, b in zip(gref, grads):
+            assert (a - b).abs().max().item() <= 3e-5 * a.abs().max().item() + 1e-12, view
+    assert len(seen) == 3  # every one of them went through the two-round builder
+    hint = next(iter(R._two_hint.values()))
+    assert hint["count1"] > 0 and hint["count1"] + hint["count2"] < 0.9 * R._count_hint[(torch.device(DEV), ((W + 15) // 16, (H + 15) // 16, 1))][1]

@@ -871,7 +871,7 @@ def test_two_round_lists_equal_the_single_walk(n, W, H, lo, hi, frac, rgbd):
         g0 = C.rasterize_backward(H, W, 16, ids, bins, xys, conics, colors, opac, bg, T0, idx0, v_img, v_alpha)
 
     # ---- two rounds
-    _, recs2 = C.count_reach(xys, radii, conics, opac, tb, counts=False)
+    _, recs2 = C.count_reach(xys, radii, conics, opac, tb, counts=False, extra_rows=1)
     n_culled = int((radii <= 0).sum())            # culled Gaussians sit at the FRONT of the depth order (key 0)
     n1 = n_culled + max(1, int(frac * (n - n_culled)))
     cap1, cap2 = I + 16, I + 16
@@ -886,14 +886,14 @@ def test_two_round_lists_equal_the_single_walk(n, W, H, lo, hi, frac, rgbd):
     C.rasterize_forward_round(1, tb, (W, H, 1), both, bins1, 0, xys, conics, colors, extra, opac, bg, 0.0, img, ext, Ts, idx,
                               flags)
     stats = torch.zeros(2, dtype=torch.int32, device=DEV)
-    C.saturation_filter(order[n1:], recs2, flags, tb, stats)
-    bins2 = C.tile_lists_subrange(order[n1:], cap2, recs2, tb, both[cap1:], c2)
+    order2 = C.saturation_filter(order[n1:], recs2, n, flags, tb, stats)
+    bins2 = C.tile_lists_subrange(order2, cap2, recs2, tb, both[cap1:], c2)
     C.rasterize_forward_round(2, tb, (W, H, 1), both, bins2, cap1, xys, conics, colors, extra, opac, bg, 0.0, img, ext, Ts, idx,
-                              None)
+                              flags)
     torch.cuda.synchronize()
     k1, k2 = int(c1[0]), int(c2[0])
     assert 0 < k1 <= I and k1 + k2 <= I, (k1, k2, I)   # the filter only ever drops entries
-    assert int(stats[0]) == int(flags.sum()) and 0 <= int(stats[1]) <= n - n1
+    assert int(stats[0]) == int((flags != 0).sum()) and 0 <= int(stats[1]) <= n - n1
     assert torch.equal(img, img0) and torch.equal(Ts, T0)
     if rgbd:
         assert torch.equal(ext, ext0)
