@@ -208,7 +208,14 @@ def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bo
         # The filter works per Gaussian: one unfinished tile keeps every Gaussian whose box holds it, so a few per
         # cent of unfinished tiles keep most of a scene of large splats.  Lengthen the prefix until (almost) no tile
         # is left; otherwise steer it towards `target` entries per tile in round 1.
-        if unfinished > 0.003 * plan["tiles"]:
+        if unfinished > 0.3 * plan["tiles"]:
+            # nothing saturates here (background shows through, or the count hint came from another scene): with
+            # most tiles unfinished hardly anything was filtered, so c1 + c2 IS the full count -- single rounds for
+            # a while, sized from it
+            th["cooldown"] = 50
+            th.pop("f", None)
+            _note_count(xys.device, n, tile_bounds, c1 + c2)
+        elif unfinished > 0.003 * plan["tiles"]:
             th["f"] = min(0.5, 1.5 * plan["f"])
             if plan["f"] >= 0.5 and c2 > 0.5 * max(plan["full"] - c1, 1.0):
                 th["cooldown"] = 50  # the scene does not saturate behind any prefix: single rounds for a while
@@ -367,6 +374,7 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     on the first segment when this function returns -- the caller runs round 2 (and, for lists from the
     cache, both rounds)."""
     num_points = xys.size(0)
+    _tls.aux = None  # (what the PREVIOUS call of this thread left: every path below sets its own)
     tile_bounds = ((img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width, 1)
     key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
     # With 16x16 tiles the lists leave out the (Gaussian, tile) pairs that cannot

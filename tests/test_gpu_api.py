@@ -561,12 +561,14 @@ def test_binning_cache_tracks_opacity_and_conics():
     assert np.abs(c.cpu().numpy() - img)[ok].max() < 1e-4
 
 
-def test_speculative_list_sizing_never_changes_results():
+def test_speculative_list_sizing_never_changes_results(monkeypatch):
     """From the second view on the lists are sized from the previous count and the
     real count is checked after compositing was enqueued (rasterize.py): a right
     guess, a guess that is far too small (lists cut, then rebuilt) and the
     synchronous path give identical images and gradients."""
     import rasterizer.cuda as C
+
+    monkeypatch.setenv("GSR_TWO_ROUND", "0")  # (this scene is deep enough for two-round lists: not what is tested here)
     from rasterizer import project_gaussians, rasterize_gaussians
     from rasterizer import rasterize as R
 
@@ -1039,5 +1041,24 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
         for a, b in zip(gref, grads):
             assert (a - b).abs().max().item() <= 3e-5 * a.abs().max().item() + 1e-12, view
     assert len(seen) == 3  # every one of them went through the two-round builder
+    # a shallow view right behind a two-round one takes the single walk again -- with ITS lists (the per-call
+    # state of the previous view must not leak into it: a regression test)
+    monkeypatch.setenv("GSR_TWO_ROUND", "auto")
+    sc2 = S.make_scene(5_000, cam, sh_degree=1, seed=4, scale_lo=0.003, scale_hi=0.02)
+
+    def run_small():
+        R._bin_cache["key"] = None
+        p2 = {k: cu(v, True) for k, v in sc2.items()}
+        o = render_view(p2["means3d"], p2["scales"], p2["quats"], p2["opacities"], p2["sh_coeffs"], camt, bg, 1,
+                        clamp_rgb=False, render_depth=render_depth, fused_depth=fused_depth)
+        o["rgb"].backward(v_img)
+        torch.cuda.synchronize()
+        return o["rgb"].detach().clone(), p2["means3d"].grad.clone()
+
+    a_img, a_g = run_small()
+    assert len(seen) == 3
+    monkeypatch.setenv("GSR_TWO_ROUND", "0")
+    b_img, b_g = run_small()
+    assert torch.equal(a_img, b_img) and (a_g - b_g).abs().max().item() <= 3e-5 * b_g.abs().max().item() + 1e-12
     hint = next(iter(R._two_hint.values()))
     assert hint["count1"] > 0 and hint["count1"] + hint["count2"] < 0.9 * R._count_hint[(torch.device(DEV), ((W + 15) // 16, (H + 15) // 16, 1))][1]
