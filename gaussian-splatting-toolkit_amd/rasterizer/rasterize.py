@@ -212,7 +212,8 @@ def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bo
             # nothing saturates here (background shows through, or the count hint came from another scene): with
             # most tiles unfinished hardly anything was filtered, so c1 + c2 IS the full count -- single rounds for
             # a while, sized from it
-            th["cooldown"] = 50
+            th["fails"] = min(th.get("fails", 0) + 1, 7)
+            th["cooldown"] = 25 << th["fails"]  # 50, 100, ... 3200 views between attempts while they keep failing
             th.pop("f", None)
             _note_count(xys.device, n, tile_bounds, c1 + c2)
         elif unfinished > 0.003 * plan["tiles"]:
@@ -220,6 +221,7 @@ def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bo
             if plan["f"] >= 0.5 and c2 > 0.5 * max(plan["full"] - c1, 1.0):
                 th["cooldown"] = 50  # the scene does not saturate behind any prefix: single rounds for a while
         else:
+            th["fails"] = 0
             th["f"] = max(0.02, plan["f"] * min(1.25, max(0.8, plan["target"] * plan["tiles"] / max(c1, 1))))
         if c1 > cap1 or c2 > cap2:  # a guess was too small: this view falls back to one exact round
             th.pop("count1", None), th.pop("count2", None)

@@ -1041,6 +1041,8 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
         for a, b in zip(gref, grads):
             assert (a - b).abs().max().item() <= 3e-5 * a.abs().max().item() + 1e-12, view
     assert len(seen) == 3  # every one of them went through the two-round builder
+    hint = next(iter(R._two_hint.values()))
+    assert hint["count1"] > 0 and hint["count1"] + hint["count2"] < 0.9 * R._count_hint[(torch.device(DEV), ((W + 15) // 16, (H + 15) // 16, 1))][1]
     # a shallow view right behind a two-round one takes the single walk again -- with ITS lists (the per-call
     # state of the previous view must not leak into it: a regression test)
     monkeypatch.setenv("GSR_TWO_ROUND", "auto")
@@ -1060,5 +1062,3 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
     monkeypatch.setenv("GSR_TWO_ROUND", "0")
     b_img, b_g = run_small()
     assert torch.equal(a_img, b_img) and (a_g - b_g).abs().max().item() <= 3e-5 * b_g.abs().max().item() + 1e-12
-    hint = next(iter(R._two_hint.values()))
-    assert hint["count1"] > 0 and hint["count1"] + hint["count2"] < 0.9 * R._count_hint[(torch.device(DEV), ((W + 15) // 16, (H + 15) // 16, 1))][1]
