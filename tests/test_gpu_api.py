@@ -279,6 +279,21 @@ def test_random_view_sequences_equal_unspeculated_calls():
     assert out.stdout.count(": ok") == 80
 
 
+def test_random_view_sequences_with_two_round_lists_forced():
+    """The same random sequences with GSR_TWO_ROUND=1: every view behind the first builds its lists in two rounds
+    (whatever the scene: shallow, deep, nothing saturating, guessed sizes overflowing) and must still equal the
+    unspeculated, uncached single walk."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSR_TWO_ROUND="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_sequence.py"), "80", "23"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(": ok") == 80
+
+
 def test_empty_scene_and_all_culled():
     from rasterizer import project_gaussians, rasterize_gaussians
 
