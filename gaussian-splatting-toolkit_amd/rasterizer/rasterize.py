@@ -139,9 +139,13 @@ def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
     tiles = tile_bounds[0] * tile_bounds[1]
     full = count_last * (num_points / n_last)
     min_depth = float(os.environ.get("GSR_TWO_ROUND_DEPTH", "1500"))
-    if mode != "1" and (full / tiles < min_depth or num_points < 100_000):
-        return None
     target = float(os.environ.get("GSR_TWO_ROUND_LEN", "500"))
+    # two rounds cost ~0.3 ms (14 more launches, and the count check has little GPU work left to hide behind); a
+    # list entry that is never built saves ~8 ps: worth it from ~45 M avoided entries on (3 M Gaussians at 1080p,
+    # 33 M entries: break-even; 3 M at 4K, 98 M: -13 %)
+    min_saved = float(os.environ.get("GSR_TWO_ROUND_SAVED", "45e6"))
+    if mode != "1" and (full / tiles < min_depth or full - target * tiles < min_saved or num_points < 100_000):
+        return None
     f = th.get("f")
     if f is None:
         # the nearest Gaussians are the largest on screen: they hold ~3x their share of the entries
