@@ -17,6 +17,7 @@ the same memory), and an in-place update bumps the version and misses.
 """
 import os
 import threading
+import time
 from typing import Optional
 
 import torch
@@ -248,14 +249,19 @@ class _PendingCount:
     # its own slot, so forwards interleaved on one device (side streams, an eval thread)
     # cannot overwrite each other's published count
 
+    PENDING = -2147483647  # what a slot holds until the kernel has written it (no count is ever that)
+
     def __init__(self, device):
         with _state_lock:
             ring = _pinned_count.get(device)
             if ring is None:
-                ring = _pinned_count[device] = [torch.empty(self.SLOTS, dtype=torch.int32, pin_memory=True), 0]
+                pinned = torch.empty(self.SLOTS, dtype=torch.int32, pin_memory=True)
+                ring = _pinned_count[device] = [pinned, 0, pinned.numpy()]  # the same memory, cheap to poll
             slot = ring[1]
             ring[1] = (slot + 1) % self.SLOTS
         self.buf = ring[0][slot:slot + 1]
+        self._np = ring[2][slot:slot + 1]
+        self._np[0] = self.PENDING
         self.device = device
         self.event = None
 
@@ -264,8 +270,16 @@ class _PendingCount:
         self.event.record(torch.cuda.current_stream(self.device))
 
     def resolve(self) -> int:
-        self.event.synchronize()
-        count = int(self.buf[0])
+        # The value lands in host memory the moment the publishing kernel writes it -- earlier than the event
+        # behind the whole call fires, and without the wake-up latency of a blocking wait: poll it (the host has
+        # nothing else to do here, and every microsecond it wakes up earlier is GPU work queued earlier).  A value
+        # that does not arrive within 2 ms is waited for the ordinary way.
+        t0 = time.perf_counter()
+        while self._np[0] == self.PENDING:
+            if time.perf_counter() - t0 > 2e-3:
+                self.event.synchronize()
+                break
+        count = int(self._np[0])
         if count < 0:  # the int32 count wrapped (more than 2^31 - 1 intersections)
             raise RuntimeError("rasterize_gaussians: the number of (Gaussian, tile) intersections does not fit the "
                                "int32 lists (the reference's cum_tiles_hit is int32 as well)")
