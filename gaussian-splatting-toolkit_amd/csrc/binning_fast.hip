@@ -17,6 +17,7 @@
 // instead of 164 B (12 B emission + six 24-B passes over 64-bit keys + 8 B).
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -31,6 +32,10 @@ int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, vo
 size_t gsr_sort_mid_depth_extra(int n, int rows);
 int gsr_sort_mid_depth(int n, const float *depths, const int *radii, const int *counts, int rows, int *order,
                        int *cum, void *workspace, size_t workspace_bytes, hipStream_t s);
+size_t gsr_sort_bucket_workspace_bytes(int n);
+int gsr_sort_bucket_wave_cap(void);
+int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *order, void *workspace,
+                          size_t workspace_bytes, int *stats, hipStream_t s);
 int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsigned *keys_out,
                        int *vals_out, int key_bits, void *workspace, size_t workspace_bytes,
                        hipStream_t s);
@@ -55,6 +60,55 @@ namespace {
 // the purpose-built sort wins between these sizes; rocPRIM elsewhere
 constexpr int kMidSortMin = 1 << 16, kMidSortMax = 1 << 22;
 inline bool use_mid_sort(int n) { return n > kMidSortMin && n <= kMidSortMax; }
+// Order only (no counts to carry along): one bucket pass + one in-LDS pass (sort_bucket.hip), as long as the buckets
+// of recent views fit its in-LDS paths.  The bucket sort is correct for any input but slow on pathological ones (a
+// million equal or almost equal depths end in one bucket); every call publishes its largest bucket to a pinned
+// word, and a call that finds the last published value too large sorts with the four LSD passes instead -- and so do
+// the next 32, 64, ... calls.  The hint is read without synchronisation (it lags by the views in flight) and never
+// changes a result.  GSR_DEPTH_SORT=radix | bucket pins the choice (A/B measurements, tests).
+struct BucketHint {
+  int *pinned = nullptr;  // [0]: largest visible bucket of the most recent bucket sort that finished
+  int cooldown = 0, fails = 0;
+};
+BucketHint g_bucket_hint[16];
+std::mutex g_bucket_hint_mutex;
+
+// -> use the bucket sort; *stats: where the call publishes (nullptr: nowhere)
+inline bool use_bucket_sort(int n, bool order_only, hipStream_t s, int **stats) {
+  *stats = nullptr;
+  if (!order_only || !use_mid_sort(n)) return false;
+  const char *e = getenv("GSR_DEPTH_SORT");
+  if (e && e[0] == 'r') return false;
+  if (e && e[0] == 'b') return true;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
+  std::lock_guard<std::mutex> lock(g_bucket_hint_mutex);
+  BucketHint &h = g_bucket_hint[dev];
+  if (!h.pinned) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return true;  // (no allocation inside a capture)
+    if (hipHostMalloc(reinterpret_cast<void **>(&h.pinned), 64, hipHostMallocDefault) != hipSuccess) {
+      h.pinned = nullptr;
+      (void)hipGetLastError();
+      return true;
+    }
+    h.pinned[0] = 0;
+  }
+  if (h.cooldown > 0) {
+    --h.cooldown;
+    return false;
+  }
+  const int largest = *reinterpret_cast<volatile int *>(h.pinned);
+  if (largest > gsr_sort_bucket_wave_cap()) {
+    h.cooldown = 32 << std::min(h.fails, 6);
+    ++h.fails;
+    h.pinned[0] = 0;  // (the next bucket sort reports afresh)
+    return false;
+  }
+  if (largest > 0) h.fails = 0;
+  *stats = h.pinned;
+  return true;
+}
 
 // element j of the (band, depth position) sequence the tile counts are scanned in:
 // counts[band j / n][order[j % n]]
@@ -302,7 +356,8 @@ GSR_EXPORT size_t gsr_depth_order_workspace_bytes(int num_points, int num_bands)
   const size_t rocprim_need = kb + align_up(std::max(depth_sort_temp(num_points), st));
   const size_t mid_need = align_up(std::max(gsr_sort_mid_workspace_bytes(num_points) +
                                                 gsr_sort_mid_depth_extra(num_points, num_bands), st));
-  return kb + (use_mid_sort(num_points) ? mid_need : rocprim_need);
+  const size_t need = kb + (use_mid_sort(num_points) ? mid_need : rocprim_need);
+  return use_mid_sort(num_points) ? std::max(need, gsr_sort_bucket_workspace_bytes(num_points)) : need;
 }
 
 GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
@@ -327,6 +382,9 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   unsigned *keys_in = reinterpret_cast<unsigned *>(ws);
   char *rest = ws + kb;
   size_t rest_bytes = workspace_bytes - kb;
+  int *bucket_stats = nullptr;
+  if (use_bucket_sort(num_points, order_only, s, &bucket_stats))
+    return gsr_sort_bucket_depth(num_points, depths, radii, order, workspace, workspace_bytes, bucket_stats, s);
   if (use_mid_sort(num_points))  // keys, sort, gather of the counts and their scan in 13 launches (sort_mid.hip)
     return gsr_sort_mid_depth(num_points, depths, radii, num_tiles_hit, num_bands, order, cum_sorted, rest,
                               rest_bytes, s);

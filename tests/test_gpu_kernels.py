@@ -397,6 +397,58 @@ def test_depth_order_sort_is_exact_and_stable(n, dist):
     assert np.array_equal(npy(cum), np.cumsum(tiles[ref]).astype(np.int32))
 
 
+def _depth_distributions(n, rng):
+    yield "two_octaves", rng.uniform(2.5, 7.5, n)
+    yield "seventeen_octaves", rng.uniform(0.01, 1000.0, n)
+    yield "equal", np.full(n, 3.25)
+    yield "two_values", rng.choice([2.0, 7.5], n)
+    yield "sorted", np.linspace(0.5, 50.0, n)
+    yield "reversed", np.linspace(50.0, 0.5, n)
+    yield "one_bucket", np.float32(4.0) + rng.integers(0, 200, n).astype(np.float32) * np.float32(4.7683716e-07)
+    yield "normal", np.abs(rng.normal(5.0, 0.7, n)) + 0.2
+    d = rng.uniform(1.0, 100.0, n)
+    d[: n // 2] = np.float32(1.0) + rng.integers(0, 400_000, n // 2).astype(np.float32) * np.float32(1.1920929e-07)
+    yield "half_in_one_bucket", d
+    d = rng.uniform(1.0, 100.0, n)
+    d[: n // 2] = 1.5
+    yield "half_equal", d
+    yield "lognormal", np.exp(rng.normal(1.0, 1.0, n))
+    yield "every_octave", np.exp(rng.uniform(-80, 80, n))
+    d = rng.uniform(2.0, 6.0, n)
+    d[rng.integers(0, n, 40)] = rng.uniform(1e-6, 1e-3, 40)   # a few keys far outside the sampled octaves:
+    d[rng.integers(0, n, 40)] = rng.uniform(1e4, 1e9, 40)     # the underflow / overflow buckets
+    yield "outliers", d
+    yield "by_position", np.sort(rng.uniform(0.3, 30.0, n))[np.argsort(np.arange(n) % 977, kind="stable")]
+
+
+@pytest.mark.parametrize("n", [65_537, 300_000, 1_000_003, 1_572_865, 3_000_000, 4_194_304])
+@pytest.mark.parametrize("mode", ["bucket", "auto"])
+def test_depth_order_without_counts_bucket_sort(n, mode, monkeypatch):
+    """The order-only depth sort (lists without counts: the product path at >= 1 M list entries): one bucket pass + one
+    in-LDS pass (sort_bucket.hip) == stable argsort by (depth, index), culled splats first, for depth distributions
+    that stress the sampled bucket map -- many octaves, one octave, one bucket, clusters of equal keys, outliers
+    beyond the sampled octaves, 4096 and 8192 buckets.  `auto` lets the pinned hint send calls back to the four
+    LSD passes after a view whose buckets overflowed: the result may never depend on the choice."""
+    import rasterizer.cuda as C
+
+    if mode == "auto":
+        monkeypatch.delenv("GSR_DEPTH_SORT", raising=False)
+    else:
+        monkeypatch.setenv("GSR_DEPTH_SORT", "bucket")
+    rng = np.random.default_rng(n % 1013)
+    for name, d in _depth_distributions(n, rng):
+        if n > 2_000_000 and name in ("equal", "two_values", "one_bucket", "half_equal"):
+            continue  # (tens of ms each on the slow path; covered at the smaller sizes)
+        d = d.astype(np.float32)
+        radii = np.ones(n, np.int32)
+        radii[rng.integers(0, n, n // 7)] = 0
+        order, cum = C.depth_order(cu(d), cu(radii), None)
+        assert cum is None
+        key = np.where(radii > 0, d, 0).astype(np.float32)
+        ref = np.argsort(key.view(np.uint32), kind="stable").astype(np.int32)
+        assert np.array_equal(npy(order), ref), (name, n, mode)
+
+
 @pytest.mark.parametrize("n,W,H,ck,opac_hi", [(3000, 160, 96, {}, 1.0), (20_000, 317, 203, {"yaw": 0.3}, 1.0),
                                              (5000, 256, 256, {}, 0.02), (200_000, 640, 360, {}, 1.0),
                                              (30_000, 3840, 2160, {}, 1.0), (20_000, 2560, 1440, {"yaw": 0.2}, 1.0)])
