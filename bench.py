@@ -45,6 +45,7 @@ KERNELS = (
     ("compute_sh_forward", "sh_fwd"),
     ("count_reach", "count_reach"),
     ("depth_order", "depth_order"),
+    ("reach_records_depth_order", "depth_order"),  # records + order in one call (the records ride in the sort's first launch)
     ("bin_sorted", "bin_sorted"),
     ("tile_lists_subrange", "bin_sorted"),       # two-round lists (deep scenes): both partitions and the filter
     ("saturation_filter", "bin_sorted"),
@@ -326,7 +327,7 @@ def cpu_baseline_one_thread(sc, cam, bg, v_img, v_alpha, deg, budget_gaussians=6
 STAGE_KERNELS = {
     "project_fwd": ("project_fwd_kernel",), "sh_fwd": ("sh16_fwd_kernel", "sh_fwd_kernel", "sh_split_fwd_kernel"),
     "count_reach": ("reach_records_kernel", "tile_rows_kernel<false>"),
-    "depth_order": ("gsr_sort::", "depth_keys_kernel"),
+    "depth_order": ("gsr_sort::", "gsr_bsort::", "depth_keys_kernel"),
     "bin_sorted": ("gsr_p2::", "gsr_ts::", "tile_rows_kernel<true>", "publish_int_kernel", "tile_flag_", "saturation_filter_kernel"),
     "raster_fwd": ("raster_fwd_tile16_kernel", "raster_fwd_generic_kernel"),
     "raster_bwd": ("raster_bwd_tile16_kernel", "raster_bwd_generic_kernel", "reduce_partials_kernel"),
@@ -601,6 +602,8 @@ def main():
         # the stages as BUILT move other bytes than the reference's scan / map / sort / bin-edges
         # organisation SURVEY prices: per-stage figures use these
         alg.update(S.built_pipeline_bytes(N, list_entries, tiles))
+        if not timers.pairs["count_reach"] and timers.pairs["depth_order"]:
+            alg["depth_order"] += alg["count_reach"]  # one call wrote the records too (gsr_reach_records_depth_order)
         step_ms_by_stage = timers.total_ms(bracketed_steps)
         # the dominant stage is the one with the most time per STEP (calls x mean), not per call
         dominant = max(step_ms_by_stage, key=lambda k: step_ms_by_stage[k])

@@ -35,7 +35,8 @@ int gsr_sort_mid_depth(int n, const float *depths, const int *radii, const int *
 size_t gsr_sort_bucket_workspace_bytes(int n);
 int gsr_sort_bucket_wave_cap(void);
 int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *order, void *workspace,
-                          size_t workspace_bytes, int *stats, hipStream_t s);
+                          size_t workspace_bytes, int *stats, const float *xys, const float *conics,
+                          const float *opacities, int tiles_x, int tiles_y, void *recs, hipStream_t s);
 int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsigned *keys_out,
                        int *vals_out, int key_bits, void *workspace, size_t workspace_bytes,
                        hipStream_t s);
@@ -129,37 +130,6 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(const int n, const floa
   // visible splats have depth > 0 (bit pattern orders like the value); culled
   // ones emit nothing, park them at the front
   keys[i] = radii[i] > 0 ? __float_as_uint(depths[i]) : 0u;
-}
-
-// The per-Gaussian record of the list builders: centre, conic, the sigma bound of the exact
-// reach test and the tile box (conics == nullptr: every box tile counts, smax = inf).
-__device__ __forceinline__ SplatRec make_splat_record(const int g, const float *__restrict__ xys,
-                                                      const int *__restrict__ radii,
-                                                      const float *__restrict__ conics,
-                                                      const float *__restrict__ opacities, const int tiles_x,
-                                                      const int tiles_y, const int bw) {
-  SplatRec rec{0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0u, 0u};
-  const int r = radii[g];
-  if (r > 0) {
-    int minx, miny, maxx, maxy;
-    const float x = xys[2 * g], y = xys[2 * g + 1];
-    gsr_tile_bbox(x, y, (float)r, tiles_x, tiles_y, 0.f, bw, minx, miny, maxx, maxy);
-    rec.x = x;
-    rec.y = y;
-    rec.smax = INFINITY;
-    if (conics) {
-      const gsr::Reach rc = gsr::make_reach(x, y, conics[3 * g], conics[3 * g + 1], conics[3 * g + 2], opacities[g]);
-      rec.a = rc.a;
-      rec.b = rc.b;
-      rec.c = rc.c;
-      rec.smax = rc.smax;
-    }
-    if (maxx > minx && maxy > miny && !(rec.smax < 0.f)) {
-      rec.box0 = (unsigned)minx | ((unsigned)miny << 16);
-      rec.box1 = (unsigned)(maxx - minx) | ((unsigned)(maxy - miny) << 16);
-    }
-  }
-  return rec;
 }
 
 // records only (gsr_count_reach with counts == NULL): what the two-level partition needs
@@ -384,7 +354,8 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   size_t rest_bytes = workspace_bytes - kb;
   int *bucket_stats = nullptr;
   if (use_bucket_sort(num_points, order_only, s, &bucket_stats))
-    return gsr_sort_bucket_depth(num_points, depths, radii, order, workspace, workspace_bytes, bucket_stats, s);
+    return gsr_sort_bucket_depth(num_points, depths, radii, order, workspace, workspace_bytes, bucket_stats, nullptr,
+                                 nullptr, nullptr, 0, 0, nullptr, s);
   if (use_mid_sort(num_points))  // keys, sort, gather of the counts and their scan in 13 launches (sort_mid.hip)
     return gsr_sort_mid_depth(num_points, depths, radii, num_tiles_hit, num_bands, order, cum_sorted, rest,
                               rest_bytes, s);
@@ -448,6 +419,35 @@ GSR_EXPORT int gsr_count_reach(int num_points, const float *xys, const int32_t *
                      (int *)nullptr, counts, 0, bands, rpb);
   GSR_CHECK_LAUNCH("count_reach");
   return GSR_OK;
+}
+
+// gsr_count_reach(counts == NULL) + gsr_depth_order(order only) in one call: when the depth order takes the bucket sort
+// (sort_bucket.hip) its first launch writes the records too -- their 60 B per Gaussian stream while that launch
+// builds its bucket map -- otherwise the two calls run one after the other.  Same records, same order.
+GSR_EXPORT int gsr_reach_records_depth_order(int num_points, const float *xys, const int32_t *radii,
+                                             const float *conics, const float *opacities, const float *depths,
+                                             int tiles_x, int tiles_y, void *reach_records, int32_t *order,
+                                             void *workspace, size_t workspace_bytes, gsr_stream_t stream) {
+  GSR_REQUIRE(num_points >= 0, "reach_records_depth_order: num_points < 0");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(xys && radii && conics && opacities && depths && reach_records && order && workspace,
+              "reach_records_depth_order: null pointer");
+  GSR_REQUIRE(tiles_x > 0 && tiles_y > 0 && tiles_x <= 65535 && tiles_y <= 65535, "reach_records_depth_order: bad tile grid");
+  GSR_REQUIRE((reinterpret_cast<uintptr_t>(reach_records) & 15) == 0,
+              "reach_records_depth_order: reach_records must be 16-byte aligned");
+  if (workspace_bytes < gsr_depth_order_workspace_bytes(num_points, 1)) {
+    gsr_set_error("reach_records_depth_order: workspace too small");
+    return GSR_ENOMEM;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int *bucket_stats = nullptr;
+  if (use_bucket_sort(num_points, true, s, &bucket_stats))
+    return gsr_sort_bucket_depth(num_points, depths, radii, order, workspace, workspace_bytes, bucket_stats, xys,
+                                 conics, opacities, tiles_x, tiles_y, reach_records, s);
+  const int rc = gsr_count_reach(num_points, xys, radii, conics, opacities, tiles_x, tiles_y, 1, nullptr,
+                                 reach_records, stream);
+  if (rc != GSR_OK) return rc;
+  return gsr_depth_order(num_points, depths, radii, nullptr, 1, order, nullptr, workspace, workspace_bytes, stream);
 }
 
 // How the depth-ordered stream is partitioned by tile:

@@ -22,6 +22,8 @@
 // bucket of EARLIER calls (published to pinned memory) and goes back to sort_mid.hip while it is above what the
 // LDS paths hold.
 #include "gsr_common.h"
+#include "raster_common.h"
+#include "tile_rows.h"
 
 #include <algorithm>
 
@@ -87,23 +89,28 @@ __device__ __forceinline__ unsigned bucket_first_mantissa(const unsigned j, cons
 
 // Called by all threads of a workgroup (blockDim.x >= 256, whole waves); afterwards map[0..256) (LDS) holds the
 // table.  Integer arithmetic on the same samples: every workgroup derives the same table.
+// the sample: 256 runs of 16 adjacent items, evenly spaced (n >= 4096).  Every workgroup reads the same 4096 items:
+// as 4096 single items spread over the array that was 2 x 4096 cache lines per workgroup, 130 MB of L2 traffic
+// for a 1 M-item sort and 12 us; runs of 16 are 64 bytes each
 template <int kT>
-__device__ __forceinline__ void build_bucket_map(const int n, const float *__restrict__ depths,
-                                                 const int *__restrict__ radii, const int log2_buckets,
+__device__ __forceinline__ void load_samples(const int n, const float *__restrict__ depths,
+                                             const int *__restrict__ radii, unsigned (&sample)[kSample / kT]) {
+  const int spacing = n / (kSample / 16);
+#pragma unroll
+  for (int q = 0; q < kSample / kT; ++q) {
+    const int j = q * kT + (int)threadIdx.x;
+    sample[q] = depth_key(depths, radii, (j >> 4) * spacing + (j & 15));
+  }
+}
+
+// Called by all threads of a workgroup (kT threads, whole waves); afterwards map[0..256) (LDS) holds the
+// table.  Integer arithmetic on the same samples: every workgroup derives the same table.
+template <int kT>
+__device__ __forceinline__ void build_bucket_map(const unsigned (&sample)[kSample / kT], const int log2_buckets,
                                                  unsigned *__restrict__ map, unsigned *__restrict__ oct,
                                                  int *__restrict__ sh /* >= 16 words */) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const unsigned B = 1u << log2_buckets;
-  // the sample: 256 runs of 16 adjacent items, evenly spaced (n >= 4096).  Every workgroup reads the same 4096 items:
-  // as 4096 single items spread over the array that was 2 x 4096 cache lines per workgroup, 130 MB of L2 traffic
-  // for a 1 M-item sort and 12 us; runs of 16 are 64 bytes each
-  const int spacing = n / (kSample / 16);
-  unsigned sample[kSample / kT];
-#pragma unroll
-  for (int q = 0; q < kSample / kT; ++q) {
-    const int j = q * kT + tid;
-    sample[q] = depth_key(depths, radii, (j >> 4) * spacing + (j & 15));
-  }
   if (tid < 256) oct[tid] = 0u;
   __syncthreads();
 #pragma unroll
@@ -154,29 +161,50 @@ __device__ __forceinline__ void build_bucket_map(const int n, const float *__res
   __syncthreads();
 }
 
-// ---- histogram -------------------------------------------------------------------------------------
+// ---- histogram (+ the reach records of the list builders, when asked) ---------------------------------
+// kRecords: the launch also writes the per-Gaussian record gsr_count_reach writes (same function, same inputs): its
+// 60 B per Gaussian stream while the map is being built, instead of in a launch of its own.
+struct RecordArgs {
+  const float *xys, *conics, *opacities;
+  int tiles_x, tiles_y;
+  SplatRec *recs;
+};
+
+template <bool kRecords>
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const int n, const float *__restrict__ depths,
                                                             const int *__restrict__ radii, const int log2_buckets,
                                                             unsigned *__restrict__ table,
-                                                            unsigned *__restrict__ map_out) {
+                                                            unsigned *__restrict__ map_out, const RecordArgs ra) {
   extern __shared__ unsigned h[];  // B counters
   __shared__ unsigned map[256], oct[256];
   __shared__ int sh[16];
+  constexpr int kI = kChunk / kHistThreads;
   const int tid = threadIdx.x, B = 1 << log2_buckets;
   const int base = blockIdx.x * kChunk;
-  // the chunk's keys are in flight while the map is built
-  unsigned key[kChunk / kHistThreads];
+  // the chunk's keys (and record inputs) are in flight while the map is built
+  unsigned key[kI];
+  SplatIn in[kRecords ? kI : 1];
 #pragma unroll
-  for (int i = 0; i < kChunk / kHistThreads; ++i) {
+  for (int i = 0; i < kI; ++i) {
     const int idx = base + i * kHistThreads + tid;
     const unsigned k = depth_key(depths, radii, min(idx, n - 1));
     key[i] = idx < n ? k : 0xffffffffu;
+    if (kRecords) in[i] = load_splat_in(min(idx, n - 1), ra.xys, radii, ra.conics, ra.opacities);
   }
+  unsigned sample[kSample / kHistThreads];
+  load_samples<kHistThreads>(n, depths, radii, sample);
   for (int j = tid; j < B; j += kHistThreads) h[j] = 0u;
-  build_bucket_map<kHistThreads>(n, depths, radii, log2_buckets, map, oct, sh);
+  if (kRecords) {  // (their stores drain while the map is built)
+#pragma unroll
+    for (int i = 0; i < kI; ++i) {
+      const int idx = base + i * kHistThreads + tid;
+      if (idx < n) ra.recs[idx] = splat_record_from(in[i], ra.conics != nullptr, ra.tiles_x, ra.tiles_y, 16);
+    }
+  }
+  build_bucket_map<kHistThreads>(sample, log2_buckets, map, oct, sh);
   if (blockIdx.x == 0 && tid < 256) map_out[tid] = map[tid];
 #pragma unroll
-  for (int i = 0; i < kChunk / kHistThreads; ++i) {
+  for (int i = 0; i < kI; ++i) {
     const bool culled = key[i] == 0u;  // (often a third of the chunk: one atomic per wave instead of one each)
     const unsigned long long c = __ballot(culled);
     if (c && (tid & 63) == 0) atomicAdd(&h[0], (unsigned)__popcll(c));
@@ -708,8 +736,10 @@ size_t gsr_sort_bucket_workspace_bytes(int n) {
 int gsr_sort_bucket_wave_cap(void) { return gsr_bsort::kWaveCap; }
 
 // stats (device-writable, e.g. pinned host memory; or NULL): the call leaves the size of its largest visible bucket there
+// xys != NULL: the first launch also writes the reach records of gsr_count_reach(counts == NULL) to `recs`.
 int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *order, void *workspace,
-                          size_t workspace_bytes, int *stats, hipStream_t s) {
+                          size_t workspace_bytes, int *stats, const float *xys, const float *conics,
+                          const float *opacities, int tiles_x, int tiles_y, void *recs, hipStream_t s) {
   using namespace gsr_bsort;
   if (n <= 0) return GSR_OK;
   if (workspace_bytes < gsr_sort_bucket_workspace_bytes(n)) {
@@ -732,8 +762,13 @@ int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *ord
   unsigned *map = reinterpret_cast<unsigned *>(ws);
   ws += 1024;
   if (!stats) stats = reinterpret_cast<int *>(ws);
-  hipLaunchKernelGGL(hist_kernel, dim3(chunks), dim3(kHistThreads), sizeof(unsigned) * B, s, n, depths, radii, lb,
-                     table, map);
+  const RecordArgs ra{xys, conics, opacities, tiles_x, tiles_y, static_cast<SplatRec *>(recs)};
+  if (xys)
+    hipLaunchKernelGGL(hist_kernel<true>, dim3(chunks), dim3(kHistThreads), sizeof(unsigned) * B, s, n, depths, radii,
+                       lb, table, map, ra);
+  else
+    hipLaunchKernelGGL(hist_kernel<false>, dim3(chunks), dim3(kHistThreads), sizeof(unsigned) * B, s, n, depths, radii,
+                       lb, table, map, ra);
   hipLaunchKernelGGL(scan_kernel, dim3(B / 16), dim3(256), 0, s, chunks, B, table, totals);
   hipLaunchKernelGGL(scatter_kernel, dim3(chunks), dim3(kScatterThreads), 0, s, n, depths, radii,
                      (const unsigned *)map, lb, (const unsigned *)table, (const unsigned *)totals, pairs, order,

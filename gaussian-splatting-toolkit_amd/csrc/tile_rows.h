@@ -2,6 +2,7 @@
 // list-building kernels (binning_fast.hip, tile_partition2.hip).
 #pragma once
 #include "gsr_common.h"
+#include "raster_common.h"
 
 namespace {
 
@@ -16,6 +17,63 @@ struct alignas(16) SplatRec {
   unsigned box1;  // box width | box height << 16   (0 | 0 when culled)
 };
 static_assert(sizeof(SplatRec) == 32, "SplatRec layout");
+
+// What a record is made from.  Loaded unconditionally (a load under `radius > 0` is a branch with its own wait: fine
+// for one Gaussian per lane, a round trip per item where a lane handles several) or only when visible.
+struct SplatIn {
+  float x, y, ca, cb, cc, opac;
+  int radius;
+};
+
+__device__ __forceinline__ SplatIn load_splat_in(const int g, const float *__restrict__ xys,
+                                                 const int *__restrict__ radii, const float *__restrict__ conics,
+                                                 const float *__restrict__ opacities) {
+  SplatIn s;
+  s.radius = radii[g];
+  s.x = xys[2 * g], s.y = xys[2 * g + 1];
+  s.ca = s.cb = s.cc = s.opac = 0.f;
+  if (conics) s.ca = conics[3 * g], s.cb = conics[3 * g + 1], s.cc = conics[3 * g + 2], s.opac = opacities[g];
+  return s;
+}
+
+// The per-Gaussian record of the list builders: centre, conic, the sigma bound of the exact
+// reach test and the tile box (have_conics false: every box tile counts, smax = inf).
+__device__ __forceinline__ SplatRec splat_record_from(const SplatIn &s, const bool have_conics, const int tiles_x,
+                                                      const int tiles_y, const int bw) {
+  SplatRec rec{0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0u, 0u};
+  if (s.radius > 0) {
+    int minx, miny, maxx, maxy;
+    gsr_tile_bbox(s.x, s.y, (float)s.radius, tiles_x, tiles_y, 0.f, bw, minx, miny, maxx, maxy);
+    rec.x = s.x;
+    rec.y = s.y;
+    rec.smax = INFINITY;
+    if (have_conics) {
+      const gsr::Reach rc = gsr::make_reach(s.x, s.y, s.ca, s.cb, s.cc, s.opac);
+      rec.a = rc.a;
+      rec.b = rc.b;
+      rec.c = rc.c;
+      rec.smax = rc.smax;
+    }
+    if (maxx > minx && maxy > miny && !(rec.smax < 0.f)) {
+      rec.box0 = (unsigned)minx | ((unsigned)miny << 16);
+      rec.box1 = (unsigned)(maxx - minx) | ((unsigned)(maxy - miny) << 16);
+    }
+  }
+  return rec;
+}
+
+__device__ __forceinline__ SplatRec make_splat_record(const int g, const float *__restrict__ xys,
+                                                      const int *__restrict__ radii,
+                                                      const float *__restrict__ conics,
+                                                      const float *__restrict__ opacities, const int tiles_x,
+                                                      const int tiles_y, const int bw) {
+  SplatIn s{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, radii[g]};
+  if (s.radius > 0) {
+    s.x = xys[2 * g], s.y = xys[2 * g + 1];
+    if (conics) s.ca = conics[3 * g], s.cb = conics[3 * g + 1], s.cc = conics[3 * g + 2], s.opac = opacities[g];
+  }
+  return splat_record_from(s, conics != nullptr, tiles_x, tiles_y, bw);
+}
 
 // derived per Gaussian, kept in LDS for the row loop
 struct RowParams {

@@ -34,10 +34,15 @@ GSR_EXPORT int gsr_view_forward(const gsr_view_desc *v, gsr_stream_t stream) {
                                v->features_dc, v->features_rest, v->colors, 0.5f, 1, stream));
   // lists: with counts (short lists: single-pass scatter) or without (two-level partition), as the caller
   // decided with gsr_bin_sorted_needs_counts when it sized the buffers
-  GSR_TRY(gsr_count_reach(n, v->xys, v->radii, v->conics, v->opac, tiles_x, tiles_y, 1, v->counts, v->reach_records,
-                          stream));
-  GSR_TRY(gsr_depth_order(n, v->depths, v->radii, v->counts, 1, v->order, v->counts ? v->cum : nullptr, v->sort_ws,
-                          v->sort_ws_bytes, stream));
+  if (v->counts) {
+    GSR_TRY(gsr_count_reach(n, v->xys, v->radii, v->conics, v->opac, tiles_x, tiles_y, 1, v->counts, v->reach_records,
+                            stream));
+    GSR_TRY(gsr_depth_order(n, v->depths, v->radii, v->counts, 1, v->order, v->cum, v->sort_ws, v->sort_ws_bytes,
+                            stream));
+  } else {
+    GSR_TRY(gsr_reach_records_depth_order(n, v->xys, v->radii, v->conics, v->opac, v->depths, tiles_x, tiles_y,
+                                          v->reach_records, v->order, v->sort_ws, v->sort_ws_bytes, stream));
+  }
   GSR_TRY(gsr_bin_sorted_dev(n, v->capacity, v->order, v->counts ? v->cum : nullptr, v->xys, v->radii,
                              v->reach_records, tiles_x, tiles_y, 16, 1, v->ids, v->tile_bins, v->count_out, nullptr,
                              v->bin_ws, v->bin_ws_bytes, stream));

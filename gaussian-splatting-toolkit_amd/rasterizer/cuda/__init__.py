@@ -326,6 +326,32 @@ def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
     return cnt, recs
 
 
+def reach_records_depth_order(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor, depths: Tensor,
+                              tile_bounds: Tuple[int, int, int], extra_rows: int = 0) -> Tuple[Tensor, Tensor]:
+    """``gsr_reach_records_depth_order``: ``count_reach(..., counts=False)`` and ``depth_order(depths, radii, None)``
+    as one call -> (records, order), the same values (lists without counts, :func:`lists_need_counts`)."""
+    _check(xys, "xys", _f32)
+    _check(radii, "radii", _i32)
+    _check(conics, "conics", _f32)
+    _check(opacities, "opacities", _f32)
+    _check(depths, "depths", _f32)
+    n = radii.numel()
+    if xys.numel() != 2 * n or conics.numel() != 3 * n or opacities.numel() != n or depths.numel() != n:
+        raise RuntimeError("reach_records_depth_order: xys [N,2], conics [N,3], opacities [N,1], depths [N] expected")
+    dev = xys.device
+    with torch.cuda.device(dev):
+        recs = torch.empty((n + int(extra_rows), int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
+        if extra_rows:
+            recs[n:].zero_()  # (as in count_reach: the dummy culled record)
+        order = torch.empty((n,), dtype=_i32, device=dev)
+        nbytes = int(_lib().gsr_depth_order_workspace_bytes(C.c_int(n), C.c_int(1)))
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        _call("gsr_reach_records_depth_order", C.c_int(n), _ptr(xys), _ptr(radii), _ptr(conics), _ptr(opacities),
+              _ptr(depths), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), _ptr(recs), _ptr(order), _ptr(ws),
+              C.c_size_t(nbytes), _stream(dev))
+    return recs, order
+
+
 MAX_SCATTER_TILES = 16384  # tile grids the device-sized path supports without reach records (tile_scatter.hip)
 
 

@@ -33,6 +33,7 @@ SYMBOLS = (
     "gsr_count_reach",
     "gsr_depth_order_workspace_bytes",
     "gsr_depth_order",
+    "gsr_reach_records_depth_order",
     "gsr_bin_sorted_workspace_bytes",
     "gsr_bin_sorted_needs_counts",
     "gsr_bin_sorted",

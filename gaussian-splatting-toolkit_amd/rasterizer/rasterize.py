@@ -122,6 +122,16 @@ def _speculative_capacity(device, num_points, tile_bounds, exact):
 _two_hint = {}
 
 
+def _records_and_order(xys, radii, conics, opacity, depths, tile_bounds, extra_rows=0):
+    """Reach records + depth order of the lists without counts: one native call (GSR_FUSED_RECORDS=0: the two calls
+    it replaces, for A/B measurements)."""
+    if os.environ.get("GSR_FUSED_RECORDS", "1") == "0":
+        _, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False, extra_rows=extra_rows)
+        order, _ = _C.depth_order(depths, radii, None)
+        return records, order
+    return _C.reach_records_depth_order(xys, radii, conics, opacity, depths, tile_bounds, extra_rows=extra_rows)
+
+
 def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
     mode = os.environ.get("GSR_TWO_ROUND", "auto")
     if mode in ("0", "off") or not exact or _deterministic["on"] or not _speculation_enabled():
@@ -188,8 +198,7 @@ def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bo
     """-> (None, ids, bins1, finish); `round1(ids, bins1, tile_flags)` composites the prefix lists (raw state)."""
     dev = xys.device
     n, n1, cap1, cap2 = xys.size(0), plan["n1"], plan["cap1"], plan["cap2"]
-    _, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False, extra_rows=1)
-    order, _ = _C.depth_order(depths, radii, None)
+    records, order = _records_and_order(xys, radii, conics, opacity, depths, tile_bounds, extra_rows=1)
     with torch.cuda.device(dev):
         ids = torch.empty((cap1 + cap2,), dtype=torch.int32, device=dev)
         flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=dev)
@@ -468,8 +477,7 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
             not _C.lists_need_counts(num_points, capacity, tile_bounds, device_sized=True, want_slots=det):
         # The two-level partition counts its entries itself: records only, the depth order only,
         # and the number of entries comes back through the pinned slot (`count_out`).
-        _, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False)
-        order, _ = _C.depth_order(depths, radii, None)
+        records, order = _records_and_order(xys, radii, conics, opacity, depths, tile_bounds)
         pending = _PendingCount(xys.device)
         ids, bins = _C.bin_sorted(num_points, capacity, order, None, xys, radii, tile_bounds, block_width, records,
                                   device_sized=True, count_out=pending.buf)

@@ -178,7 +178,16 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  * (records only, no walk over the tile rows), num_tiles_hit = cum_sorted = NULL to
  * gsr_depth_order (the order only: no gather, no scan) and cum_sorted = NULL to
  * gsr_bin_sorted(_dev); the number of entries then arrives through count_out of
- * gsr_bin_sorted_dev.  Same lists, two kernels and a scan less. */
+ * gsr_bin_sorted_dev.  Same lists, two kernels and a scan less.
+ * gsr_reach_records_depth_order is those two calls -- gsr_count_reach(counts = NULL) and
+ * gsr_depth_order(num_tiles_hit = cum_sorted = NULL, num_bands = 1) -- as one: the same records and the same
+ * order; where the depth order is built by the bucket sort (csrc/sort_bucket.hip: 64 k < num_points <= 4 M) the
+ * records are written by its first launch.  workspace: gsr_depth_order_workspace_bytes(num_points, 1).
+ *
+ * How the order-only depth sort is built (64 k < num_points <= 4 M) may depend on earlier calls on the same
+ * device -- a hint in pinned memory sends calls to the radix passes after a view whose depths overflowed the
+ * bucket sort's buckets -- the RESULT never does: both are the stable sort by (depth bits, index).
+ * GSR_DEPTH_SORT=radix | bucket in the environment pins the choice. */
 size_t gsr_reach_record_bytes(void);
 int gsr_tile_bands(int tiles_x, int tiles_y);
 int gsr_count_reach(int num_points, const float *xys, const int32_t *radii,
@@ -190,6 +199,10 @@ int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
                     const int32_t *num_tiles_hit, int num_bands,
                     int32_t *order, int32_t *cum_sorted, void *workspace,
                     size_t workspace_bytes, gsr_stream_t stream);
+int gsr_reach_records_depth_order(int num_points, const float *xys, const int32_t *radii,
+                                  const float *conics, const float *opacities, const float *depths,
+                                  int tiles_x, int tiles_y, void *reach_records, int32_t *order,
+                                  void *workspace, size_t workspace_bytes, gsr_stream_t stream);
 size_t gsr_bin_sorted_workspace_bytes(int num_points, int num_intersects,
                                       int tiles_x, int tiles_y);
 int gsr_bin_sorted_needs_counts(int num_points, int num_intersects, int tiles_x,

@@ -595,7 +595,8 @@ def test_two_level_partition_equals_banded_lists(n, W, H, scale_hi):
 
 
 @pytest.mark.parametrize("n,W,H,lo,hi", [(30_000, 3840, 2160, 0.01, 0.08),     # large grid: always the two-level path
-                                         (300_000, 1920, 1080, 0.01, 0.08)])   # 1080p with long lists
+                                         (300_000, 1920, 1080, 0.01, 0.08),    # 1080p with long lists
+                                         (1_000_000, 1920, 1080, 0.0025, 0.025)])  # the bench default's sizes
 def test_lists_without_counts_equal_the_full_flow(n, W, H, lo, hi):
     """include/gsraster.h "Lists without counts": records only + order only + cum_sorted = NULL
     build the same ids / bins and report the same number of entries as the full flow."""
@@ -617,6 +618,12 @@ def test_lists_without_counts_equal_the_full_flow(n, W, H, lo, hi):
     assert none is None and torch.equal(recs, recs2)
     order2, cum2 = C.depth_order(g["depths"], g["radii"], None)
     assert cum2 is None and torch.equal(order, order2)
+    # ... and as ONE call (the records ride in the bucket sort's first launch above 64 k Gaussians)
+    recs3, order3 = C.reach_records_depth_order(g["xys"], g["radii"], g["conics"], g["opac"], g["depths"], tb)
+    assert torch.equal(recs3, recs) and torch.equal(order3, order)
+    recs4, order4 = C.reach_records_depth_order(g["xys"], g["radii"], g["conics"], g["opac"], g["depths"], tb,
+                                                extra_rows=1)
+    assert torch.equal(recs4[:n], recs) and not recs4[n:].any() and torch.equal(order4, order)
     count = torch.zeros(1, dtype=torch.int32).pin_memory()
     ids_lean, bins_lean = C.bin_sorted(n, cap, order2, None, g["xys"], g["radii"], tb, bw, recs2, device_sized=True,
                                        count_out=count)
