@@ -117,6 +117,9 @@ __global__ __launch_bounds__(64 * WAVES) void sh16_fwd_kernel(
   const unsigned g0 = (blockIdx.x * WAVES + w) * 64;  // first Gaussian of this wave
   const unsigned navail = g0 < n ? (n - g0 < 64 ? n - g0 : 64) * 12 : 0;
   const float4 *src = coeffs + (size_t)g0 * 12;
+  // the view direction goes out with the coefficient rows (after the barrier it is a second round trip per wave)
+  const unsigned gd = g0 + lane < n ? g0 + lane : n - 1;
+  const float dx = viewdirs[3 * gd], dy = viewdirs[3 * gd + 1], dz = viewdirs[3 * gd + 2];
   float4 q[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(64 * WAVES) void sh16_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < 12; ++i) q[i] = lds[w][lane * kShRow + i];
   float B[16];
-  sh_basis<16>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+  sh_basis<16>(deg_use, dx, dy, dz, B);
   if (deg_use == 0) {
 #pragma unroll
     for (int k = 1; k < 16; ++k) B[k] = 0.f;
@@ -317,17 +320,21 @@ __global__ __launch_bounds__(256) void sh_split_fwd_kernel(
   const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned g0 = (blockIdx.x * 4 + w) * 64;
   const unsigned cnt = g0 < n ? (n - g0 < 64 ? n - g0 : 64) : 0;
+  // view direction and DC term go out before the rows (after the barrier they are a second round trip per wave)
+  const unsigned gd = g0 + lane < n ? g0 + lane : n - 1;
+  const float dx = viewdirs[3 * gd], dy = viewdirs[3 * gd + 1], dz = viewdirs[3 * gd + 2];
+  const float dc0 = dc[3 * gd], dc1 = dc[3 * gd + 1], dc2 = dc[3 * gd + 2];
   split_rows_to_lds<K, VEC>(rest + (size_t)g0 * R, cnt, lane, lds[w]);
   __syncthreads();
   const unsigned g = g0 + lane;
   if (g >= n) return;
   float B[K];
-  sh_basis<K>(deg_use, viewdirs[3 * g], viewdirs[3 * g + 1], viewdirs[3 * g + 2], B);
+  sh_basis<K>(deg_use, dx, dy, dz, B);
   if (deg_use == 0) {
 #pragma unroll
     for (int k = 1; k < K; ++k) B[k] = 0.f;
   }
-  float r = B[0] * dc[3 * g], gr = B[0] * dc[3 * g + 1], b = B[0] * dc[3 * g + 2];
+  float r = B[0] * dc0, gr = B[0] * dc1, b = B[0] * dc2;
   const float *row = lds[w] + lane * STRIDE;
 #pragma unroll
   for (int k = 1; k < K; ++k) {

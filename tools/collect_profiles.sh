@@ -43,7 +43,9 @@ names = {"project_fwd": "project_fwd_kernel", "sh_fwd": "sh16_fwd_kernel", "coun
          "tile_scatter": "gsr_ts::scatter_kernel", "tile_rows": "tile_rows_kernel",
          "p2_rowcount": "gsr_p2::rowcount_kernel", "p2_emit": "gsr_p2::emit_kernel",
          "p2_colscatter": "gsr_p2::colscatter_kernel", "reach_records": "reach_records_kernel",
-         "sort_scatter": "gsr_sort::scatter_kernel"}
+         "sort_scatter": "gsr_sort::scatter_kernel", "bsort_hist": "gsr_bsort::hist_kernel",
+         "bsort_scan": "gsr_bsort::scan_kernel", "bsort_scatter": "gsr_bsort::scatter_kernel",
+         "bsort_bucket_sort": "gsr_bsort::bucket_sort_kernel"}
 t = {"_note": "HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes "
               f"({tag}_pmc_FETCH_SIZE.json, {tag}_pmc_WRITE_SIZE.json): KB units, FETCH_SIZE doubled on gfx950 as "
               "MI355X_MICROARCH.md#HBM prescribes (calibrated there for wide coalesced reads; the compositing "
