@@ -415,6 +415,9 @@ def main():
     ap.add_argument("--sh-degree-to-use", type=int, default=None,
                     help="evaluate only the first bands (the models' SH warm-up, vanilla_gs.py:811-820); the "
                          "gradient exchange then leaves the inactive bands out")
+    ap.add_argument("--sh-exchange", default="views", choices=["views", "dense"],
+                    help="N > 1: how the SH gradient crosses ranks -- 'views': all-gather of the 12-byte colour cotangents, "
+                         "the sum over views formed on every rank; 'dense': all-reduce of the 12 K-byte gradient")
     ap.add_argument("--deterministic", action="store_true",
                     help="compositing backward with a fixed summation order (gsr_rasterize_backward_det) instead of "
                          "float atomics")
@@ -494,13 +497,17 @@ def main():
     exchange = GradientExchange({k: params[k] for k in ("means3d", "scales", "quats", "opacities", "sh_coeffs")},
                                 average=True).attach()
     exchange.active_rows["sh_coeffs"] = (deg_use + 1) ** 2
+    # N > 1: the SH gradient is formed on every rank from the ranks' all-gathered 12-byte colour cotangents instead of
+    # being all-reduced (GradientExchange `sh_views`; --sh-exchange dense: every gradient all-reduced)
+    sh_views = world > 1 and args.sh_exchange == "views" and deg <= 3
 
     def step():
         for p in plist:
             p.grad = None
         out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
                           params["sh_coeffs"], camt, bg, deg_use, clamp_rgb=False, render_depth=args.render_depth,
-                          fused_depth=args.fused_depth)
+                          fused_depth=args.fused_depth,
+                          sh_exchange=(exchange, ("sh_coeffs",), (params["sh_coeffs"],)) if sh_views else None)
         if args.render_depth:
             torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]],
                                     [v_img, v_alpha[..., None], v_alpha[..., None]])
@@ -705,8 +712,12 @@ def main():
                 "list_entries": list_entries,
                 "mean_gaussians_per_tile": round(num_intersects / tiles, 1),
                 "tile_list_length": tile_hist, "scene": args.scene, "two_round_lists": two_round,
-                "parallelism": (f"dp{world} (per-view; per-parameter all-reduce started from autograd hooks, overlapping "
-                                f"the backward; active SH bands only; "
+                "parallelism": (f"dp{world} (per-view; "
+                                + ("geometry gradients all-reduced (one flat message), SH gradient formed on every rank "
+                                   "from the all-gathered 12-byte colour cotangents (gsr_sh_backward_views), both started "
+                                   "from autograd hooks; " if sh_views else
+                                   "per-parameter all-reduce started from autograd hooks, overlapping "
+                                   "the backward; active SH bands only; ")
                                 + ("averaged in the collective, RCCL)" if args.backend == "nccl" else
                                    f"{args.backend}: ranks share GPUs, not a measurement configuration)"))
                                if world > 1 else "single",

@@ -492,6 +492,101 @@ GSR_EXPORT int gsr_sh_backward_split(unsigned num_points, unsigned degree, unsig
   return GSR_OK;
 }
 
+// ---- SH backward over several views at once (the data-parallel exchange of harness/parallel.py) ---------
+// The SH gradient of one view is rank one per Gaussian: v_coeffs[g, k, :] = B_k(dir_g) v_colors[g, :].  Ranks that
+// render different views therefore need not all-reduce 12 K bytes per Gaussian: they all-gather their 12-byte
+// v_colors (and camera positions) and every rank forms  scale * sum_r B_k(normalize(mean_g - campos_r)) v_colors_r[g]
+// itself, views in rank order: the same sum on every rank, bit for bit.
+// Output rows go through LDS so that a wave writes 64 Gaussians' rows as one contiguous run.
+// kJoint: v_coeffs [n, K, 3]; else v_dc [n, 3] + v_rest [n, K - 1, 3] (K >= 2).
+template <int K, bool kJoint>
+__global__ __launch_bounds__(256) void sh_bwd_views_kernel(const unsigned n, const unsigned deg_use,
+                                                           const unsigned num_views,
+                                                           const float *__restrict__ means,
+                                                           const float *__restrict__ campos, const size_t cstride,
+                                                           const float *__restrict__ v_colors, const size_t vstride,
+                                                           const float scale, float *__restrict__ v_dc,
+                                                           float *__restrict__ v_rest) {
+  constexpr int F = 3 * K, STRIDE = F | 1;
+  __shared__ float lds[4][64 * STRIDE];
+  const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned g0 = (blockIdx.x * 4 + w) * 64;
+  const unsigned cnt = g0 < n ? (n - g0 < 64 ? n - g0 : 64) : 0;
+  const unsigned g = g0 + lane < n ? g0 + lane : n - 1;
+  const float mx = means[3 * g], my = means[3 * g + 1], mz = means[3 * g + 2];
+  float f[F];
+#pragma unroll
+  for (int j = 0; j < F; ++j) f[j] = 0.f;
+  for (unsigned r = 0; r < num_views; ++r) {
+    const float *vc = v_colors + (size_t)r * vstride + (size_t)g * 3, *cp = campos + (size_t)r * cstride;
+    const float vr = vc[0], vg = vc[1], vb = vc[2];
+    // the direction as gsr_activate_forward forms it (activations.hip)
+    const float dx = mx - cp[0], dy = my - cp[1], dz = mz - cp[2];
+    const float dinv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+    float B[K];
+    sh_basis<K>(deg_use, dx * dinv, dy * dinv, dz * dinv, B);
+    if (deg_use == 0) {
+#pragma unroll
+      for (int k = 1; k < K; ++k) B[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      f[3 * k] += B[k] * vr;
+      f[3 * k + 1] += B[k] * vg;
+      f[3 * k + 2] += B[k] * vb;
+    }
+  }
+  float *row = lds[w] + lane * STRIDE;
+#pragma unroll
+  for (int j = 0; j < F; ++j) row[j] = f[j] * scale;
+  __syncthreads();
+  if (kJoint) {
+    float *dst = v_rest + (size_t)g0 * F;
+    for (unsigned e = lane; e < cnt * F; e += 64) dst[e] = lds[w][(e / F) * STRIDE + e % F];
+  } else {
+    constexpr int R = F - 3;
+    float *d0 = v_dc + (size_t)g0 * 3, *d1 = v_rest + (size_t)g0 * R;
+    for (unsigned e = lane; e < cnt * 3; e += 64) d0[e] = lds[w][(e / 3) * STRIDE + e % 3];
+    for (unsigned e = lane; e < cnt * R; e += 64) d1[e] = lds[w][(e / R) * STRIDE + 3 + e % R];
+  }
+}
+
+GSR_EXPORT int gsr_sh_backward_views(unsigned num_points, unsigned degree, unsigned degrees_to_use, unsigned num_views,
+                                     const float *means3d, const float *camera_positions, size_t camera_stride,
+                                     const float *v_colors, size_t v_colors_stride, float scale, float *v_dc,
+                                     float *v_rest, float *v_coeffs, gsr_stream_t stream) {
+  GSR_REQUIRE(degree <= 3, "sh_backward_views: degree must be in [0,3]");
+  GSR_REQUIRE(degrees_to_use <= degree, "sh_backward_views: degrees_to_use > degree");
+  GSR_REQUIRE(num_views >= 1, "sh_backward_views: num_views < 1");
+  GSR_REQUIRE((v_coeffs != nullptr) != (v_dc != nullptr), "sh_backward_views: give v_coeffs, or v_dc (+ v_rest)");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(means3d && camera_positions && v_colors, "sh_backward_views: null pointer");
+  GSR_REQUIRE(v_coeffs || degree == 0 || v_rest, "sh_backward_views: v_rest is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 blk(256), grd(gsr_cdiv(num_points, 256));
+#define GSR_VIEWS(KK)                                                                                          \
+  if (v_coeffs)                                                                                                \
+    hipLaunchKernelGGL((sh_bwd_views_kernel<KK, true>), grd, blk, 0, s, num_points, degrees_to_use, num_views, \
+                       means3d, camera_positions, camera_stride, v_colors, v_colors_stride, scale,             \
+                       (float *)nullptr, v_coeffs);                                                            \
+  else                                                                                                         \
+    hipLaunchKernelGGL((sh_bwd_views_kernel<KK, false>), grd, blk, 0, s, num_points, degrees_to_use, num_views, \
+                       means3d, camera_positions, camera_stride, v_colors, v_colors_stride, scale, v_dc, v_rest)
+  switch (degree) {
+    case 0:  // (K = 1: the joint layout [n, 1, 3] and v_dc [n, 3] are the same bytes)
+      hipLaunchKernelGGL((sh_bwd_views_kernel<1, true>), grd, blk, 0, s, num_points, degrees_to_use, num_views, means3d,
+                         camera_positions, camera_stride, v_colors, v_colors_stride, scale, (float *)nullptr,
+                         v_coeffs ? v_coeffs : v_dc);
+      break;
+    case 1: GSR_VIEWS(4); break;
+    case 2: GSR_VIEWS(9); break;
+    default: GSR_VIEWS(16); break;
+  }
+#undef GSR_VIEWS
+  GSR_CHECK_LAUNCH("sh_backward_views");
+  return GSR_OK;
+}
+
 // A/B knob: waves per workgroup of the K = 16 kernels (GSR_SH_WAVES = 1 / 2 / 4)
 static int sh16_waves() {
   static const int v = [] {

@@ -86,3 +86,33 @@ def spherical_harmonics_split(degrees_to_use: int, viewdirs: Tensor, features_dc
         return torch.clamp(out, min=0.0) if clamp_zero else out
     return _SplitSH.apply(degrees_to_use, viewdirs.contiguous(), features_dc.contiguous(),
                           features_rest.contiguous(), float(shift), bool(clamp_zero))
+
+
+def sh_backward_views(degree: int, degrees_to_use: int, means3d: Tensor, camera_positions: Tensor, v_colors: Tensor,
+                      scale: float = 1.0, split: bool = True):
+    """``gsr_sh_backward_views``: the SH gradient summed over several views, from the views' colour cotangents:
+    ``scale * sum_r B(normalize(means3d - camera_positions[r])) (x) v_colors[r]`` -> ``(v_dc [N,3], v_rest [N,K-1,3])``
+    (``split``) or ``v_coeffs [N,K,3]``.  ``camera_positions`` [V,3] and ``v_colors`` [V,N,3] may be strided over
+    the views (rows of one gathered message).  What `harness.parallel.GradientExchange` forms after all-gathering the
+    ranks' 12-byte colour cotangents instead of all-reducing 12 K bytes of SH gradient per Gaussian."""
+    _check(means3d, "means3d", _f32)
+    n, V = means3d.shape[0], v_colors.shape[0]
+    K = num_sh_bases(degree)
+    for t, nm, inner in ((camera_positions, "camera_positions", 3), (v_colors, "v_colors", 3 * n)):
+        if not (t.is_cuda and t.dtype == _f32 and t.shape[0] == V and t[0].numel() == inner
+                and (V == 0 or t[0].is_contiguous())):
+            raise RuntimeError(f"sh_backward_views: {nm} must be float32 CUDA, [V, ...] with contiguous views")
+    dev = means3d.device
+    with torch.cuda.device(dev):
+        v_dc = v_rest = v_coeffs = None
+        if split:
+            v_dc = torch.empty((n, 3), dtype=_f32, device=dev)
+            v_rest = torch.empty((n, K - 1, 3), dtype=_f32, device=dev)
+        else:
+            v_coeffs = torch.empty((n, K, 3), dtype=_f32, device=dev)
+        _call("gsr_sh_backward_views", C.c_uint(n), C.c_uint(degree), C.c_uint(degrees_to_use), C.c_uint(V),
+              _ptr(means3d), _ptr(camera_positions), C.c_size_t(camera_positions.stride(0) if V > 1 else 3),
+              _ptr(v_colors), C.c_size_t(v_colors.stride(0) if V > 1 else 3 * n), C.c_float(scale),
+              _ptr(v_dc) if split else None, _ptr(v_rest) if split and K > 1 else None,
+              _ptr(v_coeffs) if not split else None, _stream(dev))
+    return (v_dc, v_rest) if split else v_coeffs

@@ -95,6 +95,28 @@ def _allreduce_inplace(t: torch.Tensor, average: bool, ws: int, group) -> None:
         t.div_(ws)
 
 
+class _CaptureColorGrad(torch.autograd.Function):
+    """Identity on the colours an SH evaluation returned; in the backward the colour cotangent goes to the
+    exchange (`GradientExchange.offer`) instead of through the SH backward.  The SH parameters are inputs only so
+    that the node sits in the graph; they receive no gradient here."""
+
+    @staticmethod
+    def forward(ctx, colors, collector, clamped, *params):
+        ctx.collector, ctx.clamped = collector, clamped
+        if clamped:
+            ctx.save_for_backward(colors)
+        return colors.view_as(colors)
+
+    @staticmethod
+    def backward(ctx, v):
+        if ctx.clamped:  # the fused epilogue marks the channels its clamp cut with -0.0: no gradient there
+            (colors,) = ctx.saved_tensors
+            cut = colors.view(torch.int32) == -2147483648
+            v = torch.where(cut, torch.zeros((), dtype=v.dtype, device=v.device), v)
+        ctx.collector.offer(v.contiguous())
+        return (None, None, None) + (None,) * len(ctx.collector._sh["params"])
+
+
 class GradientExchange:
     """The per-view data-parallel exchange, overlapped with the backward and cut to what
     is non-zero.
@@ -112,6 +134,16 @@ class GradientExchange:
       ``sh_degree_interval`` iterations the exchange is 56 B instead of 236 B per Gaussian.
     * averaging happens inside the collective on RCCL (``ReduceOp.AVG``), by one in-place
       division elsewhere.
+
+    * ``sh_views`` (`deferred_sh_colors`): the SH gradient of ONE view is rank one per Gaussian,
+      ``v_coeffs[g, k, :] = B_k(dir_g) v_colors[g, :]``.  Instead of all-reducing its 12 K bytes per Gaussian (180 of the
+      236 B at degree 3) the ranks all-gather the 12-byte colour cotangents (+ their camera positions, one message,
+      started from the backward of the SH node, i.e. early) and every rank forms
+      ``1/W sum_r B(normalize(means - campos_r)) (x) v_colors_r`` itself with one kernel (`gsr_sh_backward_views`),
+      views in rank order: the same bits on every rank.  Wire bytes per Gaussian and rank at W ranks:
+      2 (W-1)/W x 236 -> 2 (W-1)/W x 44 + (W-1) x 12  (W = 8: 413 -> 161; W = 2: 236 -> 56).  Not bit-identical to the
+      all-reduce of the per-rank gradients (other summation order, directions re-formed from the camera positions:
+      1e-6 relative), and not available under HIP-graph replay (no hooks).
 
     ``bytes_last`` holds the bytes exchanged by the last ``finish()``.
     """
@@ -132,6 +164,9 @@ class GradientExchange:
         self._bytes = 0
         self._handles = []
         self.use_hooks = True
+        self._sh = None           # this step's deferred SH gradient (deferred_sh_colors), or None
+        self._sh_work = None
+        self.sh_views_backward = None  # (degree, deg_use, means, campos [W,3], v_colors [W,N,3], scale) -> grads; default: native
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self._ws = dist.get_world_size(group) if self.enabled else 1
         self._avg_in_collective = self.enabled and dist.get_backend(group) == "nccl" and average
@@ -162,8 +197,61 @@ class GradientExchange:
         return self.flat_small and p.dim() >= 1 and p.shape[0] > 0 and p.numel() // p.shape[0] <= 4 \
             and self.active_rows.get(name) is None
 
+    def _deferred(self):
+        return self._sh["names"] if self._sh is not None else ()
+
     def _small_names(self):
-        return [k for k in self.named if self._is_small(k)]
+        return [k for k in self.named if self._is_small(k) and k not in self._deferred()]
+
+    # ---- the SH gradient as gathered colour cotangents (class docstring, `sh_views`) ----
+    def deferred_sh_colors(self, sh_fn, names, params, means3d, campos, degree, degrees_to_use, clamped=False):
+        """Colours of this rank's view, `sh_fn()` evaluated WITHOUT an autograd graph, wired so that their cotangent is
+        gathered over the ranks and the gradients of the SH parameters `params` (named `names` in this exchange:
+        ("features_dc", "features_rest") or ("sh_coeffs",)) are formed by `finish()`.  `clamped`: `sh_fn` applied the
+        models' `clamp(rgbs + 0.5, min=0)` epilogue and marked the cut channels with -0.0.  Returns None when the
+        exchange is off or runs without hooks: the caller then evaluates SH the ordinary way."""
+        if not (self.enabled and self.use_hooks):
+            return None
+        with torch.no_grad():
+            colors = sh_fn()
+        self._sh = {"names": tuple(names), "params": tuple(params), "means": means3d.detach(),
+                    "campos": campos.detach().reshape(3).to(colors.dtype), "degree": int(degree),
+                    "deg_use": int(degrees_to_use)}
+        return _CaptureColorGrad.apply(colors, self, bool(clamped), *params)
+
+    def offer(self, v_colors: torch.Tensor) -> None:
+        """(from the backward of `deferred_sh_colors`) start the all-gather of [v_colors | campos]."""
+        sh = self._sh
+        msg = torch.cat((v_colors.reshape(-1), sh["campos"].to(v_colors.device)))
+        out = torch.empty((self._ws, msg.numel()), dtype=msg.dtype, device=msg.device)
+        try:
+            work = dist.all_gather_into_tensor(out.view(-1), msg, group=self.group, async_op=True)
+        except (RuntimeError, ValueError, AttributeError):
+            work = dist.all_gather(list(out.unbind(0)), msg, group=self.group, async_op=True)
+        sh["out"] = out
+        self._sh_work = work
+        self._bytes += out.numel() * out.element_size()
+
+    def _finish_sh(self) -> None:
+        sh = self._sh
+        self._sh = None
+        if sh is None:
+            return
+        if self._sh_work is None:  # the colours never received a cotangent on this rank: not a data-parallel step
+            raise RuntimeError("deferred_sh_colors: backward did not reach the colours")
+        self._sh_work.wait()
+        self._sh_work = None
+        out, n = sh["out"], sh["means"].shape[0]
+        v_all, campos_all = out[:, :3 * n], out[:, 3 * n:]
+        scale = 1.0 / self._ws if self.average else 1.0
+        split = len(sh["names"]) == 2
+        fn = self.sh_views_backward
+        if fn is None:
+            from gs_fused import sh_backward_views as fn
+        grads = fn(sh["degree"], sh["deg_use"], sh["means"], campos_all, v_all, scale, split)
+        grads = grads if split else (grads,)
+        for k, g in zip(sh["names"], grads):
+            self.named[k].grad = g.view_as(self.named[k])
 
     def _start_flat(self) -> None:
         names = self._small_names()
@@ -188,6 +276,8 @@ class GradientExchange:
         self._flat_started = True
 
     def _start(self, name, p) -> None:
+        if name in self._deferred():
+            return
         if self._is_small(name):
             self._flat_arrived[name] = True
             if not self._flat_started and all(self._flat_arrived.get(k) for k in self._small_names()):
@@ -239,7 +329,7 @@ class GradientExchange:
             return 0
         seen = {id(g) for _, _, g, rows, _ in self.pending if rows != "flat"}
         for name, p in self.named.items():
-            if self._is_small(name):
+            if self._is_small(name) or name in self._deferred():
                 continue
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
@@ -261,6 +351,7 @@ class GradientExchange:
                 g[:, :rows].copy_(buf)
         self.pending = []
         self._flat_arrived, self._flat_started = {}, False
+        self._finish_sh()
         self.bytes_last, self._bytes = self._bytes, 0
         return self.bytes_last
 

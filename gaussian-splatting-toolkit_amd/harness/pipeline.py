@@ -55,6 +55,9 @@ def render_view(
     clamp_rgb: bool = True,
     viewdirs: Optional[torch.Tensor] = None,  # normalised means3d - campos, if the caller already has them
     fused_depth: bool = False,  # RGB and depth image from one compositing pass (gs_fused.rasterize_gaussians_rgbd)
+    sh_exchange=None,  # (parallel.GradientExchange, names, leaves) with names / leaves = ("features_dc",
+                       # "features_rest") / those parameters, or ("sh_coeffs",) / ([N,K,3],): data parallel, the SH
+                       # gradient is formed from the ranks' gathered colour cotangents (GradientExchange, `sh_views`)
 ) -> Dict[str, Optional[torch.Tensor]]:
     H, W = cam.height, cam.width
     xys, depths, radii, conics, comp, num_tiles_hit, cov3d = project_gaussians(
@@ -67,14 +70,24 @@ def render_view(
     if viewdirs is None:
         viewdirs = means3d.detach() - cam.campos
         viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
-    if isinstance(sh_coeffs, (tuple, list)):
+    split = isinstance(sh_coeffs, (tuple, list))
+    if split:
         from gs_fused import spherical_harmonics_split
 
         # `torch.clamp(rgbs + 0.5, min=0.0)` inside the SH kernels
-        rgbs = spherical_harmonics_split(sh_degree_to_use, viewdirs, sh_coeffs[0], sh_coeffs[1], shift=0.5,
-                                         clamp_zero=True)
+        sh_fn = lambda: spherical_harmonics_split(sh_degree_to_use, viewdirs, sh_coeffs[0], sh_coeffs[1], shift=0.5,  # noqa: E731
+                                                  clamp_zero=True)
     else:
-        rgbs = spherical_harmonics(sh_degree_to_use, viewdirs, sh_coeffs)
+        sh_fn = lambda: spherical_harmonics(sh_degree_to_use, viewdirs, sh_coeffs)  # noqa: E731
+    rgbs = None
+    if sh_exchange is not None:
+        exchange, names, leaves = sh_exchange
+        K = leaves[-1].shape[1] + (1 if len(leaves) == 2 else 0)
+        rgbs = exchange.deferred_sh_colors(sh_fn, names, leaves, means3d, cam.campos, {1: 0, 4: 1, 9: 2, 16: 3}[K],
+                                           sh_degree_to_use, clamped=split)
+    if rgbs is None:
+        rgbs = sh_fn()
+    if not split:
         rgbs = torch.clamp(rgbs + 0.5, min=0.0)
 
     if rasterize_mode == "antialiased":

@@ -218,7 +218,7 @@ class GaussianParams(torch.nn.Module):
                 self.gauss[k] = torch.nn.Parameter(new[k])
 
     def render(self, cam: CameraTensors, background, sh_degree_to_use: int, render_depth=False,
-               retain_xys_grad=False, clamp_rgb=True):
+               retain_xys_grad=False, clamp_rgb=True, sh_exchange=None):
         g = self.gauss
         if self.split_sh and g["features_dc"].is_cuda and g["features_rest"].shape[1] in (3, 8, 15):
             coeffs = (g["features_dc"], g["features_rest"])  # gs_fused.spherical_harmonics_split
@@ -235,7 +235,9 @@ class GaussianParams(torch.nn.Module):
             opac, dirs = torch.sigmoid(g["opacities"]), None
         return render_view(g["means"], scales, quats, opac, coeffs, cam, background, sh_degree_to_use,
                            render_depth=render_depth, retain_xys_grad=retain_xys_grad, viewdirs=dirs,
-                           clamp_rgb=clamp_rgb)
+                           clamp_rgb=clamp_rgb,
+                           sh_exchange=None if sh_exchange is None else (
+                               sh_exchange, ("features_dc", "features_rest"), (g["features_dc"], g["features_rest"])))
 
 
 def _gauss_window(size=11, sigma=1.5, device="cpu"):
@@ -307,12 +309,36 @@ class TrainConfig:
     # data parallel only: reduce-scatter -> Adam on this rank's rows -> all-gather (parallel.ShardedAdam)
     # instead of all-reduce + Adam over every row on every rank
     sharded_adam: bool = False
+    # data parallel only: "views" = the SH gradient is formed on every rank from the ranks' gathered 12-byte colour
+    # cotangents (GradientExchange `sh_views`: 413 -> 161 B per Gaussian on the wire at 8 ranks), "dense" = every
+    # gradient is all-reduced.  "views" needs the hook-driven exchange and the separate-ops render path.
+    sh_exchange: str = "views"
     phase_every: int = 0                  # HIP events around render / loss / backward / optimizer on every k-th iteration
     scene_scale: tuple = (0.01, 0.06)     # range of the truth's Gaussian scales
     tex_cell: float = 0.04                # scene "objects": checker cell size in scene units
     scene_objects: tuple = (48, 0.18, 0.45)  # scene "objects": number of spheres, radius range
     cam_radius: float = 6.0               # radius of the camera orbit
     scene_extent: float = 1.5             # radius of the ball the scene fills
+
+
+def _sh_views_backward_autograd():
+    """CPU stand-in of gs_fused.sh_backward_views: the same sum over views through the autograd of whatever
+    `harness.pipeline.spherical_harmonics` is (SH is linear in the coefficients)."""
+    import harness.pipeline as HP
+
+    def fn(degree, deg_use, means, campos_all, v_all, scale, split):
+        n, K = means.shape[0], (degree + 1) ** 2
+        coeffs = torch.zeros((n, K, 3), dtype=means.dtype, device=means.device, requires_grad=True)
+        total = torch.zeros((n, K, 3), dtype=means.dtype, device=means.device)
+        for r in range(campos_all.shape[0]):
+            d = means - campos_all[r]
+            d = d / d.norm(dim=-1, keepdim=True)
+            (g,) = torch.autograd.grad(HP.spherical_harmonics(deg_use, d, coeffs), coeffs, v_all[r].reshape(n, 3))
+            total += g
+        total *= scale
+        return (total[:, 0, :].contiguous(), total[:, 1:, :].contiguous()) if split else total
+
+    return fn
 
 
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
@@ -434,6 +460,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     t0 = time.perf_counter()
     use_fused = (cfg.fused_render or cfg.use_graph) and device.type == "cuda" and cfg.split_sh and cfg.fused_loss \
         and cfg.sh_degree in (0, 1, 2, 3)
+    sh_views = world > 1 and cfg.sh_exchange == "views" and exchange.enabled and exchange.use_hooks and not use_fused
+    if sh_views and device.type != "cuda":
+        exchange.sh_views_backward = _sh_views_backward_autograd()  # no native kernel here: autograd of the SH op
     fstats = caps = vgraph = vkey = None
     generation = 0
     overflow_views = 0
@@ -506,7 +535,8 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             ph = _phase_marks(5) if (cfg.phase_every and step % cfg.phase_every == 0 and device.type == "cuda") else None
             if ph:
                 ph[0].record()
-            out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp)
+            out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp,
+                               sh_exchange=exchange if sh_views else None)
             rgb = out["rgb"]
             if ph:
                 ph[1].record()
@@ -629,7 +659,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             "allreduce_bytes": exchanged_bytes,
             "render": ("hip graph per view" if cfg.use_graph else "one fused op") if use_fused else "separate ops",
             "list_overflow_views": overflow_views, "phase_ms_median": phases,
-            "update": "reduce-scatter + sharded Adam + all-gather" if sharded is not None else "all-reduce + Adam", "init": cfg.init,
+            "update": "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
+            ("all-reduce (geometry) + all-gathered colour cotangents (SH) + Adam" if sh_views else "all-reduce + Adam"),
+            "init": cfg.init,
             "densify_grad_thresh": (rcfg.densify_grad_thresh if cfg.densify else None)}
 
 

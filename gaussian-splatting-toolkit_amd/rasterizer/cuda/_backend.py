@@ -52,6 +52,7 @@ SYMBOLS = (
     "gsr_depth_l1_backward",
     "gsr_sh_forward_split",
     "gsr_sh_backward_split",
+    "gsr_sh_backward_views",
     "gsr_rasterize_forward_rgbd",
     "gsr_rasterize_forward_scan",
     "gsr_tile_lists_subrange_workspace_bytes",

@@ -416,6 +416,21 @@ int gsr_sh_backward_split(unsigned num_points, unsigned degree,
                           const float *v_colors, const float *clamped_colors,
                           float *v_dc, float *v_rest, gsr_stream_t stream);
 
+/* SH backward over SEVERAL views at once: what per-view data parallelism exchanges instead of the SH
+ * gradient itself.  One view's gradient is rank one per Gaussian, v_coeffs[g,k,:] = B_k(dir_g) v_colors[g,:], so
+ * ranks all-gather their v_colors (12 B per Gaussian; already masked by the clamp epilogue, if any) and camera
+ * positions instead of all-reducing 12 K bytes per Gaussian, and each forms
+ *   scale * sum_r B_k(normalize(means3d[g] - camera_positions[r])) * v_colors[r][g]      (views in order r)
+ * itself -- the same sum on every rank.  v_colors: view r at v_colors + r * v_colors_stride floats, [n,3] each;
+ * camera_positions: view r at camera_positions + r * camera_stride floats.  Output: v_coeffs [n,K,3], or
+ * (v_coeffs NULL) v_dc [n,3] and v_rest [n,K-1,3]; K = (degree+1)^2, degree in [0,3]; bands above degrees_to_use
+ * are written as zeros.  The direction is formed as gsr_activate_forward forms it. */
+int gsr_sh_backward_views(unsigned num_points, unsigned degree, unsigned degrees_to_use,
+                          unsigned num_views, const float *means3d,
+                          const float *camera_positions, size_t camera_stride,
+                          const float *v_colors, size_t v_colors_stride, float scale,
+                          float *v_dc, float *v_rest, float *v_coeffs, gsr_stream_t stream);
+
 /* ---- RGB + one extra channel in ONE compositing pass -------
  * The models composite twice per view when they need a depth image: RGB, then
  * depths repeated as three colours over a zero background (vanilla_gs.py:840-855,

@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(rank, world, port, q, sharded=False, views=4):
+def _run(rank, world, port, q, sharded=False, views=4, sh_exchange="dense"):
     for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -49,7 +49,7 @@ def _run(rank, world, port, q, sharded=False, views=4):
                         stop_split_at=55, densify_grad_thresh=GRAD_THRESH, cull_alpha_thresh=0.05)
     cfg = HT.TrainConfig(num_gaussians=600, init_gaussians=200, width=64, height=48, num_views=views, iters=62,
                          sh_degree=1, sh_degree_interval=10, eval_views=2, densify=True, refine=rcfg,
-                         scene_scale=(0.03, 0.15), sharded_adam=sharded)
+                         scene_scale=(0.03, 0.15), sharded_adam=sharded, sh_exchange=sh_exchange)
     res = HT.train(cfg, torch.device("cpu"), rank, world)
     q.put((rank, res["param_checksum"], res["num_gaussians_start"], res["num_gaussians_end"], res["refinements"],
            res["psnr_start"], res["psnr_end"], res["allreduce_bytes"], res["update"]))
@@ -80,11 +80,11 @@ def test_two_rank_training_with_refinement_keeps_replicas_identical():
     assert math.isfinite(a[1]) and math.isfinite(a[6])
 
 
-def _launch(world, sharded=False, views=4):
+def _launch(world, sharded=False, views=4, sh_exchange="dense"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, q, sharded, views)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, q, sharded, views, sh_exchange)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=800) for _ in range(world)], key=lambda x: x[0])
@@ -126,3 +126,31 @@ def test_eight_rank_training_stand_in(sharded):
         # degree 0 (56 B per Gaussian) -> degree 1 (+36 B), then new N after every refinement
         assert by[0][1] == 200 * 56 and by[1][0] == 10 and by[1][1] == 200 * 92, by
     assert len(by) >= 3, by
+
+
+@pytest.mark.timeout(900)
+def test_gathered_colour_cotangents_give_the_all_reduced_sh_gradient():
+    """`GradientExchange` `sh_views` (the trainer's default): the ranks all-gather their 12-byte colour cotangents and
+    camera positions and each forms the SH gradient of all views itself, instead of all-reducing it.  Replicas stay
+    BIT-identical (every rank adds the views in rank order), the refinement history is the all-reduce run's, the
+    parameters agree with it to rounding, and fewer bytes travel."""
+    dense = _launch(2, sh_exchange="dense")
+    views = _launch(2, sh_exchange="views")
+    assert views[0][8].startswith("all-reduce (geometry) + all-gathered") and dense[0][8] == "all-reduce + Adam"
+    assert views[0][1] == views[1][1]                                   # replicas identical, bit for bit
+    assert views[0][4] == dense[0][4] and len(views[0][4]) >= 2         # same refinement history
+    assert abs(views[0][1] - dense[0][1]) <= 1e-4 * abs(dense[0][1]), (views[0][1], dense[0][1])
+    assert abs(views[0][6] - dense[0][6]) < 0.05                        # same PSNR at the end
+    # degree 0, N = 200: 44 B per Gaussian all-reduced (means, scales, quats, opacities) + 2 x (3 N + 3) floats gathered
+    assert views[0][7][0][1] == 200 * 44 + 2 * (3 * 200 + 3) * 4, views[0][7][:2]
+    assert dense[0][7][0][1] == 200 * 56
+
+
+@pytest.mark.timeout(1200)
+def test_eight_ranks_with_gathered_colour_cotangents_stay_identical():
+    res = _launch(8, views=8, sh_exchange="views")
+    assert len({r[1] for r in res}) == 1
+    assert all(r[4] == res[0][4] for r in res) and len(res[0][4]) >= 2
+    by = res[0][7]
+    # the bytes do not grow with the SH degree (step 10: degree 1): they change with N only, at the first refinement
+    assert by[0][1] == 200 * 44 + 8 * (3 * 200 + 3) * 4 and by[1][0] > 10, by[:3]

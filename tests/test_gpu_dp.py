@@ -38,7 +38,8 @@ def _run(rank, world, port, q, mode="plain"):
                         stop_split_at=150, densify_grad_thresh=0.0004)
     cfg = HT.TrainConfig(num_gaussians=12_000, init_gaussians=3_000, width=256, height=160, num_views=6, iters=140,
                          sh_degree=2, sh_degree_interval=40, eval_views=2, densify=True, refine=rcfg, log_every=10)
-    if mode in ("det", "det+sharded"):
+    cfg.sh_exchange = "views" if mode.endswith("views") else "dense"
+    if mode in ("det", "det+sharded", "det+views"):
         from rasterizer import rasterize as R
 
         R.set_deterministic(True)  # bit-reproducible compositing backward: runs become comparable bit for bit
@@ -57,7 +58,7 @@ def test_two_ranks_on_one_gpu_keep_identical_replicas_through_refinement():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q, "views")) for r in range(2)]  # (the trainer's default exchange)
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=500) for _ in range(2)], key=lambda x: x[0])
@@ -112,3 +113,18 @@ def test_two_rank_graph_replay_exchanges_each_gradient_once():
     le, lg = eager[0][8], graph[0][8]
     assert lg[-1] < 0.8 * lg[0]
     assert abs(lg[3] - le[3]) < 0.15 * le[3] and abs(lg[-1] - le[-1]) < 0.25 * le[-1], (le, lg)
+
+
+@pytest.mark.timeout(900)
+def test_gathered_colour_cotangents_against_the_all_reduce_on_the_hip_path():
+    """The SH gradient formed on every rank from the all-gathered 12-byte colour cotangents (`GradientExchange`
+    `sh_views`, `gsr_sh_backward_views`) against the all-reduced one, both with the deterministic compositing
+    backward: replicas bit-identical, same refinement history, parameters equal to rounding, fewer bytes."""
+    dense, views = _launch("det"), _launch("det+views")
+    assert views[0][1] == views[1][1] and math.isfinite(views[0][1])
+    assert views[0][9].startswith("all-reduce (geometry) + all-gathered") and dense[0][9] == "all-reduce + Adam"
+    assert views[0][4] == dense[0][4] and len(views[0][4]) >= 3, (views[0][4], dense[0][4])
+    assert abs(views[0][1] - dense[0][1]) <= 1e-4 * abs(dense[0][1]), (views[0][1], dense[0][1])
+    bv, bd = views[0][7][0], dense[0][7][0]
+    bv, bd = (bv[-1] if isinstance(bv, (tuple, list)) else bv), (bd[-1] if isinstance(bd, (tuple, list)) else bd)
+    assert bv == 3_000 * 44 + 2 * (3 * 3_000 + 3) * 4 and bd == 3_000 * 56, (bv, bd)

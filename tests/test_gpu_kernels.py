@@ -968,3 +968,35 @@ def test_two_round_lists_equal_the_single_walk(n, W, H, lo, hi, frac, rgbd):
     if frac == 0.15:
         assert k1 + k2 < 0.6 * I, (k1, k2, I)
     print(f"two rounds: {k1} + {k2} of {I} entries built, {int(stats[0])} of {nt} tiles unfinished after round 1")
+
+
+@pytest.mark.parametrize("degree,deg_use", [(0, 0), (1, 0), (1, 1), (2, 2), (3, 1), (3, 3)])
+@pytest.mark.parametrize("views", [1, 3, 8])
+def test_sh_backward_over_several_views(degree, deg_use, views):
+    """gsr_sh_backward_views (what data-parallel ranks run on their gathered colour cotangents) == scale x the sum over
+    the views of the single-view SH backward, in both output layouts, views read straight out of one gathered
+    [V, 3 N + 3] message (strided rows), tail of a workgroup included."""
+    import rasterizer.cuda as C
+    from gs_fused import sh_backward_views
+
+    n = 10_007
+    rng = np.random.default_rng(10 * degree + views)
+    means = torch.from_numpy(rng.uniform(-2, 2, (n, 3)).astype(np.float32)).cuda()
+    msg = torch.from_numpy(rng.standard_normal((views, 3 * n + 3)).astype(np.float32)).cuda()
+    msg[:, 3 * n:] = torch.from_numpy(rng.uniform(4, 6, (views, 3)).astype(np.float32)).cuda()
+    v_all, campos = msg[:, :3 * n], msg[:, 3 * n:]
+    K = (degree + 1) ** 2
+    ref = torch.zeros((n, K, 3), dtype=torch.float64, device="cuda")
+    for r in range(views):
+        d = means - campos[r]
+        d = d / d.norm(dim=-1, keepdim=True)
+        ref += C.compute_sh_backward(n, degree, deg_use, d.contiguous(), v_all[r].reshape(n, 3).contiguous()).double()
+    ref *= 1.0 / views
+    tol = 2e-6 * float(ref.abs().max()) + 1e-7
+    joint = sh_backward_views(degree, deg_use, means, campos, v_all, 1.0 / views, split=False)
+    assert joint.shape == (n, K, 3) and float((joint.double() - ref).abs().max()) <= tol
+    v_dc, v_rest = sh_backward_views(degree, deg_use, means, campos, v_all, 1.0 / views, split=True)
+    assert v_rest.shape == (n, K - 1, 3)
+    assert torch.equal(v_dc, joint[:, 0, :]) and torch.equal(v_rest, joint[:, 1:, :])
+    if deg_use < degree:
+        assert not joint[:, (deg_use + 1) ** 2:, :].any()  # bands above the warm-up degree: exact zeros
