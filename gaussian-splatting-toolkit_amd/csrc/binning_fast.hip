@@ -32,11 +32,12 @@ int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, vo
 size_t gsr_sort_mid_depth_extra(int n, int rows);
 int gsr_sort_mid_depth(int n, const float *depths, const int *radii, const int *counts, int rows, int *order,
                        int *cum, void *workspace, size_t workspace_bytes, hipStream_t s);
-size_t gsr_sort_bucket_workspace_bytes(int n);
+size_t gsr_sort_bucket_workspace_bytes(int n, int rows);
 int gsr_sort_bucket_wave_cap(void);
 int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *order, void *workspace,
                           size_t workspace_bytes, int *stats, const float *xys, const float *conics,
-                          const float *opacities, int tiles_x, int tiles_y, void *recs, hipStream_t s);
+                          const float *opacities, int tiles_x, int tiles_y, void *recs, const int *counts, int rows,
+                          int *cum, hipStream_t s);
 int gsr_sort_mid_pairs(int n, const unsigned *keys_in, const int *vals_in, unsigned *keys_out,
                        int *vals_out, int key_bits, void *workspace, size_t workspace_bytes,
                        hipStream_t s);
@@ -61,8 +62,8 @@ namespace {
 // the purpose-built sort wins between these sizes; rocPRIM elsewhere
 constexpr int kMidSortMin = 1 << 16, kMidSortMax = 1 << 22;
 inline bool use_mid_sort(int n) { return n > kMidSortMin && n <= kMidSortMax; }
-// Order only (no counts to carry along): one bucket pass + one in-LDS pass (sort_bucket.hip), as long as the buckets
-// of recent views fit its in-LDS paths.  The bucket sort is correct for any input but slow on pathological ones (a
+// 64 k < N <= 4 M: one bucket pass + one in-LDS pass (sort_bucket.hip; with counts: they are gathered where the order
+// is written and one look-back scan follows), as long as the buckets of recent views fit its in-LDS paths.  The bucket sort is correct for any input but slow on pathological ones (a
 // million equal or almost equal depths end in one bucket); every call publishes its largest bucket to a pinned
 // word, and a call that finds the last published value too large sorts with the four LSD passes instead -- and so do
 // the next 32, 64, ... calls.  The hint is read without synchronisation (it lags by the views in flight) and never
@@ -75,9 +76,12 @@ BucketHint g_bucket_hint[16];
 std::mutex g_bucket_hint_mutex;
 
 // -> use the bucket sort; *stats: where the call publishes (nullptr: nowhere)
-inline bool use_bucket_sort(int n, bool order_only, hipStream_t s, int **stats) {
+// (below 64 k items the bucket sort's five launches cost what rocPRIM's do -- 60 us at 10 k items, measured -- and its
+// sample of 256 runs of 16 items needs at least 4096)
+inline bool bucket_sort_range(int n) { return use_mid_sort(n); }
+inline bool use_bucket_sort(int n, hipStream_t s, int **stats) {
   *stats = nullptr;
-  if (!order_only || !use_mid_sort(n)) return false;
+  if (!bucket_sort_range(n)) return false;
   const char *e = getenv("GSR_DEPTH_SORT");
   if (e && e[0] == 'r') return false;
   if (e && e[0] == 'b') return true;
@@ -327,7 +331,7 @@ GSR_EXPORT size_t gsr_depth_order_workspace_bytes(int num_points, int num_bands)
   const size_t mid_need = align_up(std::max(gsr_sort_mid_workspace_bytes(num_points) +
                                                 gsr_sort_mid_depth_extra(num_points, num_bands), st));
   const size_t need = kb + (use_mid_sort(num_points) ? mid_need : rocprim_need);
-  return use_mid_sort(num_points) ? std::max(need, gsr_sort_bucket_workspace_bytes(num_points)) : need;
+  return bucket_sort_range(num_points) ? std::max(need, gsr_sort_bucket_workspace_bytes(num_points, num_bands)) : need;
 }
 
 GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_t *radii,
@@ -353,9 +357,9 @@ GSR_EXPORT int gsr_depth_order(int num_points, const float *depths, const int32_
   char *rest = ws + kb;
   size_t rest_bytes = workspace_bytes - kb;
   int *bucket_stats = nullptr;
-  if (use_bucket_sort(num_points, order_only, s, &bucket_stats))
+  if (use_bucket_sort(num_points, s, &bucket_stats))
     return gsr_sort_bucket_depth(num_points, depths, radii, order, workspace, workspace_bytes, bucket_stats, nullptr,
-                                 nullptr, nullptr, 0, 0, nullptr, s);
+                                 nullptr, nullptr, 0, 0, nullptr, num_tiles_hit, num_bands, cum_sorted, s);
   if (use_mid_sort(num_points))  // keys, sort, gather of the counts and their scan in 13 launches (sort_mid.hip)
     return gsr_sort_mid_depth(num_points, depths, radii, num_tiles_hit, num_bands, order, cum_sorted, rest,
                               rest_bytes, s);
@@ -441,9 +445,9 @@ GSR_EXPORT int gsr_reach_records_depth_order(int num_points, const float *xys, c
   }
   hipStream_t s = (hipStream_t)stream;
   int *bucket_stats = nullptr;
-  if (use_bucket_sort(num_points, true, s, &bucket_stats))
+  if (use_bucket_sort(num_points, s, &bucket_stats))
     return gsr_sort_bucket_depth(num_points, depths, radii, order, workspace, workspace_bytes, bucket_stats, xys,
-                                 conics, opacities, tiles_x, tiles_y, reach_records, s);
+                                 conics, opacities, tiles_x, tiles_y, reach_records, nullptr, 0, nullptr, s);
   const int rc = gsr_count_reach(num_points, xys, radii, conics, opacities, tiles_x, tiles_y, 1, nullptr,
                                  reach_records, stream);
   if (rc != GSR_OK) return rc;

@@ -174,13 +174,15 @@ template <bool kRecords>
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const int n, const float *__restrict__ depths,
                                                             const int *__restrict__ radii, const int log2_buckets,
                                                             unsigned *__restrict__ table,
-                                                            unsigned *__restrict__ map_out, const RecordArgs ra) {
+                                                            unsigned *__restrict__ map_out, const RecordArgs ra,
+                                                            unsigned *__restrict__ zero, const int zero_words) {
   extern __shared__ unsigned h[];  // B counters
   __shared__ unsigned map[256], oct[256];
   __shared__ int sh[16];
   constexpr int kI = kChunk / kHistThreads;
   const int tid = threadIdx.x, B = 1 << log2_buckets;
   const int base = blockIdx.x * kChunk;
+  for (int z = blockIdx.x * kHistThreads + tid; z < zero_words; z += gridDim.x * kHistThreads) zero[z] = 0u;  // (the look-back scan's state)
   // the chunk's keys (and record inputs) are in flight while the map is built
   unsigned key[kI];
   SplatIn in[kRecords ? kI : 1];
@@ -325,6 +327,20 @@ __device__ __forceinline__ void block_sort(unsigned (&v)[kI], const int R, const
   }
 }
 
+// Where an item lands in the order, its tile counts go along: cum[r n + pos] = counts[r n + id] (rows r: one count
+// per Gaussian, or one per tile-row band); the inclusive scan over (r, pos) follows the sort (sort_mid.hip's
+// look-back kernel).  counts == nullptr: the order only.
+struct Gather {
+  const int *counts;
+  int *cum;
+  int rows, n;
+};
+__device__ __forceinline__ void place(int *__restrict__ order, const Gather &ga, const unsigned pos, const int id) {
+  order[pos] = id;
+  if (ga.counts)
+    for (int r = 0; r < ga.rows; ++r) ga.cum[(size_t)r * ga.n + pos] = ga.counts[(size_t)r * ga.n + id];
+}
+
 // ---- scatter ---------------------------------------------------------------------------------------
 // One workgroup per chunk, items in registers in (wave, round, lane) = index order.  An item's slot is
 //   (bucket's first slot) + (bucket's items in earlier chunks) + (in earlier waves of this chunk) + (rank in its wave),
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(kScatterThreads) void scatter_kernel(
     const unsigned *__restrict__ map_in, const int log2_buckets, const unsigned *__restrict__ table,
     const unsigned *__restrict__ totals,
     uint2 *__restrict__ pairs, int *__restrict__ order, unsigned *__restrict__ bucket_base,
-    int *__restrict__ stats) {
+    int *__restrict__ stats, const Gather ga) {
   __shared__ unsigned arr[kSweep];
   __shared__ unsigned short cnt[kScatterWaves][kSweep];
   __shared__ unsigned s_sum[kScatterWaves], s_max[kScatterWaves], map[256];
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(kScatterThreads) void scatter_kernel(
         const unsigned pos = arr[d] + cnt[w][d] + rank[i];
         const int id = base + w * seg + i * 64 + lane;
         if (bkt[i] == 0)
-          order[pos] = id;
+          place(order, ga, pos, id);
         else
           pairs[pos] = make_uint2(key[i], (unsigned)id);
       }
@@ -486,7 +502,8 @@ struct BlockShared {
 // cost 216 VGPRs and spill the SGPRs.)
 template <int kI>
 __device__ __forceinline__ void wave_sort(const unsigned s, const int m, const int lowbits, const unsigned sub,
-                                          const uint2 *__restrict__ pairs, int *__restrict__ order, WaveShared &W) {
+                                          const uint2 *__restrict__ pairs, int *__restrict__ order, const Gather &ga,
+                                          WaveShared &W) {
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   unsigned v[kI], rank[kI];
@@ -541,13 +558,13 @@ __device__ __forceinline__ void wave_sort(const unsigned s, const int m, const i
   }
 #pragma unroll
   for (int i = 0; i < kI; ++i)
-    if (i * 64 + lane < m) order[s + i * 64 + lane] = (int)W.ids[v[i] & ((1u << kElemBits) - 1u)];
+    if (i * 64 + lane < m) place(order, ga, s + i * 64 + lane, (int)W.ids[v[i] & ((1u << kElemBits) - 1u)]);
 }
 
 // The slow path of a bucket above kCap items: LSD rounds through HBM (pairs <-> pairs2), one workgroup.
 __device__ __noinline__ void sort_large_bucket(const unsigned s, const unsigned m, const int lowbits, const unsigned sub,
                                                uint2 *pairs, uint2 *pairs2,
-                                  int *__restrict__ order, unsigned *run, SortShared<4> &S) {
+                                  int *__restrict__ order, const Gather &ga, unsigned *run, SortShared<4> &S) {
   constexpr int kI = 4, kTile = kI * kSortThreads;  // (small tiles: few registers; speed is not the point here)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   {  // all keys equal: the scatter's order is final
@@ -563,7 +580,7 @@ __device__ __noinline__ void sort_large_bucket(const unsigned s, const unsigned 
     hi = max(max(S.cnt[1][0], S.cnt[1][1]), max(S.cnt[1][2], S.cnt[1][3]));
     __syncthreads();
     if (lo == hi) {
-      for (unsigned e = tid; e < m; e += kSortThreads) order[s + e] = (int)pairs[s + e].y;
+      for (unsigned e = tid; e < m; e += kSortThreads) place(order, ga, s + e, (int)pairs[s + e].y);
       return;
     }
   }
@@ -621,14 +638,14 @@ __device__ __noinline__ void sort_large_bucket(const unsigned s, const unsigned 
     done += bits, --rounds;
     __threadfence_block();
   }
-  for (unsigned e = tid; e < m; e += kSortThreads) order[s + e] = (int)src[s + e].y;
+  for (unsigned e = tid; e < m; e += kSortThreads) place(order, ga, s + e, (int)src[s + e].y);
 }
 
 // One workgroup, m <= 256 kI items.
 template <int kI>
 __device__ __forceinline__ void block_bucket(const unsigned s, const int m, const int lowbits, const unsigned sub,
                                              const uint2 *__restrict__ pairs, int *__restrict__ order,
-                                             BlockShared &L) {
+                                             const Gather &ga, BlockShared &L) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   constexpr int seg = kI * 64;
   unsigned v[kI];
@@ -643,7 +660,7 @@ __device__ __forceinline__ void block_bucket(const unsigned s, const int m, cons
 #pragma unroll
   for (int i = 0; i < kI; ++i) {
     const int e = w * seg + i * 64 + lane;
-    if (e < m) order[s + e] = (int)L.idL[v[i] & ((1u << kElemBits) - 1u)];
+    if (e < m) place(order, ga, s + e, (int)L.idL[v[i] & ((1u << kElemBits) - 1u)]);
   }
 }
 
@@ -652,7 +669,7 @@ __device__ __forceinline__ void block_bucket(const unsigned s, const int m, cons
 __global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(const unsigned *__restrict__ map_in, const int B,
                                                                    const unsigned *__restrict__ bucket_base,
                                                                    uint2 *pairs, uint2 *pairs2,
-                                                                   int *__restrict__ order) {
+                                                                   int *__restrict__ order, const Gather ga) {
   __shared__ union {
     WaveShared wave[4];
     BlockShared blk;
@@ -690,15 +707,15 @@ __global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(const unsigne
       const int lowbits = __builtin_amdgcn_readfirstlane(low_bits_of(b, sw, sub));
       sub = __builtin_amdgcn_readfirstlane(sub);
       if (mw <= 64)
-        wave_sort<1>(sw, (int)mw, lowbits, sub, pairs, order, L.wave[w]);
+        wave_sort<1>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
       else if (mw <= 128)
-        wave_sort<2>(sw, (int)mw, lowbits, sub, pairs, order, L.wave[w]);
+        wave_sort<2>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
       else if (mw <= 256)
-        wave_sort<4>(sw, (int)mw, lowbits, sub, pairs, order, L.wave[w]);
+        wave_sort<4>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
       else if (mw <= 512)
-        wave_sort<8>(sw, (int)mw, lowbits, sub, pairs, order, L.wave[w]);
+        wave_sort<8>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
       else
-        wave_sort<16>(sw, (int)mw, lowbits, sub, pairs, order, L.wave[w]);
+        wave_sort<16>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
     }
   }
   if (!any_large) return;  // (uniform)
@@ -713,9 +730,9 @@ __global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(const unsigne
     const int lowbits = __builtin_amdgcn_readfirstlane(low_bits_of(b, s, sub));
     sub = __builtin_amdgcn_readfirstlane(sub);
     if (whole || m > (unsigned)kCap)
-      sort_large_bucket(s, m, lowbits, sub, pairs, pairs2, order, L.blk.buf, L.blk.S);
+      sort_large_bucket(s, m, lowbits, sub, pairs, pairs2, order, ga, L.blk.buf, L.blk.S);
     else
-      block_bucket<8>(s, (int)m, lowbits, sub, pairs, order, L.blk);
+      block_bucket<8>(s, (int)m, lowbits, sub, pairs, order, ga, L.blk);
   }
 }
 
@@ -724,11 +741,14 @@ inline int log2_buckets_for(int n) { return n <= (3 << 19) ? 12 : 13; }  // 4096
 }  // namespace gsr_bsort
 
 // ---- internal interface used by binning_fast.hip ------------------------------------------------------
-// workspace: pairs | pairs2 | table[chunks][B] | totals[B] | bucket_base[B + 1] | map[256] | stats
-size_t gsr_sort_bucket_workspace_bytes(int n) {
+// workspace: pairs | pairs2 | table[chunks][B] | totals[B] | bucket_base[B + 1] | map[256] | stats | scan state
+int gsr_sort_mid_scan_state_words(long long total);
+size_t gsr_sort_bucket_workspace_bytes(int n, int rows) {
   using namespace gsr_bsort;
   const size_t chunks = gsr_cdiv((unsigned)n, kChunk), B = (size_t)1 << log2_buckets_for(n);
-  return 2 * align_up(8 * (size_t)n) + align_up(4 * chunks * B) + align_up(4 * B) + align_up(4 * (B + 1)) + 1024 + 256;
+  const size_t state = rows > 0 ? align_up(4 * (size_t)gsr_sort_mid_scan_state_words((long long)n * rows)) : 0;
+  return 2 * align_up(8 * (size_t)n) + align_up(4 * chunks * B) + align_up(4 * B) + align_up(4 * (B + 1)) + 1024 + 256 +
+         state;
 }
 
 // Items a single wave of the per-bucket sort holds: larger buckets occupy a whole workgroup (<= 2048: in LDS, above:
@@ -736,13 +756,21 @@ size_t gsr_sort_bucket_workspace_bytes(int n) {
 int gsr_sort_bucket_wave_cap(void) { return gsr_bsort::kWaveCap; }
 
 // stats (device-writable, e.g. pinned host memory; or NULL): the call leaves the size of its largest visible bucket there
+// sort_mid.hip: in-place inclusive scan of `total` ints, one launch; `state` = its words (gsr_sort_mid_scan_state_words),
+// zeroed by the caller
+int gsr_sort_mid_scan_state_words(long long total);
+int gsr_sort_mid_scan_inplace(long long total, int *data, unsigned *state, hipStream_t s);
+
 // xys != NULL: the first launch also writes the reach records of gsr_count_reach(counts == NULL) to `recs`.
+// counts != NULL (rows x n, row-major): cum[rows * n] <- inclusive scan of counts[r][order[i]] over (r, i) -- the
+// counts are gathered where the order is written, one look-back scan launch follows.
 int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *order, void *workspace,
                           size_t workspace_bytes, int *stats, const float *xys, const float *conics,
-                          const float *opacities, int tiles_x, int tiles_y, void *recs, hipStream_t s) {
+                          const float *opacities, int tiles_x, int tiles_y, void *recs, const int *counts, int rows,
+                          int *cum, hipStream_t s) {
   using namespace gsr_bsort;
   if (n <= 0) return GSR_OK;
-  if (workspace_bytes < gsr_sort_bucket_workspace_bytes(n)) {
+  if (workspace_bytes < gsr_sort_bucket_workspace_bytes(n, counts ? rows : 0)) {
     gsr_set_error("sort_bucket_depth: workspace too small");
     return GSR_ENOMEM;
   }
@@ -762,19 +790,24 @@ int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *ord
   unsigned *map = reinterpret_cast<unsigned *>(ws);
   ws += 1024;
   if (!stats) stats = reinterpret_cast<int *>(ws);
+  ws += 256;
+  unsigned *scan_state = reinterpret_cast<unsigned *>(ws);
+  const int state_words = counts ? gsr_sort_mid_scan_state_words((long long)n * rows) : 0;
   const RecordArgs ra{xys, conics, opacities, tiles_x, tiles_y, static_cast<SplatRec *>(recs)};
+  const Gather ga{counts, cum, counts ? rows : 0, n};
   if (xys)
     hipLaunchKernelGGL(hist_kernel<true>, dim3(chunks), dim3(kHistThreads), sizeof(unsigned) * B, s, n, depths, radii,
-                       lb, table, map, ra);
+                       lb, table, map, ra, scan_state, state_words);
   else
     hipLaunchKernelGGL(hist_kernel<false>, dim3(chunks), dim3(kHistThreads), sizeof(unsigned) * B, s, n, depths, radii,
-                       lb, table, map, ra);
+                       lb, table, map, ra, scan_state, state_words);
   hipLaunchKernelGGL(scan_kernel, dim3(B / 16), dim3(256), 0, s, chunks, B, table, totals);
   hipLaunchKernelGGL(scatter_kernel, dim3(chunks), dim3(kScatterThreads), 0, s, n, depths, radii,
                      (const unsigned *)map, lb, (const unsigned *)table, (const unsigned *)totals, pairs, order,
-                     bucket_base, stats);
+                     bucket_base, stats, ga);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(gsr_cdiv((unsigned)(B - 1), 4)), dim3(kSortThreads), 0, s,
-                     (const unsigned *)map, B, (const unsigned *)bucket_base, pairs, pairs2, order);
+                     (const unsigned *)map, B, (const unsigned *)bucket_base, pairs, pairs2, order, ga);
   GSR_CHECK_LAUNCH("sort_bucket_depth");
+  if (counts) return gsr_sort_mid_scan_inplace((long long)n * rows, cum, scan_state, s);
   return GSR_OK;
 }

@@ -337,6 +337,21 @@ int gsr_sort_mid(int n, const unsigned *keys_in, int *vals_out, int key_bits, vo
   return gsr_sort_mid_pairs(n, keys_in, nullptr, nullptr, vals_out, key_bits, workspace, workspace_bytes, s);
 }
 
+// the look-back scan on its own (sort_bucket.hip gathers the counts itself)
+int gsr_sort_mid_scan_state_words(long long total) {
+  using namespace gsr_sort;
+  const long long tiles = (total + kScanTile - 1) / kScanTile;
+  return (int)(2 * (tiles + 1) + 2);
+}
+int gsr_sort_mid_scan_inplace(long long total, int *data, unsigned *state, hipStream_t s) {
+  using namespace gsr_sort;
+  if (total <= 0) return GSR_OK;
+  const int tiles = (int)((total + kScanTile - 1) / kScanTile);
+  hipLaunchKernelGGL(scan_lookback_kernel, dim3(tiles), dim3(kThreads), 0, s, (int)total, data, state);
+  GSR_CHECK_LAUNCH("sort_mid_scan_inplace");
+  return GSR_OK;
+}
+
 // ---- the depth ordering: order + inclusive prefix of the tile counts in that order -------
 // counts[rows][n] (index order) -> cum[rows * n]: inclusive scan of counts[r][order[i]] over
 // (r, i); counts == cum == nullptr: the order only.  Needs the workspace of gsr_sort_mid_workspace_bytes(n) + gsr_sort_mid_depth_extra(n, rows).

@@ -363,7 +363,7 @@ def test_cov2d_bounds():
     assert (r_g == r_r).mean() > 0.995 and np.abs(r_g - r_r).max() <= 1
 
 
-@pytest.mark.parametrize("n", [65_537, 100_000, 1_000_003, 4_194_304, 4_194_305])
+@pytest.mark.parametrize("n", [3_000, 4_097, 65_537, 100_000, 1_000_003, 4_194_304, 4_194_305])
 @pytest.mark.parametrize("dist", ["random", "equal", "two", "sorted", "reversed", "narrow"])
 def test_depth_order_sort_is_exact_and_stable(n, dist):
     """gsr_depth_order (purpose-built radix sort between 64k and 4M items, rocPRIM
@@ -421,7 +421,7 @@ def _depth_distributions(n, rng):
     yield "by_position", np.sort(rng.uniform(0.3, 30.0, n))[np.argsort(np.arange(n) % 977, kind="stable")]
 
 
-@pytest.mark.parametrize("n", [65_537, 300_000, 1_000_003, 1_572_865, 3_000_000, 4_194_304])
+@pytest.mark.parametrize("n", [4_096, 10_000, 65_537, 300_000, 1_000_003, 1_572_865, 3_000_000, 4_194_304])
 @pytest.mark.parametrize("mode", ["bucket", "auto"])
 def test_depth_order_without_counts_bucket_sort(n, mode, monkeypatch):
     """The order-only depth sort (lists without counts: the product path at >= 1 M list entries): one bucket pass + one
@@ -447,6 +447,13 @@ def test_depth_order_without_counts_bucket_sort(n, mode, monkeypatch):
         key = np.where(radii > 0, d, 0).astype(np.float32)
         ref = np.argsort(key.view(np.uint32), kind="stable").astype(np.int32)
         assert np.array_equal(npy(order), ref), (name, n, mode)
+        if n <= 1_000_003 and name in ("two_octaves", "normal", "half_equal", "outliers"):
+            # with counts (one per Gaussian, and three tile-row bands): gathered where the order is written, then scanned
+            for rows in (1, 3):
+                tiles = rng.integers(0, 5, (rows, n)).astype(np.int32) * (radii > 0)
+                order2, cum2 = C.depth_order(cu(d), cu(radii), cu(tiles.reshape(-1)))
+                assert np.array_equal(npy(order2), ref), (name, n, mode, rows)
+                assert np.array_equal(npy(cum2), np.cumsum(tiles[:, ref].reshape(-1)).astype(np.int32)), (name, n, rows)
 
 
 @pytest.mark.parametrize("n,W,H,ck,opac_hi", [(3000, 160, 96, {}, 1.0), (20_000, 317, 203, {"yaw": 0.3}, 1.0),
