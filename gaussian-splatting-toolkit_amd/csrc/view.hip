@@ -85,8 +85,11 @@ GSR_EXPORT int gsr_view_backward(const gsr_view_desc *v, const gsr_view_grads *g
   if (g->stats_first != nullptr)
     GSR_TRY(gsr_densify_stats_dev(n, v_xy, v->radii, g->stats_inv_size, g->stats_first, g->xys_grad_norm,
                                   g->vis_counts, g->max_2dsize, stream));
-  GSR_TRY(gsr_sh_backward_split((unsigned)n, (unsigned)v->sh_degree, (unsigned)v->sh_degree_to_use, v->dirs, v_colors,
-                                v->colors, g->v_dc, g->v_rest, stream));
+  // v_dc == NULL: the caller forms the SH gradient itself from the colour cotangents left in the accumulators (data
+  // parallel: gathered over the ranks, gsr_sh_backward_views)
+  if (g->v_dc != nullptr)
+    GSR_TRY(gsr_sh_backward_split((unsigned)n, (unsigned)v->sh_degree, (unsigned)v->sh_degree_to_use, v->dirs,
+                                  v_colors, v->colors, g->v_dc, g->v_rest, stream));
   GSR_TRY(gsr_project_backward(n, v->means, v->scales, v->glob_scale, v->quats, v->viewmat, v->projmat, v->fx, v->fy,
                                v->cx, v->cy, (unsigned)v->img_height, (unsigned)v->img_width, v->cov3d, v->radii,
                                v->conics, v->comp, v_xy, v->render_depth ? v_extra : nullptr, v_conic, nullptr,

@@ -121,7 +121,8 @@ class DensifyStats:
 class _Render(Function):
     @staticmethod
     def forward(ctx, means, log_scales, raw_quats, logits, features_dc, features_rest, viewmat, projmat, campos,
-                background, spec: ViewSpec, capacity: int, count_out: Tensor, stats: Optional[DensifyStats]):
+                background, spec: ViewSpec, capacity: int, count_out: Tensor, stats: Optional[DensifyStats],
+                sh_collector=None):
         n = means.shape[0]
         dev = means.device
         H, W = spec.height, spec.width
@@ -154,6 +155,7 @@ class _Render(Function):
                              0 if acc is None else acc.numel() * 4)
             _call("gsr_view_forward", C.byref(desc), _stream(dev))
         ctx.spec, ctx.stats, ctx.degree = spec, stats, degree
+        ctx.sh_collector = sh_collector
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(means, raw_quats, features_dc, features_rest, viewmat, projmat, background, scales, quats,
                               opac, dirs, cov3d, xys, depths, radii, conics, comp, colors, ids, bins, Ts, idx)
@@ -187,7 +189,11 @@ class _Render(Function):
             e = lambda shape: torch.empty(shape, dtype=_f32, device=dev)
             t_cov2d, t_cov3d, t_vs, t_vq = e((n, 3)), e((n, 6)), e((n, 3)), e((n, 4))
             v_means, g_s, g_q, g_o = e((n, 3)), e((n, 3)), e((n, 4)), torch.empty_like(opac)
-            v_dc, v_rest = torch.empty_like(features_dc), torch.empty_like(features_rest)
+            collector = ctx.sh_collector
+            if collector is None:
+                v_dc, v_rest = torch.empty_like(features_dc), torch.empty_like(features_rest)
+            else:  # data parallel: the SH gradient is formed from the ranks' gathered colour cotangents
+                v_dc = v_rest = None
             use_stats = stats is not None and stats.enabled
             p = lambda t: None if t is None else t.data_ptr()
             desc = _ViewDesc(n, ctx.degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy,
@@ -205,13 +211,19 @@ class _Render(Function):
             _call("gsr_view_backward", C.byref(desc), C.byref(grads), _stream(dev))
             if use_stats:
                 stats.first.zero_()
-        return (v_means, g_s, g_q, g_o, v_dc, v_rest) + (None,) * 8
+            if collector is not None:
+                # the colour cotangents the compositing backward left in the accumulators, cut where the forward's
+                # clamp cut the colour (marked -0.0), as gsr_sh_backward_split would have cut them
+                v_col = acc[5 * n:8 * n].view(n, 3)
+                cut = colors.view(torch.int32) == -2147483648
+                collector.offer(torch.where(cut, torch.zeros((), dtype=_f32, device=dev), v_col).contiguous())
+        return (v_means, g_s, g_q, g_o, v_dc, v_rest) + (None,) * 9
 
 
 def render_gaussians(means: Tensor, log_scales: Tensor, raw_quats: Tensor, opacity_logits: Tensor,
                      features_dc: Tensor, features_rest: Tensor, viewmat: Tensor, projmat: Tensor, campos: Tensor,
                      background: Tensor, spec: ViewSpec, capacity: int, count_out: Optional[Tensor] = None,
-                     stats: Optional[DensifyStats] = None) -> Dict[str, Optional[Tensor]]:
+                     stats: Optional[DensifyStats] = None, sh_collector=None) -> Dict[str, Optional[Tensor]]:
     """The raw parameters of a Gaussian model -> ``{"rgb" [H,W,3] (not clamped at 1), "alpha"
     [H,W], "depth" [H,W] or None (accumulated, not divided by alpha), "radii" [N] i32,
     "count" int32[1]}``.
@@ -220,7 +232,10 @@ def render_gaussians(means: Tensor, log_scales: Tensor, raw_quats: Tensor, opaci
     all on the device.  ``capacity``: entries the tile lists are sized for; ``count`` receives
     the entries the view really needs -- if it exceeds the capacity the lists were cut and
     the result is incomplete: render again with a larger capacity (`ListCapacity`).
-    ``count_out`` may be a caller-owned int32[1] (device, or pinned host memory)."""
+    ``count_out`` may be a caller-owned int32[1] (device, or pinned host memory).    ``sh_collector`` (data parallel, `harness.parallel.GradientExchange.begin_sh_views`): the backward skips its SH
+    backward, hands the colour cotangents [N,3] to ``sh_collector.offer`` and returns no gradient for
+    ``features_dc`` / ``features_rest`` -- the exchange forms it from all ranks' cotangents.
+    """
     n = means.shape[0]
     if features_dc.shape != (n, 3) or features_rest.dim() != 3 or features_rest.shape[1] + 1 not in (1, 4, 9, 16):
         raise ValueError("features_dc [N,3] and features_rest [N,K-1,3] with K in (1, 4, 9, 16) expected")
@@ -234,7 +249,7 @@ def render_gaussians(means: Tensor, log_scales: Tensor, raw_quats: Tensor, opaci
     out = _Render.apply(means.contiguous(), log_scales.contiguous(), raw_quats.contiguous(),
                         opacity_logits.contiguous(), features_dc.contiguous(), features_rest.contiguous(),
                         vm.contiguous(), projmat.contiguous(), campos.contiguous(), background.contiguous(), spec,
-                        int(capacity), count_out, stats)
+                        int(capacity), count_out, stats, sh_collector)
     return {"rgb": out[0], "alpha": out[1], "radii": out[2], "depth": out[3] if spec.render_depth else None,
             "count": count_out}
 

@@ -210,14 +210,24 @@ class GradientExchange:
         ("features_dc", "features_rest") or ("sh_coeffs",)) are formed by `finish()`.  `clamped`: `sh_fn` applied the
         models' `clamp(rgbs + 0.5, min=0)` epilogue and marked the cut channels with -0.0.  Returns None when the
         exchange is off or runs without hooks: the caller then evaluates SH the ordinary way."""
-        if not (self.enabled and self.use_hooks):
+        if self.begin_sh_views(names, params, means3d, campos, degree, degrees_to_use) is None:
             return None
         with torch.no_grad():
             colors = sh_fn()
-        self._sh = {"names": tuple(names), "params": tuple(params), "means": means3d.detach(),
-                    "campos": campos.detach().reshape(3).to(colors.dtype), "degree": int(degree),
-                    "deg_use": int(degrees_to_use)}
         return _CaptureColorGrad.apply(colors, self, bool(clamped), *params)
+
+    def begin_sh_views(self, names, params, means3d, campos, degree, degrees_to_use):
+        """Announce that this step's SH gradient arrives as colour cotangents: the caller's backward must call
+        `offer(v_colors)` once (v_colors [N,3], the clamp of the colours already applied) and leave the `.grad` of
+        `params` alone; `finish()` sets them.  -> self (the collector), or None when the exchange is off or runs
+        without hooks.  (`deferred_sh_colors` is this + the capture node; `gs_fused.render_gaussians(...,
+        sh_collector=)` calls `offer` from its one native backward.)"""
+        if not (self.enabled and self.use_hooks):
+            return None
+        self._sh = {"names": tuple(names), "params": tuple(params), "means": means3d.detach(),
+                    "campos": campos.detach().reshape(3).to(means3d.dtype), "degree": int(degree),
+                    "deg_use": int(degrees_to_use)}
+        return self
 
     def offer(self, v_colors: torch.Tensor) -> None:
         """(from the backward of `deferred_sh_colors`) start the all-gather of [v_colors | campos]."""

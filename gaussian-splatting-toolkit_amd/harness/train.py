@@ -460,7 +460,8 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     t0 = time.perf_counter()
     use_fused = (cfg.fused_render or cfg.use_graph) and device.type == "cuda" and cfg.split_sh and cfg.fused_loss \
         and cfg.sh_degree in (0, 1, 2, 3)
-    sh_views = world > 1 and cfg.sh_exchange == "views" and exchange.enabled and exchange.use_hooks and not use_fused
+    # (through the one native call per view as well, but not under graph replay: no hooks there)
+    sh_views = world > 1 and cfg.sh_exchange == "views" and exchange.enabled and exchange.use_hooks
     if sh_views and device.type != "cuda":
         exchange.sh_views_backward = _sh_views_backward_autograd()  # no native kernel here: autograd of the SH op
     fstats = caps = vgraph = vkey = None
@@ -522,9 +523,12 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                 zero_grads()
                 slot = caps.slot(device)
                 used = caps.capacity
+                collector = exchange.begin_sh_views(("features_dc", "features_rest"),
+                                                    (g_["features_dc"], g_["features_rest"]), g_["means"], cam.campos,
+                                                    cfg.sh_degree, deg) if sh_views else None
                 out = render_gaussians(g_["means"], g_["scales"], g_["quats"], g_["opacities"], g_["features_dc"],
                                        g_["features_rest"], cam.viewmat, cam.projmat, cam.campos, bg, spec, used,
-                                       count_out=slot, stats=fstats)
+                                       count_out=slot, stats=fstats, sh_collector=collector)
                 loss = loss_fn(out["rgb"], gt[v])
                 loss.backward()
                 caps.submitted(slot, used, device)

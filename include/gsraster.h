@@ -562,7 +562,9 @@ typedef struct gsr_view_desc {
 /* cotangents in, parameter gradients out.  accumulators: (9 + render_depth) n floats laid out
  * v_xy | v_conic | v_colors | v_opacity [| v_depths]; accumulators_zeroed != 0 when the forward's
  * launch cleared them (zero_ptr).  stats_first != NULL: also after_train's statistics
- * (gsr_densify_stats_dev).  tmp_*: scratch of [n,3] [n,6] [n,3] [n,4] floats. */
+ * (gsr_densify_stats_dev).  tmp_*: scratch of [n,3] [n,6] [n,3] [n,4] floats.  v_dc == NULL: no SH backward --
+ * the colour cotangents stay in the accumulators (before the clamp of the colours is applied to them) for a caller
+ * that forms the SH gradient over several views (gsr_sh_backward_views). */
 typedef struct gsr_view_grads {
   const float *v_img, *v_alpha, *v_depth; /* v_alpha / v_depth nullable (v_depth required iff render_depth) */
   float *accumulators;

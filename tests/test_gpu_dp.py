@@ -38,8 +38,9 @@ def _run(rank, world, port, q, mode="plain"):
                         stop_split_at=150, densify_grad_thresh=0.0004)
     cfg = HT.TrainConfig(num_gaussians=12_000, init_gaussians=3_000, width=256, height=160, num_views=6, iters=140,
                          sh_degree=2, sh_degree_interval=40, eval_views=2, densify=True, refine=rcfg, log_every=10)
-    cfg.sh_exchange = "views" if mode.endswith("views") else "dense"
-    if mode in ("det", "det+sharded", "det+views"):
+    cfg.sh_exchange = "views" if "views" in mode else "dense"
+    cfg.fused_render = mode.endswith("+oneop")
+    if mode.startswith("det"):
         from rasterizer import rasterize as R
 
         R.set_deterministic(True)  # bit-reproducible compositing backward: runs become comparable bit for bit
@@ -121,6 +122,11 @@ def test_gathered_colour_cotangents_against_the_all_reduce_on_the_hip_path():
     `sh_views`, `gsr_sh_backward_views`) against the all-reduced one, both with the deterministic compositing
     backward: replicas bit-identical, same refinement history, parameters equal to rounding, fewer bytes."""
     dense, views = _launch("det"), _launch("det+views")
+    one = _launch("det+views+oneop")  # ... and through the one native call per view (its backward skips the SH backward)
+    # (its compositing backward sums with float atomics: replicas identical, the run itself not bit-reproducible)
+    assert one[0][1] == one[1][1] and one[0][9] == views[0][9] and one[0][4] == one[1][4]
+    assert abs(one[0][3] - views[0][3]) <= 0.03 * views[0][3], (one[0][3], views[0][3])
+    assert abs(one[0][1] - views[0][1]) <= 2e-3 * abs(views[0][1]), (one[0][1], views[0][1])
     assert views[0][1] == views[1][1] and math.isfinite(views[0][1])
     assert views[0][9].startswith("all-reduce (geometry) + all-gathered") and dense[0][9] == "all-reduce + Adam"
     assert views[0][4] == dense[0][4] and len(views[0][4]) >= 3, (views[0][4], dense[0][4])
