@@ -4,18 +4,19 @@
 // (key, index) pair through HBM four times and spend most of their 100 us on launch/latency chains.
 // Depths of one view are not arbitrary 31-bit numbers, so four launches do:
 //   hist      every workgroup first derives the SAME monotone bucket map from the same 4096 sampled keys: the
-//             sample's population per float octave (exponent) decides how many of the B buckets the octave gets
-//             (a power of two, so bucket = base[exp] + (mantissa >> (23 - k[exp])): linear in depth inside an
-//             octave, population-proportional across octaves); octaves outside the sampled window fall into an
-//             underflow / overflow bucket; bucket 0 = culled.  Then an LDS histogram of its 4096-item chunk
-//             over all B buckets -> table[chunk][B]
+//             sample's population per float octave (exponent) decides how many of the B buckets the octave gets,
+//             spread linearly over its mantissas (over the part of them the sample's smallest / largest key bound,
+//             in the first / last octave): linear in depth inside an octave, population-proportional across
+//             octaves; octaves outside the sampled window fall into an underflow / overflow bucket; bucket 0 =
+//             culled.  Then an LDS histogram of its 4096-item chunk over all B buckets -> table[chunk][B]
 //   scan      every bucket's column of the table, exclusive, in place, + the bucket's total
 //   scatter   items in registers; slot = bucket's first slot + its items in earlier chunks + in earlier waves of
 //             the chunk + rank in the wave (wave-level matching on the bucket bits, wave-private counters):
 //             stable without sorting the chunk; writes (key, index) pairs, bucket 0 straight into the order
-//   sort      four adjacent buckets per workgroup, one WAVE each (<= 1024 items, no barrier), by the mantissa
-//             bits the bucket map did not use, stable; larger buckets by the whole workgroup (<= 2048 in LDS,
-//             above that -- and the under/overflow buckets, on full keys -- LSD rounds through HBM)
+//   sort      four adjacent buckets per workgroup, one WAVE each (<= 1024 items, no barrier), stable, by
+//             (key - the bucket's smallest key), whose few bits the wave takes from the data; larger buckets by the
+//             whole workgroup (<= 2048 in LDS, above that -- and the under/overflow buckets -- LSD rounds
+//             through HBM)
 // Monotone bucket map + stable passes = the same permutation as the LSD sort (and as a stable sort of the
 // keys): ties keep ascending index.  The sample only shapes the map: any map built this way is monotone, so
 // the result never depends on it, only the balance of the buckets does.  gsr_depth_order looks at the largest
@@ -71,20 +72,26 @@ __device__ __forceinline__ unsigned long long match_digit(const unsigned d, cons
 }
 
 // ---- the bucket map -----------------------------------------------------------------------------------
-// map[exp] = (W << 16) | base: bucket = base + ((mantissa * W) >> 23), W buckets for the octave; W == 0: every key of
-// the octave goes to bucket `base` (the underflow bucket 1, the overflow bucket B - 1)
+// One entry per float octave (exponent): W buckets from `base` on, spread linearly over the mantissas [mlo, mlo + span)
+// (the whole octave, except in the sample's first and last octave, which the depths fill only partly: there the
+// sample's smallest / largest key bound the range, padded by 1/32; keys beyond it fall into the octave's first /
+// last bucket):  bucket = base + min(W - 1, (unsigned)(float(clamp(mantissa - mlo, 0, span - 1)) * c)),  c = W / span.
+// Every step is monotone in the key, whatever the table holds; octaves outside the sampled window (+- 1) have
+// W = 1 and base = the underflow bucket 1 / the overflow bucket B - 1.
+struct OctaveMap {
+  unsigned base_w;  // base | W << 16
+  unsigned mlo, span;
+  float c;
+};
 constexpr unsigned kMinWidth = 16;  // (a bucket spans at most 2^23 / 16 + 1 mantissas: 20 bits)
 constexpr int kSample = 4096;
 
-__device__ __forceinline__ unsigned bucket_of(const unsigned key, const unsigned *__restrict__ map) {
+__device__ __forceinline__ unsigned bucket_of(const unsigned key, const OctaveMap *__restrict__ map) {
   if (!key) return 0u;
-  const unsigned t = map[key >> 23], W = t >> 16, base = t & 0xffffu;
-  return base + __umulhi(key << 9, W);  // ((key & 0x7fffff) * W) >> 23
-}
-
-// the smallest mantissa of local bucket j of an octave with W buckets
-__device__ __forceinline__ unsigned bucket_first_mantissa(const unsigned j, const unsigned W) {
-  return (unsigned)((((unsigned long long)j << 23) + W - 1u) / W);
+  const OctaveMap t = map[key >> 23];
+  const unsigned mant = key & 0x7fffffu, W = t.base_w >> 16, base = t.base_w & 0xffffu;
+  const unsigned d = min(mant > t.mlo ? mant - t.mlo : 0u, t.span - 1u);
+  return base + min(W - 1u, (unsigned)((float)d * t.c));
 }
 
 // Called by all threads of a workgroup (blockDim.x >= 256, whole waves); afterwards map[0..256) (LDS) holds the
@@ -107,11 +114,12 @@ __device__ __forceinline__ void load_samples(const int n, const float *__restric
 // table.  Integer arithmetic on the same samples: every workgroup derives the same table.
 template <int kT>
 __device__ __forceinline__ void build_bucket_map(const unsigned (&sample)[kSample / kT], const int log2_buckets,
-                                                 unsigned *__restrict__ map, unsigned *__restrict__ oct,
-                                                 int *__restrict__ sh /* >= 16 words */) {
+                                                 OctaveMap *__restrict__ map, unsigned *__restrict__ oct,
+                                                 int *__restrict__ sh /* >= 24 words */) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const unsigned B = 1u << log2_buckets;
   if (tid < 256) oct[tid] = 0u;
+  if (tid == 0) sh[16] = -1, sh[17] = 0;  // (unsigned min / max of the sampled keys)
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < kSample / kT; ++q) {  // one LDS atomic per (wave, octave), not per sample
@@ -119,6 +127,14 @@ __device__ __forceinline__ void build_bucket_map(const unsigned (&sample)[kSampl
     if (sample[q] && (peers & ((1ull << lane) - 1ull)) == 0) atomicAdd(&oct[sample[q] >> 23], (unsigned)__popcll(peers));
   }
   __syncthreads();
+  {  // the sample's smallest and largest visible key: what the first and the last octave really hold
+    unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+    for (int q = 0; q < kSample / kT; ++q)
+      if (sample[q]) kmin = min(kmin, sample[q]), kmax = max(kmax, sample[q]);
+    wave_minmax(kmin, kmax);
+    if (lane == 0) atomicMin(reinterpret_cast<unsigned *>(&sh[16]), kmin), atomicMax(reinterpret_cast<unsigned *>(&sh[17]), kmax);
+  }
   unsigned pop = 0;
   int first = 256, last = -1;
   if (tid < 256) {
@@ -156,7 +172,20 @@ __device__ __forceinline__ void build_bucket_map(const unsigned (&sample)[kSampl
   if (tid < 256) {
     unsigned base = 2u + incl - width;
     for (int q = 0; q < w; ++q) base += (unsigned)sh[q];
-    map[tid] = tid > hi ? (B - 1u) : tid < lo ? 1u : (width << 16) | base;
+    OctaveMap t{(1u << 16) | (tid > hi ? B - 1u : 1u), 0u, 1u, 0.f};
+    if (inside) {
+      const unsigned kmin = (unsigned)sh[16], kmax = (unsigned)sh[17];
+      unsigned m0 = 0u, m1 = 0x7fffffu;
+      if (tid == first) m0 = kmin & 0x7fffffu;
+      if (tid == last) m1 = kmax & 0x7fffffu;
+      const unsigned pad = (m1 - m0 + 1u) >> 5;
+      if (tid == first) m0 = m0 > pad ? m0 - pad : 0u;
+      if (tid == last) m1 = min(m1 + pad, 0x7fffffu);
+      t.base_w = (width << 16) | base;
+      t.mlo = m0, t.span = m1 - m0 + 1u;
+      t.c = (float)width / (float)t.span;
+    }
+    map[tid] = t;
   }
   __syncthreads();
 }
@@ -174,11 +203,12 @@ template <bool kRecords>
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const int n, const float *__restrict__ depths,
                                                             const int *__restrict__ radii, const int log2_buckets,
                                                             unsigned *__restrict__ table,
-                                                            unsigned *__restrict__ map_out, const RecordArgs ra,
+                                                            OctaveMap *__restrict__ map_out, const RecordArgs ra,
                                                             unsigned *__restrict__ zero, const int zero_words) {
   extern __shared__ unsigned h[];  // B counters
-  __shared__ unsigned map[256], oct[256];
-  __shared__ int sh[16];
+  __shared__ OctaveMap map[256];
+  __shared__ unsigned oct[256];
+  __shared__ int sh[24];
   constexpr int kI = kChunk / kHistThreads;
   const int tid = threadIdx.x, B = 1 << log2_buckets;
   const int base = blockIdx.x * kChunk;
@@ -364,13 +394,14 @@ __device__ __forceinline__ unsigned long long match12(const unsigned d, const bo
 
 __global__ __launch_bounds__(kScatterThreads) void scatter_kernel(
     const int n, const float *__restrict__ depths, const int *__restrict__ radii,
-    const unsigned *__restrict__ map_in, const int log2_buckets, const unsigned *__restrict__ table,
+    const OctaveMap *__restrict__ map_in, const int log2_buckets, const unsigned *__restrict__ table,
     const unsigned *__restrict__ totals,
     uint2 *__restrict__ pairs, int *__restrict__ order, unsigned *__restrict__ bucket_base,
     int *__restrict__ stats, const Gather ga) {
   __shared__ unsigned arr[kSweep];
   __shared__ unsigned short cnt[kScatterWaves][kSweep];
-  __shared__ unsigned s_sum[kScatterWaves], s_max[kScatterWaves], map[256];
+  __shared__ unsigned s_sum[kScatterWaves], s_max[kScatterWaves];
+  __shared__ OctaveMap map[256];
   constexpr int kI = kScatterItems, seg = kChunk / kScatterWaves, kPer = kSweep / kScatterThreads;
   const int B = 1 << log2_buckets;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -497,27 +528,41 @@ struct BlockShared {
   SortShared<4> S;
 };
 
-// One wave, m <= 64 kI items, no barrier: the rounds of rank_round / block_sort with wave-private state.  (The item
-// count per lane is a template parameter: with a run-time count the sixteen predicated copies of the ranking step
-// cost 216 VGPRs and spill the SGPRs.)
+// One wave, m <= 64 kI items, no barrier: the rounds of rank_round / block_sort with wave-private state.  The keys
+// of a bucket differ in few bits: they are sorted as (key - smallest key of the bucket), whose width the wave takes
+// from the data.  -> false when those bits and the item's position do not fit one word (a bucket that caught keys from
+// beyond the sampled range): the workgroup then takes it through the slow path.  (The item count per lane is a
+// template parameter: with a run-time count the sixteen predicated copies of the ranking step cost 216 VGPRs and
+// spill the SGPRs.)
 template <int kI>
-__device__ __forceinline__ void wave_sort(const unsigned s, const int m, const int lowbits, const unsigned sub,
-                                          const uint2 *__restrict__ pairs, int *__restrict__ order, const Gather &ga,
-                                          WaveShared &W) {
+__device__ __forceinline__ bool wave_sort(const unsigned s, const int m, const uint2 *__restrict__ pairs,
+                                          int *__restrict__ order, const Gather &ga, WaveShared &W) {
+  constexpr int kEBits = kI == 1 ? 6 : kI == 2 ? 7 : kI == 4 ? 8 : kI == 8 ? 9 : 10;
   const int lane = threadIdx.x & 63;
   const unsigned long long lt = (1ull << lane) - 1ull;
   unsigned v[kI], rank[kI];
+  unsigned kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
   for (int i = 0; i < kI; ++i) {
     const int e = i * 64 + lane;
     const uint2 pr = pairs[s + min(e, m - 1)];  // (unconditional: the loads of all rounds go out together)
     if (e < m) W.ids[e] = pr.y;
-    v[i] = e < m ? ((pr.x - sub) << kElemBits) | (unsigned)e : 0u;
+    v[i] = pr.x;
+    kmin = min(kmin, pr.x), kmax = max(kmax, pr.x);  // (a clamped duplicate changes neither)
+  }
+  wave_minmax(kmin, kmax);
+  kmin = __builtin_amdgcn_readfirstlane(kmin), kmax = __builtin_amdgcn_readfirstlane(kmax);
+  const int lowbits = kmax > kmin ? 32 - __clz((int)(kmax - kmin)) : 0;
+  if (lowbits + kEBits > 32) return false;
+#pragma unroll
+  for (int i = 0; i < kI; ++i) {
+    const int e = i * 64 + lane;
+    v[i] = e < m ? ((v[i] - kmin) << kEBits) | (unsigned)e : 0u;
   }
   int rounds = (lowbits + 7) / 8;
   for (int done = 0; done < lowbits;) {
     const int bits = (lowbits - done + rounds - 1) / rounds;
-    const int shf = kElemBits + done;
+    const int shf = kEBits + done;
     const unsigned mask = (1u << bits) - 1u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) W.cnt[q * 64 + lane] = 0u;
@@ -558,16 +603,19 @@ __device__ __forceinline__ void wave_sort(const unsigned s, const int m, const i
   }
 #pragma unroll
   for (int i = 0; i < kI; ++i)
-    if (i * 64 + lane < m) place(order, ga, s + i * 64 + lane, (int)W.ids[v[i] & ((1u << kElemBits) - 1u)]);
+    if (i * 64 + lane < m) place(order, ga, s + i * 64 + lane, (int)W.ids[v[i] & ((1u << kEBits) - 1u)]);
+  return true;
 }
 
 // The slow path of a bucket above kCap items: LSD rounds through HBM (pairs <-> pairs2), one workgroup.
-__device__ __noinline__ void sort_large_bucket(const unsigned s, const unsigned m, const int lowbits, const unsigned sub,
-                                               uint2 *pairs, uint2 *pairs2,
-                                  int *__restrict__ order, const Gather &ga, unsigned *run, SortShared<4> &S) {
+__device__ __noinline__ void sort_large_bucket(const unsigned s, const unsigned m, uint2 *pairs, uint2 *pairs2,
+                                               int *__restrict__ order, const Gather &ga, unsigned *run,
+                                               SortShared<4> &S) {
   constexpr int kI = 4, kTile = kI * kSortThreads;  // (small tiles: few registers; speed is not the point here)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  {  // all keys equal: the scatter's order is final
+  unsigned sub;
+  int lowbits;
+  {  // the bucket's key range; all keys equal: the scatter's order is final
     unsigned lo = 0xffffffffu, hi = 0u;
     for (unsigned e = tid; e < m; e += kSortThreads) {
       const unsigned k = pairs[s + e].x;
@@ -583,6 +631,7 @@ __device__ __noinline__ void sort_large_bucket(const unsigned s, const unsigned 
       for (unsigned e = tid; e < m; e += kSortThreads) place(order, ga, s + e, (int)pairs[s + e].y);
       return;
     }
+    sub = lo, lowbits = 32 - __clz((int)(hi - lo));
   }
   uint2 *src = pairs, *dst = pairs2;
   int rounds = (lowbits + 7) / 8;
@@ -641,20 +690,35 @@ __device__ __noinline__ void sort_large_bucket(const unsigned s, const unsigned 
   for (unsigned e = tid; e < m; e += kSortThreads) place(order, ga, s + e, (int)src[s + e].y);
 }
 
-// One workgroup, m <= 256 kI items.
+// One workgroup, m <= 256 kI items (kI <= 8: positions take 11 bits).  -> false: key range too wide to pack.
 template <int kI>
-__device__ __forceinline__ void block_bucket(const unsigned s, const int m, const int lowbits, const unsigned sub,
-                                             const uint2 *__restrict__ pairs, int *__restrict__ order,
-                                             const Gather &ga, BlockShared &L) {
+__device__ __forceinline__ bool block_bucket(const unsigned s, const int m, const uint2 *__restrict__ pairs,
+                                             int *__restrict__ order, const Gather &ga, BlockShared &L) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   constexpr int seg = kI * 64;
   unsigned v[kI];
+  unsigned kmin = 0xffffffffu, kmax = 0u;
 #pragma unroll
   for (int i = 0; i < kI; ++i) {
     const int e = w * seg + i * 64 + lane;
     const uint2 pr = pairs[s + min(e, m - 1)];  // (unconditional: the loads of all rounds go out together)
     if (e < m) L.idL[e] = pr.y;
-    v[i] = e < m ? ((pr.x - sub) << kElemBits) | (unsigned)e : 0u;
+    v[i] = pr.x;
+    kmin = min(kmin, pr.x), kmax = max(kmax, pr.x);
+  }
+  wave_minmax(kmin, kmax);
+  if (lane == 0) L.S.cnt[0][w] = kmin, L.S.cnt[1][w] = kmax;
+  __syncthreads();
+  kmin = min(min(L.S.cnt[0][0], L.S.cnt[0][1]), min(L.S.cnt[0][2], L.S.cnt[0][3]));
+  kmax = max(max(L.S.cnt[1][0], L.S.cnt[1][1]), max(L.S.cnt[1][2], L.S.cnt[1][3]));
+  kmin = __builtin_amdgcn_readfirstlane(kmin), kmax = __builtin_amdgcn_readfirstlane(kmax);
+  __syncthreads();
+  const int lowbits = kmax > kmin ? 32 - __clz((int)(kmax - kmin)) : 0;
+  if (lowbits + kElemBits > 32) return false;
+#pragma unroll
+  for (int i = 0; i < kI; ++i) {
+    const int e = w * seg + i * 64 + lane;
+    v[i] = e < m ? ((v[i] - kmin) << kElemBits) | (unsigned)e : 0u;
   }
   block_sort<4, kI>(v, kI, seg, m, kElemBits, lowbits, L.buf, L.S);
 #pragma unroll
@@ -662,11 +726,12 @@ __device__ __forceinline__ void block_bucket(const unsigned s, const int m, cons
     const int e = w * seg + i * 64 + lane;
     if (e < m) place(order, ga, s + e, (int)L.idL[v[i] & ((1u << kElemBits) - 1u)]);
   }
+  return true;
 }
 
 // A workgroup takes four adjacent buckets: each wave sorts one (<= 1024 items) on its own; larger ones are
 // then taken one at a time by the whole workgroup.
-__global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(const unsigned *__restrict__ map_in, const int B,
+__global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(const int B,
                                                                    const unsigned *__restrict__ bucket_base,
                                                                    uint2 *pairs, uint2 *pairs2,
                                                                    int *__restrict__ order, const Gather ga) {
@@ -674,65 +739,45 @@ __global__ __launch_bounds__(kSortThreads) void bucket_sort_kernel(const unsigne
     WaveShared wave[4];
     BlockShared blk;
   } L;
-  __shared__ unsigned map[256];
   __shared__ unsigned s_start[5];
+  __shared__ int s_left[4];  // bucket k still to be sorted by the whole workgroup
   const int tid = threadIdx.x, w = tid >> 6;
   const int b0 = 1 + 4 * blockIdx.x;
-  map[tid] = map_in[tid];
   if (tid < 5) s_start[tid] = bucket_base[min(b0 + tid, B)];
   __syncthreads();
-  // the mantissa bits bucket b's keys still differ in (they share the exponent and the bits the map used); the
-  // under/overflow buckets hold keys of any octave: all 31 bits, through the slow path whatever their size
-  // -> (bits, subtrahend): the bucket's keys minus `subtrahend` fit `bits` bits and order like the keys
-  auto low_bits_of = [&](const int b, const unsigned first_slot, unsigned &sub) -> int {
-    sub = 0u;
-    if (b == 1 || b == B - 1) return 31;
-    const unsigned key = pairs[first_slot].x, t = map[key >> 23], W = t >> 16, base = t & 0xffffu;
-    sub = (key & 0x7f800000u) | bucket_first_mantissa((unsigned)b - base, W);
-    return 32 - __clz((int)((1u << 23) / W + 1u));
-  };
-  bool any_large = false;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const unsigned m = s_start[k + 1] - s_start[k];
-    any_large |= m > (unsigned)kWaveCap || (m > 0 && (b0 + k == 1 || b0 + k == B - 1));
-  }
   {
     // (wave-uniform values, told to the compiler: as vector values every `bit < bits` is a divergent branch)
     const unsigned sw = __builtin_amdgcn_readfirstlane(s_start[w]);
     const unsigned mw = __builtin_amdgcn_readfirstlane(s_start[w + 1]) - sw;
     const int b = b0 + __builtin_amdgcn_readfirstlane(w);
-    if (mw > 0 && mw <= (unsigned)kWaveCap && b != 1 && b < B - 1) {
-      unsigned sub;
-      const int lowbits = __builtin_amdgcn_readfirstlane(low_bits_of(b, sw, sub));
-      sub = __builtin_amdgcn_readfirstlane(sub);
+    // the under/overflow buckets hold keys of any octave: through the slow path, on full keys, whatever their size
+    bool left = mw > 0 && b < B;
+    if (left && mw <= (unsigned)kWaveCap && b != 1 && b != B - 1) {
       if (mw <= 64)
-        wave_sort<1>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
+        left = !wave_sort<1>(sw, (int)mw, pairs, order, ga, L.wave[w]);
       else if (mw <= 128)
-        wave_sort<2>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
+        left = !wave_sort<2>(sw, (int)mw, pairs, order, ga, L.wave[w]);
       else if (mw <= 256)
-        wave_sort<4>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
+        left = !wave_sort<4>(sw, (int)mw, pairs, order, ga, L.wave[w]);
       else if (mw <= 512)
-        wave_sort<8>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
+        left = !wave_sort<8>(sw, (int)mw, pairs, order, ga, L.wave[w]);
       else
-        wave_sort<16>(sw, (int)mw, lowbits, sub, pairs, order, ga, L.wave[w]);
+        left = !wave_sort<16>(sw, (int)mw, pairs, order, ga, L.wave[w]);
     }
+    if ((tid & 63) == 0) s_left[w] = left;
   }
-  if (!any_large) return;  // (uniform)
+  __syncthreads();
+  if (!(s_left[0] | s_left[1] | s_left[2] | s_left[3])) return;  // (uniform)
   for (int k = 0; k < 4; ++k) {
+    if (!s_left[k]) continue;
     const unsigned s = __builtin_amdgcn_readfirstlane(s_start[k]);
     const unsigned m = __builtin_amdgcn_readfirstlane(s_start[k + 1]) - s;
     const int b = b0 + k;
-    const bool whole = b == 1 || b == B - 1;
-    if (m == 0 || b >= B || (m <= (unsigned)kWaveCap && !whole)) continue;
     __syncthreads();
-    unsigned sub;
-    const int lowbits = __builtin_amdgcn_readfirstlane(low_bits_of(b, s, sub));
-    sub = __builtin_amdgcn_readfirstlane(sub);
-    if (whole || m > (unsigned)kCap)
-      sort_large_bucket(s, m, lowbits, sub, pairs, pairs2, order, ga, L.blk.buf, L.blk.S);
-    else
-      block_bucket<8>(s, (int)m, lowbits, sub, pairs, order, ga, L.blk);
+    if (b == 1 || b == B - 1 || m > (unsigned)kCap || !block_bucket<8>(s, (int)m, pairs, order, ga, L.blk)) {
+      __syncthreads();
+      sort_large_bucket(s, m, pairs, pairs2, order, ga, L.blk.buf, L.blk.S);
+    }
   }
 }
 
@@ -747,7 +792,7 @@ size_t gsr_sort_bucket_workspace_bytes(int n, int rows) {
   using namespace gsr_bsort;
   const size_t chunks = gsr_cdiv((unsigned)n, kChunk), B = (size_t)1 << log2_buckets_for(n);
   const size_t state = rows > 0 ? align_up(4 * (size_t)gsr_sort_mid_scan_state_words((long long)n * rows)) : 0;
-  return 2 * align_up(8 * (size_t)n) + align_up(4 * chunks * B) + align_up(4 * B) + align_up(4 * (B + 1)) + 1024 + 256 +
+  return 2 * align_up(8 * (size_t)n) + align_up(4 * chunks * B) + align_up(4 * B) + align_up(4 * (B + 1)) + 4096 + 256 +
          state;
 }
 
@@ -787,8 +832,8 @@ int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *ord
   ws += align_up(4 * (size_t)B);
   unsigned *bucket_base = reinterpret_cast<unsigned *>(ws);
   ws += align_up(4 * ((size_t)B + 1));
-  unsigned *map = reinterpret_cast<unsigned *>(ws);
-  ws += 1024;
+  OctaveMap *map = reinterpret_cast<OctaveMap *>(ws);
+  ws += 4096;
   if (!stats) stats = reinterpret_cast<int *>(ws);
   ws += 256;
   unsigned *scan_state = reinterpret_cast<unsigned *>(ws);
@@ -803,10 +848,10 @@ int gsr_sort_bucket_depth(int n, const float *depths, const int *radii, int *ord
                        lb, table, map, ra, scan_state, state_words);
   hipLaunchKernelGGL(scan_kernel, dim3(B / 16), dim3(256), 0, s, chunks, B, table, totals);
   hipLaunchKernelGGL(scatter_kernel, dim3(chunks), dim3(kScatterThreads), 0, s, n, depths, radii,
-                     (const unsigned *)map, lb, (const unsigned *)table, (const unsigned *)totals, pairs, order,
+                     (const OctaveMap *)map, lb, (const unsigned *)table, (const unsigned *)totals, pairs, order,
                      bucket_base, stats, ga);
   hipLaunchKernelGGL(bucket_sort_kernel, dim3(gsr_cdiv((unsigned)(B - 1), 4)), dim3(kSortThreads), 0, s,
-                     (const unsigned *)map, B, (const unsigned *)bucket_base, pairs, pairs2, order, ga);
+                     B, (const unsigned *)bucket_base, pairs, pairs2, order, ga);
   GSR_CHECK_LAUNCH("sort_bucket_depth");
   if (counts) return gsr_sort_mid_scan_inplace((long long)n * rows, cum, scan_state, s);
   return GSR_OK;
