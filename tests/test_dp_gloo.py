@@ -214,3 +214,77 @@ def test_vis_counts_merge_equals_one_process_seeing_all_views():
         total += c
     assert torch.equal(total, single)
     assert not torch.equal(sum(per_rank), single)  # the plain sum is not
+
+
+def _views_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for p in (ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cpu_standins as SI
+    import harness.pipeline as HP
+    import harness.train as HT
+    from harness.parallel import GradientExchange
+
+    HP.spherical_harmonics = SI.spherical_harmonics
+    n, K, deg_use = 257, 9, 1
+    g = torch.Generator().manual_seed(3)
+    means = torch.randn(n, 3, generator=g)
+    dc = torch.randn(n, 3, generator=g).requires_grad_(True)
+    rest = torch.randn(n, K - 1, 3, generator=g).requires_grad_(True)
+    other = torch.randn(n, 3, generator=g).requires_grad_(True)       # a parameter that is all-reduced as before
+    campos = torch.tensor([4.0 + rank, 0.5 * rank, -1.0])
+    weight = torch.randn(n, 3, generator=torch.Generator().manual_seed(10 + rank))   # this rank's colour cotangent
+    dirs = means - campos
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+
+    def loss_of(colors):
+        return (torch.clamp(colors + 0.5, min=0.0) * weight).sum() + (other * (rank + 1)).sum()
+
+    # (a) every gradient all-reduced
+    ex = GradientExchange({"features_dc": dc, "features_rest": rest, "other": other}, average=True).attach()
+    loss_of(SI.spherical_harmonics(deg_use, dirs, torch.cat((dc[:, None, :], rest), 1))).backward()
+    ex.finish()
+    dense = [t.grad.clone() for t in (dc, rest, other)]
+    ex.detach()
+    for t in (dc, rest, other):
+        t.grad = None
+    # (b) the SH gradient from the gathered colour cotangents
+    ex = GradientExchange({"features_dc": dc, "features_rest": rest, "other": other}, average=True).attach()
+    ex.sh_views_backward = HT._sh_views_backward_autograd()
+    colors = ex.deferred_sh_colors(lambda: SI.spherical_harmonics(deg_use, dirs, torch.cat((dc[:, None, :], rest), 1)),
+                                   ("features_dc", "features_rest"), (dc, rest), means, campos, 2, deg_use)
+    loss_of(colors).backward()
+    assert dc.grad is None and rest.grad is None      # nothing went through the SH backward
+    nbytes = ex.finish()
+    views = [t.grad.clone() for t in (dc, rest, other)]
+    q.put((rank, dense, views, nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sh_gradient_from_gathered_colour_cotangents_equals_the_all_reduced_one():
+    """`GradientExchange.deferred_sh_colors`: the SH parameters get no gradient from autograd; `finish()` forms
+    1/W sum_r B(dir_r) (x) v_colors_r from the all-gathered cotangents (here through the autograd stand-in of
+    gsr_sh_backward_views) -- equal to the all-reduced gradients, bands above the warm-up degree zero, identical on
+    both ranks, and the third parameter still travels by all-reduce."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_views_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        for d, v in zip(r[1], r[2]):
+            assert torch.allclose(d, v, rtol=1e-5, atol=1e-6)
+        assert not r[2][1][:, 3:, :].any()             # degree 1 in use: bands 4.. are exact zeros
+        assert r[3] == 257 * 3 * 4 + world * (3 * 257 + 3) * 4   # `other` all-reduced + the gathered message
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)                        # the same bits on both ranks
