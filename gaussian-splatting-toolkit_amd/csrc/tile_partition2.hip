@@ -10,10 +10,12 @@
 //
 //   level A, by tile ROW, fused into the emission (no intermediate depth-ordered stream):
 //     P1 rowcount   one workgroup per SLAB of 256 Gaussians in depth order: entries per tile
-//                   row -> tableC[slab][row]
-//     P2 rowscan    exclusive prefix of every row's column of that table (two small
-//                   kernels), row starts, per-row chunk starts, the total count
-//     P3 emit       the same walk again; the workgroup sorts its (Gaussian, row) items by row
+//                   row -> tableC[row][slab]
+//     P2 rowscan    one workgroup per tile row: exclusive prefix down the row's slabs + the row's
+//                   total (one launch; a two-level scan in two launches until round 3)
+//     P3 emit       every workgroup scans the row totals itself (tiles_y values) for the rows'
+//                   starts -- workgroup 0 also leaves them, the rows' chunk starts and the total
+//                   count for the kernels that follow -- then the same walk again; the workgroup sorts its (Gaussian, row) items by row
 //                   in LDS (1024 at a time) and writes each row's entries -- (tile column,
 //                   Gaussian id) -- as ONE contiguous run at row_start + prefix, threads
 //                   owning consecutive addresses.  Within a row the stream stays in depth
@@ -141,68 +143,52 @@ __global__ __launch_bounds__(kSlab) void rowcount_kernel(const Dims D, const int
     if (t1 > t0) atomicAdd(&rowcnt[ty], t1 - t0);
   }
   __syncthreads();
-  int *out = tableC + (size_t)slab * D.tiles_y;
-  for (int r = tid; r < D.tiles_y; r += kSlab) out[r] = rowcnt[r];
+  // [row][slab]: the scan below runs along a row's slabs (adjacent slabs write adjacent words)
+  for (int r = tid; r < D.tiles_y; r += kSlab) tableC[(size_t)r * D.slabs + slab] = rowcnt[r];
 }
 
-// ---- P2a: per (group of 64 slabs, block of 64 rows): exclusive prefix down the slabs -------
-// Lane l of every wave owns row r0 + l (coalesced 256-byte reads along a table row); the four
-// waves of the workgroup take a quarter of the group's slabs each.
-__global__ __launch_bounds__(256) void rowscan1_kernel(const Dims D, const int *__restrict__ tableC,
-                                                       int *__restrict__ tableA, int *__restrict__ gtot) {
-  __shared__ int part[4][64];
-  const int grp = blockIdx.x, row = blockIdx.y * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  const int w_beg = grp * kGroup + q * (kGroup / 4);
-  const int w_end = min(w_beg + kGroup / 4, D.slabs);
-  const bool live = row < D.tiles_y;
-  int sum = 0;
-  if (live)
-    for (int w = w_beg; w < w_end; ++w) sum += tableC[(size_t)w * D.tiles_y + row];
-  part[q][threadIdx.x & 63] = sum;
-  __syncthreads();
-  int run = 0;
-  for (int k = 0; k < q; ++k) run += part[k][threadIdx.x & 63];
-  if (live) {
-    for (int w = w_beg; w < w_end; ++w) {
-      const size_t at = (size_t)w * D.tiles_y + row;
-      const int v = tableC[at];
-      tableA[at] = run;
-      run += v;
-    }
-    if (q == 3) gtot[(size_t)grp * D.tiles_y + row] = run;  // run = the group's total for this row
-  }
-}
-
-// ---- P2b: one workgroup: group bases per row, row starts, chunk starts, the total ---------
-__global__ __launch_bounds__(1024) void rowscan2_kernel(const Dims D, const int capacity, int *__restrict__ gtot,
-                                                        int *__restrict__ row_start, int *__restrict__ row_chunk_start,
-                                                        int *__restrict__ count_out) {
+// ---- P2: per tile row, the exclusive prefix of its entries down the slabs + the row's total -----------
+// (round 3: one workgroup per row over the transposed table, instead of a two-level scan in two launches; the
+// scan over the rows themselves -- tiles_y values -- is redone by every workgroup of `emit` in its prologue)
+__global__ __launch_bounds__(1024) void rowscan_kernel(const Dims D, const int *__restrict__ tableC,
+                                                       int *__restrict__ tableA, int *__restrict__ rowtot) {
   __shared__ int wsum[16];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // thread r: exclusive prefix over the groups of row r (in place) and the row's total
-  int rt = 0;
-  if (tid < D.tiles_y) {
-    int *g = gtot + tid;  // [group][row]: the threads of a wave read consecutive rows
-    const size_t st = (size_t)D.tiles_y;
-    int k = 0;
-    for (; k + 8 <= D.groups; k += 8) {
-      int v[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = blockIdx.x;
+  const int *src = tableC + (size_t)row * D.slabs;
+  int *dst = tableA + (size_t)row * D.slabs;
+  int carry = 0;
+  for (int base = 0; base < D.slabs; base += 1024) {
+    const int i = base + tid;
+    const int v = i < D.slabs ? src[i] : 0;
+    int incl = v;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = g[(k + u) * st];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        g[(k + u) * st] = rt;
-        rt += v[u];
-      }
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
     }
-    for (; k < D.groups; ++k) {
-      const int v = g[k * st];
-      g[k * st] = rt;
-      rt += v;
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int before = carry, all = 0;
+    for (int k = 0; k < 16; ++k) {
+      if (k < w) before += wsum[k];
+      all += wsum[k];
     }
+    if (i < D.slabs) dst[i] = before + incl - v;
+    carry += all;
+    __syncthreads();
   }
-  // exclusive scans over the rows: entries and 4096-entry chunks (cut at the capacity)
-  auto block_excl = [&](int v, int &total) {
+  if (tid == 0) rowtot[row] = carry;
+}
+
+// Exclusive scan of f(r) over the tile rows by a workgroup of kSlab threads: out[r] (LDS or global, ny + 1 values
+// when `with_total`), returns the total.  wsum: 4 ints of LDS.
+template <class F>
+__device__ __forceinline__ int scan_rows(const int ny, F f, int *out, const bool with_total, int *wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int carry = 0;
+  for (int base = 0; base < ny; base += kSlab) {
+    const int r = base + tid;
+    const int v = r < ny ? f(r) : 0;
     int incl = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -212,34 +198,24 @@ __global__ __launch_bounds__(1024) void rowscan2_kernel(const Dims D, const int 
     __syncthreads();
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    int base = 0, all = 0;
-    for (int k = 0; k < 16; ++k) {
-      if (k < w) base += wsum[k];
-      all += wsum[k];
-    }
-    total = all;
-    return base + incl - v;
-  };
-  int total = 0;
-  const int start = block_excl(rt, total);
-  if (tid <= D.tiles_y) row_start[tid] = tid < D.tiles_y ? start : total;
-  if (tid == 0 && count_out) *count_out = total;
-  const int s_cut = start < capacity ? start : capacity;
-  const int e_cut = (start + rt) < capacity ? (start + rt) : capacity;
-  const int chunks = tid < D.tiles_y ? (e_cut - s_cut + kChunk - 1) / kChunk : 0;
-  int ctotal = 0;
-  const int cstart = block_excl(chunks, ctotal);
-  if (tid <= D.tiles_y) row_chunk_start[tid] = tid < D.tiles_y ? cstart : ctotal;
+    int before = carry;
+    for (int k = 0; k < w; ++k) before += wsum[k];
+    if (r < ny) out[r] = before + incl - v;
+    carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+  __syncthreads();
+  if (with_total && tid == 0) out[ny] = carry;
+  return carry;
 }
 
-// ---- P3: emission, row-partitioned --------------------------------------------------------
 // One workgroup per slab; its (Gaussian, row) items are taken kItems at a time (in (Gaussian,
 // row) order), sorted stably by row in LDS, and every row's entries of the batch are written as
 // one run.  The sort ranks like P7 below: every wave ranks its own contiguous quarter of the
 // batch with wave-private row counters, one prefix over (row, wave) later every item has its slot.
 __global__ __launch_bounds__(kSlab) void emit_kernel(const Dims D, const int capacity, const int *__restrict__ order,
                                                      const SplatRec *__restrict__ recs, const int *__restrict__ tableA,
-                                                     const int *__restrict__ gbase, const int *__restrict__ row_start,
+                                                     const int *__restrict__ rowtot, int *__restrict__ row_start,
+                                                     int *__restrict__ row_chunk_start, int *__restrict__ count_out,
                                                      unsigned short *__restrict__ tx_out, int *__restrict__ gid_out) {
   constexpr int kR = kItems / kSlab;     // items per thread and batch
   __shared__ SlabItems W;
@@ -261,10 +237,28 @@ __global__ __launch_bounds__(kSlab) void emit_kernel(const Dims D, const int cap
   int *gcur = bentc + ny;                // the row's global cursor
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, slab = blockIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  const int grp = slab / kGroup;
-  for (int r = tid; r < ny; r += kSlab)
-    gcur[r] = row_start[r] + gbase[(size_t)grp * ny + r] + tableA[(size_t)slab * ny + r];
+  // (this thread's row total and slab prefix are requested before the slab's two dependent gathers, order -> record,
+  //  so that the row scan below does not add a round trip of its own; grids of more than kSlab tile rows load later)
+  const bool few_rows = ny <= kSlab;
+  int my_total = 0, my_prefix = 0;
+  if (few_rows && tid < ny) my_total = rowtot[tid], my_prefix = tableA[(size_t)tid * D.slabs + slab];
   const int total = load_slab(W, wsum, slab * kSlab + tid, D.n, order, recs);
+  // where every row's segment starts: the exclusive scan of the row totals, redone by every workgroup (tiles_y
+  // values) instead of a launch of its own; workgroup 0 leaves it -- and the rows' first 4096-entry chunks, cut at the
+  // capacity, and the number of entries -- for the kernels that follow
+  const int entries = scan_rows(ny, [&](int r) { return few_rows ? my_total : rowtot[r]; }, gcur, false, wsum);
+  if (slab == 0) {
+    for (int r = tid; r < ny; r += kSlab) row_start[r] = gcur[r];
+    if (tid == 0) {
+      row_start[ny] = entries;
+      if (count_out) *count_out = entries;
+    }
+    scan_rows(ny, [&](int r) {
+      const int s0 = min(gcur[r], capacity), s1 = min(gcur[r] + rowtot[r], capacity);
+      return (s1 - s0 + kChunk - 1) / kChunk;
+    }, row_chunk_start, true, wsum);
+  }
+  for (int r = tid; r < ny; r += kSlab) gcur[r] += few_rows ? my_prefix : tableA[(size_t)r * D.slabs + slab];
   int row_bits = 1;
   while ((1 << row_bits) < ny) ++row_bits;
   const int rp = (ny + kSlab - 1) / kSlab;  // rows per thread in the row scans (contiguous)
@@ -692,7 +686,7 @@ inline Layout make_layout(const Dims &D, int capacity) {
   };
   L.tableC = take(4 * (size_t)D.slabs * D.tiles_y);
   L.tableA = take(4 * (size_t)D.slabs * D.tiles_y);
-  L.gtot = take(4 * (size_t)D.tiles_y * D.groups);
+  L.gtot = take(4 * (size_t)D.tiles_y * (D.groups > 1 ? D.groups : 1));  // (the row totals: tiles_y ints)
   L.row_start = take(4 * (size_t)(D.tiles_y + 1));
   L.row_chunk_start = take(4 * (size_t)(D.tiles_y + 1));
   L.tx = take(2 * (size_t)capacity + 8);  // P4 reads whole groups of four
@@ -752,12 +746,9 @@ int gsr_tile_partition2(int n, int capacity, const int *order, const void *recs,
   unsigned *tile_cnt = reinterpret_cast<unsigned *>(ws + L.tile_cnt);
   const SplatRec *R = static_cast<const SplatRec *>(recs);
   hipLaunchKernelGGL(rowcount_kernel, dim3(D.slabs), dim3(kSlab), 4 * (size_t)tiles_y, s, D, order, R, tableC);
-  hipLaunchKernelGGL(rowscan1_kernel, dim3(D.groups, gsr_cdiv(tiles_y, 64)), dim3(256), 0, s, D, (const int *)tableC,
-                     tableA, gtot);
-  hipLaunchKernelGGL(rowscan2_kernel, dim3(1), dim3(1024), 0, s, D, capacity, gtot, row_start, row_chunk_start,
-                     count_out);
+  hipLaunchKernelGGL(rowscan_kernel, dim3(tiles_y), dim3(1024), 0, s, D, (const int *)tableC, tableA, gtot);
   hipLaunchKernelGGL(emit_kernel, dim3(D.slabs), dim3(kSlab), 28 * (size_t)tiles_y, s, D, capacity, order, R,
-                     (const int *)tableA, (const int *)gtot, (const int *)row_start, txs, gids);
+                     (const int *)tableA, (const int *)gtot, row_start, row_chunk_start, count_out, txs, gids);
   hipLaunchKernelGGL(colhist_kernel, dim3(L.chunk_slots), dim3(256), 0, s, D, capacity, (const int *)row_start,
                      (const int *)row_chunk_start, (const unsigned short *)txs, tableB);
   if (tiles_x <= 256) {
