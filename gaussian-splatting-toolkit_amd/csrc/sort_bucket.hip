@@ -2,7 +2,8 @@
 //
 // sort_mid.hip orders the N ~ 1e6 Gaussians with four 8-bit LSD passes: 12 launches that move every
 // (key, index) pair through HBM four times and spend most of their 100 us on launch/latency chains.
-// Depths of one view are not arbitrary 31-bit numbers, so four launches do:
+// Depths of one view are not arbitrary 31-bit numbers, so four launches do (a fifth scans the tile counts when the
+// caller wants them: they are gathered wherever an index is written into the order):
 //   hist      every workgroup first derives the SAME monotone bucket map from the same 4096 sampled keys: the
 //             sample's population per float octave (exponent) decides how many of the B buckets the octave gets,
 //             spread linearly over its mantissas (over the part of them the sample's smallest / largest key bound,
