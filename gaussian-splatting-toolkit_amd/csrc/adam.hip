@@ -62,15 +62,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, const Hyper
     for (int u = 0; u < 4; ++u) {
       const long long i = blk * kVecPerBlock + u * 256 + threadIdx.x;
       if (i < n4) {
-        float4 p = P[i], m = M[i], v = V[i];
-        const float4 g = G[i];
+        float4 p = gsr_load_stream(P + i), m = gsr_load_stream(M + i), v = gsr_load_stream(V + i);
+        const float4 g = gsr_load_stream(G + i);
         adam_one(p.x, g.x, m.x, v.x, h, step_size);
         adam_one(p.y, g.y, m.y, v.y, h, step_size);
         adam_one(p.z, g.z, m.z, v.z, h, step_size);
         adam_one(p.w, g.w, m.w, v.w, h, step_size);
-        P[i] = p;
-        M[i] = m;
-        V[i] = v;
+        gsr_store_stream(P + i, p);
+        gsr_store_stream(M + i, m);
+        gsr_store_stream(V + i, v);
       }
     }
     // the < 4 trailing elements: first workgroup of the tensor

@@ -48,6 +48,20 @@ static inline unsigned gsr_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b
 int gsr_zero_async(void *ptr, size_t bytes, hipStream_t s);
 
 // ---- device helpers --------------------------------------------------------
+// Streams that are touched once per step (SH coefficient rows, their gradients, the optimizer's state): non-temporal
+// accesses (`global_load ... nt`) -- measured, 1 M Gaussians: sh16_fwd 57.8 -> 40.5 us for the same 216 MB.
+typedef float gsr_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gsr_load_stream(const float4 *p) {
+  const gsr_v4f v = __builtin_nontemporal_load(reinterpret_cast<const gsr_v4f *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gsr_store_stream(float4 *p, const float4 v) {
+  const gsr_v4f t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<gsr_v4f *>(p));
+}
+__device__ __forceinline__ float gsr_load_stream(const float *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void gsr_store_stream(float *p, const float v) { __builtin_nontemporal_store(v, p); }
+
 #define GSR_WAVE 64
 
 // thresholds of the compositing rule (forward.cu:360-366, backward.cu:232-233)

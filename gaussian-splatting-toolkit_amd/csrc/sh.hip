@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * WAVES) void sh16_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     const unsigned j = i * 64 + lane;
-    q[i] = j < navail ? src[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    q[i] = j < navail ? gsr_load_stream(src + j) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * WAVES) void sh16_bwd_kernel(
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     const unsigned j = i * 64 + lane;
-    if (j < navail) dst[j] = lds[w][(j / 12) * kShRow + j % 12];
+    if (j < navail) gsr_store_stream(dst + j, lds[w][(j / 12) * kShRow + j % 12]);
   }
 }
 
@@ -272,7 +272,7 @@ __device__ __forceinline__ void split_rows_to_lds(const float *__restrict__ src,
     for (int i = 0; i < (16 * R + 63) / 64; ++i) {
       const unsigned j = i * 64 + lane;
       if (j < 16u * R) {
-        const float4 q = s4[j];
+        const float4 q = gsr_load_stream(s4 + j);
         const float v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -302,7 +302,7 @@ __device__ __forceinline__ void split_rows_from_lds(float *__restrict__ dst, con
           const unsigned e = 4 * j + c;
           v[c] = lds[(e / R) * STRIDE + e % R];
         }
-        d4[j] = make_float4(v[0], v[1], v[2], v[3]);
+        gsr_store_stream(d4 + j, make_float4(v[0], v[1], v[2], v[3]));
       }
     }
   } else {
