@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 
   if (scales) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) cov3d[6 * i + k] = o_cov[k];
+    for (int k = 0; k < 6; ++k) gsr_store_stream(cov3d + 6 * i + k, o_cov[k]);  // (read again by the backward only)
   }
   xys[2 * i] = o_x;
   xys[2 * i + 1] = o_y;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
   conics[3 * i] = o_k0;
   conics[3 * i + 1] = o_k1;
   conics[3 * i + 2] = o_k2;
-  compensation[i] = o_comp;
+  gsr_store_stream(compensation + i, o_comp);
   num_tiles_hit[i] = o_tiles;
 }
 
@@ -301,14 +301,14 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
   }
 
 #pragma unroll
-  for (int k = 0; k < 3; ++k) v_cov2d[3 * i + k] = g2[k];
+  for (int k = 0; k < 3; ++k) gsr_store_stream(v_cov2d + 3 * i + k, g2[k]);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) v_cov3d[6 * i + k] = g3[k];
+  for (int k = 0; k < 6; ++k) gsr_store_stream(v_cov3d + 6 * i + k, g3[k]);  // (scratch of the chain: nobody reads it)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) v_mean3d[3 * i + k] = gm[k];
+  for (int k = 0; k < 3; ++k) gsr_store_stream(v_mean3d + 3 * i + k, gm[k]);
   if (scales) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v_scale[3 * i + k] = gs[k];
+    for (int k = 0; k < 3; ++k) v_scale[3 * i + k] = gs[k];  // (read next by the activation backward)
 #pragma unroll
     for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = gq[k];
   }
