@@ -283,32 +283,50 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
 
   float T[4], K[4], vr[4], vg[4], vb[4], ve[4];
   int binf[4];
+  // The per-pixel inputs of all four pixels are requested together, from a clamped address and selected afterwards
+  // (a load under `inside` / `drawn` is a branch with its own wait: eight dependent round trips per wave before the
+  // first splat).  What is selected away is never used: see `drawn` below.
+  float in_T[4], in_r[4], in_g[4], in_b[4], in_a[4], in_e[4];
+  int in_idx[4];
+  bool in_img[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
-    const bool inside = col < img_w && row < img_h && ((allowed >> p) & 1);
+    in_img[p] = col < img_w && row < img_h && ((allowed >> p) & 1);
+    const size_t pid = in_img[p] ? (size_t)row * img_w + col : 0;
+    in_T[p] = final_Ts[pid];
+    in_r[p] = v_output[3 * pid];
+    in_g[p] = v_output[3 * pid + 1];
+    in_b[p] = v_output[3 * pid + 2];
+    in_a[p] = v_output_alpha ? v_output_alpha[pid] : 0.f;
+    in_e[p] = 0.f;
+    if constexpr (RGBD) in_e[p] = v_out_extra[pid];
+    in_idx[p] = final_idx[pid];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const bool inside = in_img[p];
     T[p] = 1.f;
     K[p] = vr[p] = vg[p] = vb[p] = ve[p] = 0.f;
     binf[p] = -1;  // `inside && idx <= bin_final` folds into one compare
-    if (inside) {
-      const size_t pid = (size_t)row * img_w + col;
-      const float Tf = final_Ts[pid];
+    {
+      const float Tf = inside ? in_T[p] : 1.f;
       T[p] = Tf;
       // T_final == 1 exactly <=> nothing was composited at this pixel (a drawn splat has alpha >= 1/255):
-      // no splat is `valid` there, and its cotangent must not be READ either -- the models' depth image is
+      // no splat is `valid` there, and its cotangent must not be USED either -- the models' depth image is
       // `where(alpha > 0, depth / alpha, max)` (vanilla_gs.py:855, depth_gs.py:356), whose backward hands
       // 0/0 = NaN to exactly these pixels.  The reference's kernel branches on `valid` and never touches
       // them (backward.cu:133-303); the flat selects below would turn 0 * NaN into NaN sums.
-      const bool drawn = Tf < 1.f;
-      vr[p] = drawn ? v_output[3 * pid] : 0.f;
-      vg[p] = drawn ? v_output[3 * pid + 1] : 0.f;
-      vb[p] = drawn ? v_output[3 * pid + 2] : 0.f;
+      const bool drawn = Tf < 1.f;  // (false outside the image)
+      vr[p] = drawn ? in_r[p] : 0.f;
+      vg[p] = drawn ? in_g[p] : 0.f;
+      vb[p] = drawn ? in_b[p] : 0.f;
       // T_final*ra*v_out_alpha - T_final*ra*(bg . v_out) = ra * K
-      if constexpr (RGBD) ve[p] = drawn ? v_out_extra[pid] : 0.f;
+      if constexpr (RGBD) ve[p] = drawn ? in_e[p] : 0.f;
       K[p] = !drawn ? 0.f
-                    : Tf * ((v_output_alpha ? v_output_alpha[pid] : 0.f) -
+                    : Tf * ((v_output_alpha ? in_a[p] : 0.f) -
                             (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p] + (RGBD ? bg_extra * ve[p] : 0.f)));
-      binf[p] = drawn ? final_idx[pid] : -1;
+      binf[p] = drawn ? in_idx[p] : -1;
     }
   }
   // last sorted index any pixel of sub-tile p still needs (wave-uniform)
