@@ -91,7 +91,11 @@ inline bool use_bucket_sort(int n, hipStream_t s, int **stats) {
   BucketHint &h = g_bucket_hint[dev];
   if (!h.pinned) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return true;  // (no allocation inside a capture)
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+      (void)hipGetLastError();  // (e.g. the legacy stream while another one captures: not this call's error)
+      return true;
+    }
+    if (cap != hipStreamCaptureStatusNone) return true;  // (no allocation inside a capture)
     if (hipHostMalloc(reinterpret_cast<void **>(&h.pinned), 64, hipHostMallocDefault) != hipSuccess) {
       h.pinned = nullptr;
       (void)hipGetLastError();
