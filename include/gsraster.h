@@ -184,7 +184,7 @@ int gsr_tile_bin_edges(int num_intersects, const int64_t *isect_ids_sorted,
  * order; where the depth order is built by the bucket sort (csrc/sort_bucket.hip: 64 k < num_points <= 4 M) the
  * records are written by its first launch.  workspace: gsr_depth_order_workspace_bytes(num_points, 1).
  *
- * How the order-only depth sort is built (64 k < num_points <= 4 M) may depend on earlier calls on the same
+ * How the depth sort is built (64 k < num_points <= 4 M, with or without counts) may depend on earlier calls on the same
  * device -- a hint in pinned memory sends calls to the radix passes after a view whose depths overflowed the
  * bucket sort's buckets -- the RESULT never does: both are the stable sort by (depth bits, index).
  * GSR_DEPTH_SORT=radix | bucket in the environment pins the choice. */
