@@ -13,6 +13,10 @@
 // 4 passes x 3 launches for 31-bit keys.  The first pass reads the index as the
 // lane's position (no iota buffer).
 //
+// Round 3: the depth ordering itself is built by sort_bucket.hip (one bucket pass + one in-LDS pass); what follows
+// serves it as the fallback its hint selects after a view whose buckets overflowed (binning_fast.hip:
+// use_bucket_sort), as the look-back scan of the gathered counts (gsr_sort_mid_scan_inplace), and the other
+// mid-size sorts of the library (GSR_TILE_SORT=m).
 // gsr_sort_mid_depth is the depth ordering's own entry: the first pass makes its keys
 // from (depth, radius) on the fly (no key-building launch), the last pass also moves the
 // per-Gaussian tile counts into depth order (the gather rides along with the scatter's own
