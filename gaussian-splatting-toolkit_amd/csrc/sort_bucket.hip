@@ -258,6 +258,26 @@ __global__ __launch_bounds__(256) void scan_kernel(const int chunks, const int B
   const int b = blockIdx.x * 16 + bl;
   const int per = (chunks + 15) / 16;
   const int c0 = g * per, c1 = min(chunks, c0 + per);
+  if (per <= 16) {  // (up to 1 M items: the group's counts stay in registers between the two passes)
+    unsigned t[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const unsigned v = table[(size_t)min(c0 + k, chunks - 1) * B + b];  // (clamped: all sixteen loads go out together)
+      t[k] = c0 + k < c1 ? v : 0u;
+      sum += t[k];
+    }
+    part[g][bl] = sum;
+    __syncthreads();
+    unsigned run = 0;
+    for (int k = 0; k < g; ++k) run += part[k][bl];
+    if (g == 15) totals[b] = run + sum;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (c0 + k < c1) table[(size_t)(c0 + k) * B + b] = run;
+      run += t[k];
+    }
+    return;
+  }
   unsigned sum = 0;
 #pragma unroll 8
   for (int c = c0; c < c1; ++c) sum += table[(size_t)c * B + b];
