@@ -354,7 +354,7 @@ __device__ __forceinline__ unsigned rank_round(const unsigned (&v)[kI], unsigned
   return tot;
 }
 
-// Stable sort of the m (<= 4096) words in v[] by bits [lo, lo + nbits), in rounds of <= 8 bits; buf: 4096
+// Stable sort of the m (<= 256 kI) words in v[] by bits [lo, lo + nbits), in rounds of <= 8 bits; buf: that many
 // words of LDS, left holding the sorted sequence; v[] holds it too, in the same arrangement.
 template <int kW, int kI>
 __device__ __forceinline__ void block_sort(unsigned (&v)[kI], const int R, const int seg, const int m, const int lo,
