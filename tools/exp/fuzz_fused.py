@@ -12,8 +12,8 @@ from gs_fused import FusedAdam, L1SSIMLoss
 from oracle import oracle as O
 
 
-def close(a, b, rel=4e-6):
-    return float((a - b).abs().max()) <= rel * max(1e-30, float(b.abs().max()))
+def close(a, b, rel=4e-6, floor=1e-30):
+    return float((a - b).abs().max()) <= rel * max(floor, float(b.abs().max()))
 
 
 def adam_case(rng):
@@ -44,8 +44,10 @@ def adam_case(rng):
             p.grad, q.grad = gr, gr.clone()
         opt.step()
         topt.step()
-    for p, q in zip(mine, ref):
-        assert close(p.detach(), q.detach()), "parameter"
+    for p, q, lr in zip(mine, ref, lrs):
+        # (an Adam step moves a parameter by ~lr: a 1-ulp difference in the step is 1e-7 lr, which a parameter that
+        #  the step happens to bring near zero would otherwise be held against -- seed 3003, case 60)
+        assert close(p.detach(), q.detach(), floor=lr), "parameter"
         a, b = opt.state.get(p, {}), topt.state.get(q, {})
         assert ("exp_avg" in a) == ("exp_avg" in b)
         if "exp_avg" in a:
