@@ -65,15 +65,38 @@ def optimizer_state_dicts(model, optims: Dict[str, torch.optim.Optimizer]) -> Di
     return out
 
 
+def sharded_state_dicts(sharded) -> Dict[str, dict]:
+    """The same per-group dicts from a `parallel.ShardedAdam`, whose moments live in row shards across the ranks:
+    gathered to full size first (COLLECTIVE: every rank must call this; all of them return the full state)."""
+    moments = sharded.full_moments()
+    groups = {g["name"]: g for g in sharded.inner.param_groups}
+    out = {}
+    for name in sharded.named:
+        g = groups[name]
+        group = {k: v for k, v in g.items() if k not in ("params", "name")}
+        group["params"] = [0]
+        state = {}
+        if name in moments:
+            state[0] = {"step": torch.tensor(float(sharded.step_count)), "exp_avg": moments[name][0],
+                        "exp_avg_sq": moments[name][1]}
+        out[name] = {"state": state, "param_groups": [group]}
+    return out
+
+
 def save_checkpoint(directory: str, step: int, model, optims: Dict[str, torch.optim.Optimizer],
-                    save_only_latest: bool = True) -> str:
-    """trainer.py:444-476."""
+                    save_only_latest: bool = True, sharded=None, write: bool = True) -> Optional[str]:
+    """trainer.py:444-476.  With `sharded` (a `parallel.ShardedAdam`) EVERY rank calls this -- the moments are
+    gathered by a collective -- and only the rank with `write=True` touches the disk (the reference: rank 0,
+    trainer.py:446 `@check_main_thread`)."""
+    opt_state = sharded_state_dicts(sharded) if sharded is not None else optimizer_state_dicts(model, optims)
+    if not write:
+        return None
     os.makedirs(directory, exist_ok=True)
     path = checkpoint_path(directory, step)
     torch.save({
         "step": step,
         "pipeline": {_PREFIX + k: model.gauss[k].detach() for k in PARAM_NAMES},
-        "optimizers": optimizer_state_dicts(model, optims),
+        "optimizers": opt_state,
         "schedulers": {},
         # exactly what the reference writes for this method: mixed_precision=False -> a DISABLED
         # GradScaler, whose state_dict() is {} and whose load_state_dict is a no-op (trainer.py:126,425,467)
@@ -109,11 +132,13 @@ def load_model_state(model, state: Dict[str, torch.Tensor]) -> int:
     return newp
 
 
-def load_checkpoint(path: str, model, optims: Dict[str, torch.optim.Optimizer], trust_pickle: bool = False) -> int:
+def load_checkpoint(path: str, model, optims: Dict[str, torch.optim.Optimizer], trust_pickle: bool = False,
+                    sharded=None) -> int:
     """trainer.py:404-443 for one file or a directory (latest step).  The model is resized,
     every optimizer is pointed at the new parameter objects and gets the saved Adam state
     (``step``, ``exp_avg``, ``exp_avg_sq``) and learning rate.  Returns the step to resume
-    at (``loaded step + 1``)."""
+    at (``loaded step + 1``).  With `sharded` (a `parallel.ShardedAdam`; every rank reads the same file) the
+    full-size moments are cut into this rank's rows instead."""
     if os.path.isdir(path):
         path = latest_checkpoint(path)
     # the payload is tensors, dicts, numbers and strings: the safe loader reads it.  A third-party
@@ -121,6 +146,26 @@ def load_checkpoint(path: str, model, optims: Dict[str, torch.optim.Optimizer], 
     loaded = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
     old = {k: model.gauss[k] for k in PARAM_NAMES}
     load_model_state(model, loaded["pipeline"])
+    if sharded is not None:
+        moments, steps = {}, []
+        for name in PARAM_NAMES:
+            sd = loaded.get("optimizers", {}).get(name)
+            if not sd:
+                continue
+            if "lr" in sd["param_groups"][0]:
+                sharded.lrs[name] = sd["param_groups"][0]["lr"]
+            st = sd["state"].get(0)
+            if st:
+                dev = model.gauss[name].device
+                if st["exp_avg"].shape != model.gauss[name].shape:
+                    raise ValueError(f"optimizer state of {name} has {st['exp_avg'].shape[0]} rows, the model "
+                                     f"{model.gauss[name].shape[0]}")
+                moments[name] = (st["exp_avg"].to(device=dev, dtype=torch.float32).contiguous(),
+                                 st["exp_avg_sq"].to(device=dev, dtype=torch.float32).contiguous())
+                steps.append(int(float(st["step"])))
+        sharded.step_count = max(steps) if steps else 0
+        sharded.bind({k: model.gauss[k] for k in PARAM_NAMES}, moments)
+        return int(loaded["step"]) + 1
     for name in PARAM_NAMES:
         found = _group_of(optims, old[name])
         if found is None:

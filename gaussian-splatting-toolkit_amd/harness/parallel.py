@@ -77,19 +77,59 @@ def allreduce_gradients(params: Sequence[torch.Tensor], average: bool = True, gr
     return buf
 
 
-_avg_supported = {"ok": True}
+_capabilities = {}
+
+
+def collective_capabilities(group=None, device=None) -> dict:
+    """What the process group's backend can do, found out ONCE, synchronously, on a 4-element message, before any
+    gradient is on the wire -- never by catching an exception around a real (asynchronous) collective: an RCCL
+    error on an async collective surfaces at `wait()`, after the communicator is already unusable.
+
+    COLLECTIVE: every rank of `group` must call this at the same point (GradientExchange / ShardedAdam do, in
+    their constructors).  -> {"avg": ReduceOp.AVG works for all_reduce and reduce_scatter_tensor,
+    "gather_into_tensor": all_gather_into_tensor exists, "reduce_scatter_tensor": ...}.  Every rank runs the same
+    library and probes the same calls, so every rank gets the same answers."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"avg": False, "gather_into_tensor": False, "reduce_scatter_tensor": False}
+    backend = dist.get_backend(group)
+    key = (backend, id(group))
+    caps = _capabilities.get(key)
+    if caps is not None:
+        return caps
+    ws = dist.get_world_size(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+    def works(fn):
+        try:
+            fn()
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            return True
+        except (RuntimeError, ValueError, AttributeError, NotImplementedError):
+            return False
+
+    one = torch.ones(4 * ws, dtype=torch.float32, device=device)
+    shard = torch.empty(4, dtype=torch.float32, device=device)
+    caps = {
+        # gloo has no AVG: it raises at issue, on every rank alike (nothing was enqueued)
+        "avg": backend == "nccl" and works(lambda: dist.all_reduce(one.clone(), op=dist.ReduceOp.AVG, group=group)),
+        "gather_into_tensor": works(lambda: dist.all_gather_into_tensor(one.clone(), shard.zero_(), group=group)),
+        "reduce_scatter_tensor": works(lambda: dist.reduce_scatter_tensor(shard, one.clone(), op=dist.ReduceOp.SUM,
+                                                                          group=group)),
+    }
+    if caps["avg"] and caps["reduce_scatter_tensor"]:
+        caps["avg"] = works(lambda: dist.reduce_scatter_tensor(shard, one.clone(), op=dist.ReduceOp.AVG, group=group))
+    _capabilities[key] = caps
+    return caps
 
 
 def _allreduce_inplace(t: torch.Tensor, average: bool, ws: int, group) -> None:
     """RCCL averages inside the collective (ReduceOp.AVG): no extra pass over the
-    192-MB SH gradient to divide it.  Falls back to SUM + div_ once if the backend
-    refuses AVG (every rank runs the same library, so every rank falls back)."""
-    if average and _avg_supported["ok"]:
-        try:
-            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
-            return
-        except (RuntimeError, ValueError):
-            _avg_supported["ok"] = False
+    192-MB SH gradient to divide it; SUM + div_ where `collective_capabilities` found no AVG."""
+    if average and collective_capabilities(group, t.device)["avg"]:
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        return
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     if average:
         t.div_(ws)
@@ -148,7 +188,10 @@ class GradientExchange:
     ``bytes_last`` holds the bytes exchanged by the last ``finish()``.
     """
 
-    def __init__(self, named_params, average: bool = True, group=None, flat_small: bool = True):
+    def __init__(self, named_params, average: bool = True, group=None, flat_small: bool = True,
+                 force: bool = False):
+        """`force`: run the exchange on a process group of ONE rank too (every collective is then an identity that
+        still goes through the backend: how the RCCL code path is exercised on a single-GPU box)."""
         self.named = dict(named_params)
         self.average, self.group = average, group
         # the small tensors (rows of <= 4 floats: means, scales, quats, opacities, features_dc = 56 of
@@ -167,9 +210,11 @@ class GradientExchange:
         self._sh = None           # this step's deferred SH gradient (deferred_sh_colors), or None
         self._sh_work = None
         self.sh_views_backward = None  # (degree, deg_use, means, campos [W,3], v_colors [W,N,3], scale) -> grads; default: native
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self._ws = dist.get_world_size(group) if self.enabled else 1
-        self._avg_in_collective = self.enabled and dist.get_backend(group) == "nccl" and average
+        dev = next(iter(self.named.values())).device if self.named else None
+        self._caps = collective_capabilities(group, dev) if self.enabled else {}
+        self._avg_in_collective = self.enabled and average and self._caps.get("avg", False)
 
     def attach(self) -> "GradientExchange":
         """(Re-)register the hooks, e.g. after refinement replaced the parameter objects.
@@ -234,9 +279,9 @@ class GradientExchange:
         sh = self._sh
         msg = torch.cat((v_colors.reshape(-1), sh["campos"].to(v_colors.device)))
         out = torch.empty((self._ws, msg.numel()), dtype=msg.dtype, device=msg.device)
-        try:
+        if self._caps.get("gather_into_tensor", False):
             work = dist.all_gather_into_tensor(out.view(-1), msg, group=self.group, async_op=True)
-        except (RuntimeError, ValueError, AttributeError):
+        else:
             work = dist.all_gather(list(out.unbind(0)), msg, group=self.group, async_op=True)
         sh["out"] = out
         self._sh_work = work
@@ -247,8 +292,14 @@ class GradientExchange:
         self._sh = None
         if sh is None:
             return
-        if self._sh_work is None:  # the colours never received a cotangent on this rank: not a data-parallel step
-            raise RuntimeError("deferred_sh_colors: backward did not reach the colours")
+        if self._sh_work is None:
+            # the colours never received a cotangent on this rank (their output was unused in its loss): the other
+            # ranks are already inside the all-gather -- join it with zeros, so that the collectives stay matched
+            # (raising here would leave them hanging), and contribute no gradient
+            n = sh["means"].shape[0]
+            self._sh = sh
+            self.offer(torch.zeros((n, 3), dtype=sh["means"].dtype, device=sh["means"].device))
+            self._sh = None
         self._sh_work.wait()
         self._sh_work = None
         out, n = sh["out"], sh["means"].shape[0]
@@ -273,14 +324,7 @@ class GradientExchange:
             parts.append(p.grad.reshape(-1))
         flat = torch.cat(parts)
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
-        try:
-            work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
-        except (RuntimeError, ValueError):
-            if op != dist.ReduceOp.AVG:
-                raise
-            self._avg_in_collective = False
-            op = dist.ReduceOp.SUM
-            work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+        work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
         self._bytes += flat.numel() * flat.element_size()
         self.pending.append((work, flat, names, "flat", op))
         self._flat_started = True
@@ -307,13 +351,7 @@ class GradientExchange:
         else:
             buf = g
         op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
-        try:
-            work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
-        except (RuntimeError, ValueError):
-            if op != dist.ReduceOp.AVG:
-                raise
-            self._avg_in_collective = False  # every rank runs the same library: all fall back together
-            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        work = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
         self._bytes += buf.numel() * buf.element_size()
         self.pending.append((work, buf, g, rows if stage is not None else None, op))
 
@@ -353,9 +391,16 @@ class GradientExchange:
                 buf.div_(self._ws)
             if rows == "flat":
                 off = 0
-                for k in g:  # the reduced gradients are views of the flat buffer: no unpacking copy
+                for k in g:
                     q = self.named[k]
-                    q.grad = buf[off:off + q.numel()].view_as(q)
+                    piece = buf[off:off + q.numel()].view_as(q)
+                    if self.use_hooks:
+                        q.grad = piece  # a view of the flat buffer: no unpacking copy
+                    else:
+                        # gradients written by a replayed HIP graph live in STATIC tensors the graph keeps writing to:
+                        # re-pointing `.grad` would leave the next replay's gradients where nobody reads them (and
+                        # `start_all` would re-reduce this step's values) -- copy the reduced values back
+                        q.grad.copy_(piece)
                     off += q.numel()
             elif rows is not None:
                 g[:, :rows].copy_(buf)
@@ -417,14 +462,16 @@ class ShardedAdam:
     `make_optimizer(param_groups)` builds the inner optimizer (gs_fused.FusedAdam on the GPU,
     torch.optim.Adam elsewhere); its parameters are VIEWS of the model's rows."""
 
-    def __init__(self, named_params, lrs, make_optimizer, group=None, average: bool = True):
+    def __init__(self, named_params, lrs, make_optimizer, group=None, average: bool = True, force: bool = False):
+        """`force`: go through the collectives on a process group of one rank too (see GradientExchange)."""
         self.group, self.average = group, average
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.lrs = dict(lrs)
         self.make_optimizer = make_optimizer
-        self._avg = self.enabled and dist.get_backend(group) == "nccl" and average
+        dev = next(iter(dict(named_params).values())).device
+        self._avg = self.enabled and average and collective_capabilities(group, dev)["avg"]
         self.bytes_last = 0
         self.step_count = 0
         self.bind(named_params, None)

@@ -389,8 +389,6 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     if cfg.sharded_adam and world > 1:
         from .parallel import ShardedAdam
 
-        if cfg.save_every or cfg.resume_from:
-            raise NotImplementedError("checkpoints with sharded_adam: gather ShardedAdam.full_moments() first")
         if cfg.fused_adam and device.type == "cuda":
             from gs_fused import FusedAdam
 
@@ -436,7 +434,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     if cfg.resume_from:
         from .checkpoint import load_checkpoint
 
-        start_step = load_checkpoint(cfg.resume_from, model, optims)  # resizes the model to the saved N
+        start_step = load_checkpoint(cfg.resume_from, model, optims, sharded=sharded)  # resizes the model to the saved N
         n = model.num_points
         xys_grad_norm = torch.zeros(n, device=device)
         vis_counts = torch.zeros(n, device=device, dtype=torch.int32)
@@ -635,10 +633,12 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             first_pending, first_vis = True, None
             if use_fused:
                 fstats.restart()
-        if cfg.save_every and cfg.checkpoint_dir and step > 0 and step % cfg.save_every == 0 and rank == 0:
+        if cfg.save_every and cfg.checkpoint_dir and step > 0 and step % cfg.save_every == 0 and \
+                (rank == 0 or sharded is not None):
             from .checkpoint import save_checkpoint
 
-            save_checkpoint(cfg.checkpoint_dir, step, model, optims)
+            # (sharded moments are gathered by a collective: every rank calls, rank 0 writes)
+            save_checkpoint(cfg.checkpoint_dir, step, model, optims, sharded=sharded, write=rank == 0)
         if cfg.log_every and step % cfg.log_every == 0:
             losses.append(float(loss.detach()))
     if world > 1:

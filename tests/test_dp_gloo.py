@@ -288,3 +288,97 @@ def test_sh_gradient_from_gathered_colour_cotangents_equals_the_all_reduced_one(
         assert r[3] == 257 * 3 * 4 + world * (3 * 257 + 3) * 4   # `other` all-reduced + the gathered message
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)                        # the same bits on both ranks
+
+
+def _static_grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness.parallel import GradientExchange
+
+    n = 16
+    named = {"means": torch.zeros(n, 3, requires_grad=True), "opacities": torch.zeros(n, 1, requires_grad=True),
+             "features_rest": torch.zeros(n, 15, 3, requires_grad=True)}
+    # what a captured HIP graph leaves behind: STATIC .grad tensors it writes into on every replay
+    static = {k: torch.zeros_like(p) for k, p in named.items()}
+    for k, p in named.items():
+        p.grad = static[k]
+    ex = GradientExchange(named, average=True)
+    ex.use_hooks = False
+    ex.attach()
+    seen = []
+    for step in range(1, 4):
+        for k in named:  # "replay": this rank's gradient of this step, written in place
+            static[k].fill_(float(step * (rank + 1)))
+        ex.start_all()
+        ex.finish()
+        seen.append({k: (float(named[k].grad.mean()), named[k].grad.data_ptr() == static[k].data_ptr())
+                     for k in named})
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_exchange_without_hooks_keeps_the_static_gradients_of_a_replayed_graph():
+    """Round-3 advice (high): under HIP-graph replay the exchange is started by `start_all()`; the gradients live
+    in static tensors the graph writes into.  The flat small-tensor message must hand its result back INTO those
+    tensors: re-pointing `.grad` at the flat buffer left the next replay's gradients unread (steps 2 and 3 then
+    re-reduced step 1's values: 1.5, 1.5, 1.5 instead of 1.5, 3.0, 4.5)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_static_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen in results:
+        for step, rec in enumerate(seen, start=1):
+            for name, (mean, same_storage) in rec.items():
+                assert mean == 1.5 * step, (rank, step, name, mean)   # mean of step and 2 step
+                assert same_storage, (rank, step, name)
+
+
+def _unoffered_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness.parallel import GradientExchange
+
+    n = 12
+    named = {"means": torch.randn(n, 3).requires_grad_(True), "sh_coeffs": torch.zeros(n, 4, 3, requires_grad=True)}
+    ex = GradientExchange(named, average=False).attach()
+    got = {}
+    ex.sh_views_backward = lambda degree, deg_use, means, campos_all, v_all, scale, split: (
+        got.setdefault("v", v_all.clone()), torch.zeros(n, 4, 3))[1]
+    colors = ex.deferred_sh_colors(lambda: torch.ones(n, 3), ("sh_coeffs",), (named["sh_coeffs"],), named["means"],
+                                   torch.zeros(3), 1, 1)
+    # rank 1's loss does not use the colours at all: no cotangent reaches them there
+    loss = named["means"].sum() + (colors.sum() * (rank + 2) if rank == 0 else 0.0)
+    loss.backward()
+    ex.finish()
+    q.put((rank, got["v"].reshape(world, n, 3)[:, 0, 0].tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_rank_without_colour_cotangent_joins_the_gather_with_zeros():
+    """Round-3 advice: `_finish_sh` used to raise on the rank whose backward never reached the colours while the
+    others were already inside the all-gather (a hang, not an error).  It now contributes zeros."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unoffered_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0][1] == results[1][1] == [2.0, 0.0]
