@@ -104,7 +104,39 @@ class KernelTimers:
                 for k, v in self.pairs.items()}
 
 
-def cpu_baseline(sc, cam, bg, v_img, v_alpha, deg):
+def _rnd(v, k):
+    return None if v is None else round(v, k)
+
+
+def parity_vs_oracle(gpu, ref):
+    """The timed workload's own results against the CPU oracle's (which `cpu_baseline` has just computed on the same
+    scene, camera and cotangents): north_star's bars are 1e-4 abs on the image (pixels whose discrete decisions --
+    skip / clamp / termination -- are not within 1e-5 of flipping, `ambig`) and 1e-3 relative on the gradients."""
+    ok = ~ref["ambig"]
+    img_err = np.abs(gpu["rgb"] - ref["out_img"])
+    a_err = np.abs((1.0 - gpu["alpha"]) - ref["final_Ts"])
+    visible = ref["radii"] > 0
+    rec = {"img_max_abs_stable": float(img_err[ok].max()), "alpha_max_abs_stable": float(a_err[ok].max()),
+           "img_max_abs_all_pixels": float(img_err.max()), "ambiguous_px_frac": round(float(ref["ambig"].mean()), 6),
+           "projection_bit_identical": bool(np.array_equal(gpu["xys"], ref["xys"]) and np.array_equal(gpu["radii"], ref["radii"])),
+           "grad_l2_rel": {}, "grad_max_abs_over_max_ref": {}, "within_1e-3_frac": {}}
+    for k, g_ref in ref["grads"].items():
+        g = gpu["grads"][k]
+        err = np.abs(g - g_ref)
+        rec["grad_l2_rel"][k] = float(np.linalg.norm((g - g_ref).ravel()) / max(np.linalg.norm(g_ref.ravel()), 1e-30))
+        rec["grad_max_abs_over_max_ref"][k] = float(err.max() / max(np.abs(g_ref).max(), 1e-30))
+        rel = err / np.maximum(np.abs(g_ref), 1e-4 * np.abs(g_ref).max())
+        rec["within_1e-3_frac"][k] = round(float((rel.reshape(len(g_ref), -1).max(axis=1) <= 1e-3)[visible].mean()), 5)
+    rec["meets"] = {"image_1e-4_abs": bool(rec["img_max_abs_stable"] < 1e-4 and rec["alpha_max_abs_stable"] < 1e-4),
+                    "gradients_1e-3_rel": bool(all(v <= 1e-3 for v in rec["grad_max_abs_over_max_ref"].values())
+                                               and all(v <= 1e-4 for v in rec["grad_l2_rel"].values()))}
+    rec["what"] = ("this run's GPU image / alpha / gradients of the timed scene vs the CPU oracle on the same inputs: image on "
+                   "pixels with no decision within 1e-5 of flipping; gradients as L2-relative error, max error over "
+                   "max |ref|, and the share of visible Gaussians within 1e-3 relative (|ref| floored at 1e-4 max|ref|)")
+    return rec
+
+
+def cpu_baseline(sc, cam, bg, v_img, v_alpha, deg, keep=None):
     """The CPU oracle (a port of the reference algorithm, oracle/gsr_oracle.c)
     timed on the host cores over the same workload (one full fwd+bwd)."""
     from oracle import oracle as O
@@ -117,18 +149,22 @@ def cpu_baseline(sc, cam, bg, v_img, v_alpha, deg):
     rgbs = np.maximum(sh + 0.5, 0).astype(np.float32)
     r = O.render_forward(sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat,
                          cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width, 16, rgbs,
-                         sc["opacities"], bg)
+                         sc["opacities"], bg, ambig_eps=1e-5 if keep is not None else None)
     t1 = time.perf_counter()
     vxy, vconic, vcol, vop = O.rasterize_backward(
         cam.height, cam.width, 16, r["gaussian_ids_sorted"], r["tile_bins"], r["xys"], r["conics"], rgbs,
         sc["opacities"], bg, r["final_Ts"], r["final_idx"], v_img, v_alpha)
-    O.compute_sh_backward(n, deg, deg, dirs, (vcol * (sh + 0.5 > 0)).astype(np.float32))
+    vsh = O.compute_sh_backward(n, deg, deg, dirs, (vcol * (sh + 0.5 > 0)).astype(np.float32))
     zeros = np.zeros(n, np.float32)
-    O.project_gaussians_backward(n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3],
-                                 cam.projmat, cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width,
-                                 r["cov3d"], r["radii"], r["conics"], r["compensation"], vxy, zeros, vconic,
-                                 zeros)
+    vproj = O.project_gaussians_backward(n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3],
+                                         cam.projmat, cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width,
+                                         r["cov3d"], r["radii"], r["conics"], r["compensation"], vxy, zeros, vconic,
+                                         zeros)
     t2 = time.perf_counter()
+    if keep is not None:  # the arrays the GPU's results for this very workload are checked against (`parity_vs_oracle`)
+        keep.update(out_img=r["out_img"], final_Ts=r["final_Ts"], ambig=r["ambig"], radii=r["radii"], xys=r["xys"],
+                    grads={"xys": vxy, "opacities": vop, "sh_coeffs": vsh, "means3d": vproj[2], "scales": vproj[3],
+                           "quats": vproj[4]})
     pix = cam.width * cam.height
     return {
         "value": pix / (t2 - t0) / 1e6,
@@ -143,13 +179,19 @@ def cpu_baseline(sc, cam, bg, v_img, v_alpha, deg):
 # BASELINE config 3 ("gs-train gaussian-splatting on a nerfstudio-style synthetic scene (~1M Gaussians),
 # 1xMI355X, 7k iters"; config 4 = the same under per-view data parallelism).  ONE definition: bench.py's
 # `train` record, tests/test_gpu_train.py::test_config3_* and tools/train_bench.py --config3 all use it.
-def config3(iters=7000):
+def config3(iters=7000, schedule="reference"):
+    """schedule="reference": the reference's defaults for resolution and background as well (coarse-to-fine:
+    num_downscales 2 / resolution_schedule 2000, vanilla_gs.py:48-53 -- 480x270 until step 2000, 960x540 until 4000,
+    then 1920x1080; `background_color="random"`, :50) -- what `gs-train gaussian-splatting` runs.
+    schedule="full": 1920x1080 from step 0 over one fixed background (the round-3 record, kept for continuity)."""
     from gs_fused import RefineConfig
     from harness.train import TrainConfig
 
+    ref = schedule == "reference"
     return TrainConfig(
         num_gaussians=CONFIG3["truth_gaussians"], width=1920, height=1080, num_views=48, iters=iters,
         sh_degree=3, sh_degree_interval=1000,          # vanilla_gs.py:67 (reference default)
+        num_downscales=2 if ref else 0, resolution_schedule=2000, background_color="random" if ref else "fixed",
         densify=True, refine=RefineConfig(),           # every reference default, densify_grad_thresh = 2e-4 included
         init="sfm", init_gaussians=CONFIG3["seed_points"],  # populate_modules from a sparse point cloud
         means_lr_schedule=True,                        # method_configs.py:98-104
@@ -178,6 +220,28 @@ def fixed_1m(iters=400):
                        sh_degree=3, sh_degree_interval=max(1, iters // 4), phase_every=20)
 
 
+def refined_1m(iters=1500):
+    """1 M Gaussians at 1080p WITH the reference's refinement running (BASELINE config 3's "~1M Gaussians", config 5's
+    "densify/prune active"): the model starts as a perturbed copy of a 1 M-Gaussian scene, densify / cull / opacity
+    reset follow the reference's schedule and thresholds (warm-up 500, every 100), N moves as the rule decides."""
+    from gs_fused import RefineConfig
+    from harness.train import TrainConfig
+
+    return TrainConfig(num_gaussians=1_000_000, width=1920, height=1080, num_views=16, iters=iters, sh_degree=3,
+                       sh_degree_interval=max(1, iters // 4), densify=True, refine=RefineConfig(), phase_every=20,
+                       means_lr_schedule=True)
+
+
+def unchanged_caller(cfg):
+    """`cfg` with the caller as the toolkit has it: torch ops for the activations, `torch.cat` of the SH features,
+    the torch-op L1 + SSIM, one `torch.optim.Adam` per group, `after_train` in torch ops -- and the host read-backs
+    of `get_outputs` (intrinsics, `radii.sum() == 0`, `(num_tiles_hit > 0).any()`).  Only the three rasterizer ops
+    are this package's."""
+    cfg.fused_loss = cfg.fused_adam = cfg.split_sh = cfg.fused_activations = False
+    cfg.caller_syncs = "camera"
+    return cfg
+
+
 def train_only(args):
     """`bench.py --train-only`: BASELINE config 3 (N = 1) / config 4 (N > 1) through harness.train.train;
     rank 0 prints the record as one JSON line.  Run as a subprocess of the main bench so that a
@@ -200,17 +264,34 @@ def train_only(args):
     from harness.train import train
 
     cfg = config3(args.train_iters)
-    if args.train_small:  # tests only: the same code path on a scene that trains in seconds
+    def _small(cfg):  # tests only: the same code path on a scene that trains in seconds
         from gs_fused import RefineConfig
 
         cfg.num_gaussians, cfg.init_gaussians, cfg.width, cfg.height, cfg.num_views = 40_000, 8_000, 320, 180, 8
         cfg.scene_objects, cfg.scene_scale, cfg.sh_degree_interval, cfg.phase_every = (12, 0.3, 0.6), (0.01, 0.03), 40, 10
         cfg.refine = RefineConfig(warmup_length=30, refine_every=20, reset_alpha_every=6, stop_screen_size_at=200)
         cfg.log_every = 10
+        cfg.resolution_schedule = max(1, cfg.iters // 4)  # both resolution switches inside the short run
+
+    if args.train_small:
+        _small(cfg)
     res = train(cfg, dev, rank, world)
-    res1m = train(fixed_1m(), dev, rank, world) if (args.train_iters >= 1000 and not args.train_small) else None
+    full_run = args.train_iters >= 1000 and not args.train_small
+    res1m = train(fixed_1m(), dev, rank, world) if full_run else None
+    extra = {}
+    if full_run or args.train_small:
+        # the same configuration with the host blocked where the unchanged models block it (vanilla_gs.py:784,811)
+        cfg_s = config3(args.train_iters)
+        if args.train_small:
+            _small(cfg_s)
+        cfg_s.caller_syncs = True
+        extra["caller_syncs"] = train(cfg_s, dev, rank, world)
+    if full_run:
+        extra["full_res"] = train(config3(args.train_iters, schedule="full"), dev, rank, world)
+        extra["unchanged_caller"] = train(unchanged_caller(config3(args.train_iters)), dev, rank, world)
+        extra["refined_1m"] = train(refined_1m(), dev, rank, world)
     res_one = None
-    if args.train_iters >= 1000 and not args.train_small:
+    if full_run:
         # the same configuration through gs_fused.render_gaussians: one autograd node and one native call per view
         # instead of the models' op-by-op sequence (optional API; the headline figure above is the public ops)
         cfg_one = config3(args.train_iters)
@@ -237,23 +318,54 @@ def train_only(args):
             "psnr": {"start": round(res["psnr_start"], 2), "end": round(res["psnr_end"], 2)},
             "loss_first_last": [losses[0], losses[-1]],
             "phase_ms_median": res["phase_ms_median"],
+            "phase_ms_median_by_resolution": res["phase_ms_median_by_resolution"],
+            "schedule": res["schedule"],
             "list_overflow_views": res["list_overflow_views"],
             "render": res["render"],
             "scene": (f"hidden truth: {cfg.num_gaussians} flat textured Gaussians on {cfg.scene_objects[0]} spheres in a ball of "
                       f"radius {cfg.scene_extent} (harness.train.blob_scene 'objects'), {cfg.num_views} views from an orbit of "
                       f"radius {cfg.cam_radius} rendered by this rasterizer"),
-            "why_not_1M": ("every reference default incl. densify_grad_thresh 2e-4: the rule stops splitting at a roughly fixed "
-                           "number of Gaussians per covered pixel, ~0.45 M here (tools/exp/exp_seed.sh, DESIGN 4.7); "
-                           "the rate at a fixed 1 M Gaussians is in `fixed_1m`"),
+            "why_not_1M": ("every reference default incl. densify_grad_thresh 2e-4, the coarse-to-fine resolution schedule and "
+                           "the random background: the rule stops splitting at a roughly fixed number of Gaussians per "
+                           "covered pixel (tools/exp/exp_seed.sh, DESIGN 4.7); the rate at 1 M Gaussians is in `fixed_1m` "
+                           "(N fixed) and `refined_1m` (refinement active)"),
             "model_start": (f"{cfg.init}: {cfg.init_gaussians} noisy surface points with 8-bit colours; scales = 3-NN distance, "
                             "random quats, opacity 0.1 (vanilla_gs.py:128-174)"),
             "refinement": {"densify_grad_thresh": res["densify_grad_thresh"], "schedule": "reference defaults "
                            "(warm-up 500, every 100, opacity reset every 3000, screen-size rules until 4000)"},
+            "ground_truth": ("RGBA (straight colour + alpha, as a blender-style dataset stores it), downscaled every step "
+                             "(vanilla_gs.py:659-670) and composited over the step's random background (:870-881)"
+                             if cfg.background_color == "random" else "RGB over the fixed background"),
             "allreduce_bytes_step_bytes": res["allreduce_bytes"] or None,
             "replicas_identical": res.get("replicas_identical"),
             "parallelism": (f"dp{world} per-view, {backend}" if world > 1 else "single"),
             "update": res["update"],
         }
+        brief = lambda r: {"iters_per_s": round(r["iters_per_s"], 1), "gaussians_end": r["num_gaussians_end"],  # noqa: E731
+                           "gaussians_max": max([n_ for _, n_ in r["refinements"]] + [r["num_gaussians_start"]]),
+                           "psnr": [round(r["psnr_start"], 2), round(r["psnr_end"], 2)],
+                           "list_overflow_views": r["list_overflow_views"], "phase_ms_median": r["phase_ms_median"],
+                           "phase_ms_median_by_resolution": r["phase_ms_median_by_resolution"]}
+        if "caller_syncs" in extra:
+            rec["iters_per_s_with_caller_syncs"] = round(extra["caller_syncs"]["iters_per_s"], 1)
+            rec["with_caller_syncs"] = dict(brief(extra["caller_syncs"]), what=(
+                "the same run with the host blocked where the unchanged models block it: `if (self.radii).sum() == 0` "
+                "and `assert (num_tiles_hit > 0).any()` (vanilla_gs.py:784,811)"))
+        if "full_res" in extra:
+            rec["full_resolution_from_step_0"] = dict(brief(extra["full_res"]), what=(
+                "num_downscales 0, fixed background: the round-3 record's configuration"))
+        if "unchanged_caller" in extra:
+            rec["iters_per_s_unchanged_caller"] = round(extra["unchanged_caller"]["iters_per_s"], 1)
+            rec["unchanged_caller"] = dict(brief(extra["unchanged_caller"]), what=(
+                "only the three rasterizer ops are this package's: torch-op activations / torch.cat / torch-op L1+SSIM / "
+                "six torch.optim.Adam / torch-op after_train, and all of get_outputs' host read-backs (intrinsics "
+                ".item(), radii.sum() == 0, (num_tiles_hit > 0).any())"))
+        if "refined_1m" in extra:
+            r_ = extra["refined_1m"]
+            rec["refined_1m"] = dict(brief(r_), iters=r_["iters"], gaussians_start=r_["num_gaussians_start"],
+                                     history_step_N=r_["refinements"][:: max(1, len(r_["refinements"]) // 12)],
+                                     what="1 M Gaussians at 1920x1080 with the reference's refinement schedule and "
+                                          "thresholds active (densify / cull / opacity reset), full training iteration")
         if res_one is not None:
             rec["one_op_path"] = {"what": "config 3 through gs_fused.render_gaussians (one native call per view, statistics "
                                           "from its backward)", "iters_per_s": round(res_one["iters_per_s"], 1),
@@ -423,6 +535,15 @@ def main():
                          "float atomics")
     ap.add_argument("--scene", default="uniform", choices=["uniform", "longtail"],
                     help="longtail: 10 %% of the tiles hold ~10x the list depth (clustered Gaussians)")
+    ap.add_argument("--caller-syncs", default="off", choices=["off", "on", "camera"],
+                    help="run the MAIN timed region with the unchanged models' host read-backs in the caller (profiling "
+                         "runs; the default line reports all three modes anyway)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="with --gpus 1: create the process group anyway (one rank) and run the gradient exchange "
+                         "through it -- every collective of the N > 1 path goes through the backend as an identity "
+                         "(how the RCCL path is exercised on a single-GPU box)")
+    ap.add_argument("--no-synced-regions", action="store_true",
+                    help="skip the two extra timed regions with the caller's read-backs (profiling runs)")
     ap.add_argument("--train-iters", type=int, default=7000,
                     help="iterations of the config-3 training record (BASELINE metric, second half); 0: skip it")
     ap.add_argument("--train-timeout", type=int, default=900)
@@ -458,8 +579,16 @@ def main():
     if backend == "auto":
         backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
     args.backend = backend
-    if world > 1:
+    dp = world > 1 or args.force_exchange
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -495,25 +624,27 @@ def main():
     # the exchange starts per parameter from autograd hooks, as soon as a gradient exists (the SH
     # block while project_backward still runs), and leaves inactive SH bands out
     exchange = GradientExchange({k: params[k] for k in ("means3d", "scales", "quats", "opacities", "sh_coeffs")},
-                                average=True).attach()
+                                average=True, force=args.force_exchange).attach()
     exchange.active_rows["sh_coeffs"] = (deg_use + 1) ** 2
     # N > 1: the SH gradient is formed on every rank from the ranks' all-gathered 12-byte colour cotangents instead of
     # being all-reduced (GradientExchange `sh_views`; --sh-exchange dense: every gradient all-reduced)
-    sh_views = world > 1 and args.sh_exchange == "views" and deg <= 3
+    sh_views = dp and args.sh_exchange == "views" and deg <= 3
 
-    def step():
+    main_mode = {"off": False, "on": True, "camera": "camera"}[args.caller_syncs]
+
+    def step(caller_syncs=main_mode):
         for p in plist:
             p.grad = None
         out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
                           params["sh_coeffs"], camt, bg, deg_use, clamp_rgb=False, render_depth=args.render_depth,
-                          fused_depth=args.fused_depth,
+                          fused_depth=args.fused_depth, caller_syncs=caller_syncs,
                           sh_exchange=(exchange, ("sh_coeffs",), (params["sh_coeffs"],)) if sh_views else None)
         if args.render_depth:
             torch.autograd.backward([out["rgb"], out["alpha"], out["depth"]],
                                     [v_img, v_alpha[..., None], v_alpha[..., None]])
         else:
             torch.autograd.backward([out["rgb"], out["alpha"]], [v_img, v_alpha[..., None]])
-        if world > 1:
+        if dp:
             if timers.enabled:  # what is left of the exchange once the backward has been queued
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -525,7 +656,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -586,8 +717,46 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     pixels = W * H
     value = world * pixels / (elapsed / args.steps) / 1e6
-    allreduce_bytes = exchange.bytes_last if world > 1 else None
-    if world > 1:
+
+    # The same K steps again with the host blocked where the UNCHANGED models block it (render_view `caller_syncs`):
+    # `if (self.radii).sum() == 0` and `assert (num_tiles_hit > 0).any()` (vanilla_gs.py:784,811); and once more with
+    # the intrinsics' `.item()` read-backs ahead of the projection as well (:736-740,772-773), which drain the stream
+    # at the head of every view.  `value` above is what a caller without read-backs gets; these are what
+    # `gs-train` gets with the models as they are.
+    synced = {}
+    for mode, key in ((True, "caller_syncs"), ("camera", "caller_and_camera_syncs")):
+        if args.no_synced_regions:
+            synced[key] = (None, None)
+            continue
+        for _ in range(min(3, args.warmup)):
+            step(mode)
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            step(mode)
+        barrier()
+        el = time.perf_counter() - ts
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        synced[key] = (1e3 * el / args.steps, world * pixels / (el / args.steps) / 1e6)
+    gpu_results = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dp:
+        # one more (untimed) step whose results go to the host: what `parity_vs_oracle` checks
+        for p in plist:
+            p.grad = None
+        o = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"], params["sh_coeffs"],
+                        camt, bg, deg_use, clamp_rgb=False, retain_xys_grad=True)
+        torch.autograd.backward([o["rgb"], o["alpha"]], [v_img, v_alpha[..., None]])
+        torch.cuda.synchronize()
+        c = lambda t_: t_.detach().cpu().numpy()  # noqa: E731
+        gpu_results = {"rgb": c(o["rgb"]), "alpha": c(o["alpha"])[..., 0], "xys": c(o["xys"]), "radii": c(o["radii"]),
+                       "grads": dict({k: c(params[k].grad) for k in ("means3d", "scales", "quats", "opacities", "sh_coeffs")},
+                                     xys=c(o["xys"].grad))}
+        del o
+    allreduce_bytes = exchange.bytes_last if dp else None
+    if dp:
         # the timed job is over: the other ranks leave (and free their GPUs) while rank 0 runs the
         # training leg in a fresh process group of its own and then prints the line
         dist.barrier()
@@ -675,10 +844,17 @@ def main():
                 per_kernel[k]["traffic_per_step"] = stage_traffic[k]
         end_to_end = alg_job["total"] / (ms_per_step * 1e-3) / 1e9
 
-        cpu = cpu1 = None
+        cpu = cpu1 = parity = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu, _ = cpu_baseline(sc, cam, bg_np, v_img_np, v_alpha_np, deg)
+            kept = {} if (deg_use == deg and not args.render_depth) else None
+            cpu, _ = cpu_baseline(sc, cam, bg_np, v_img_np, v_alpha_np, deg, keep=kept)
             cpu["value"] = round(cpu["value"], 4)
+            if kept:
+                try:
+                    parity = parity_vs_oracle(gpu_results, kept)
+                except Exception as e:  # the line must survive
+                    parity = {"error": repr(e)}
+                kept.clear()
             cpu1 = cpu_baseline_one_thread(sc, cam, bg_np, v_img_np, v_alpha_np, deg)
             cpu1["value"] = round(cpu1["value"], 4)
         res_name = "1080p" if (W, H) == (1920, 1080) else ("4K" if (W, H) == (3840, 2160) else f"{W}x{H}")
@@ -693,6 +869,17 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            # the same steps with the unchanged models' host read-backs in the caller (see `synced` above)
+            "value_with_caller_syncs": _rnd(synced["caller_syncs"][1], 2),
+            "ms_per_step_with_caller_syncs": _rnd(synced["caller_syncs"][0], 4),
+            "caller_syncs_gap": (None if synced["caller_syncs"][0] is None
+                                 else round(synced["caller_syncs"][0] / ms_per_step - 1.0, 4)),
+            "value_with_caller_and_camera_syncs": _rnd(synced["caller_and_camera_syncs"][1], 2),
+            "ms_per_step_with_caller_and_camera_syncs": _rnd(synced["caller_and_camera_syncs"][0], 4),
+            "caller_syncs_what": ("caller_syncs: `if (self.radii).sum() == 0` + `assert (num_tiles_hit > 0).any()` "
+                                  "(vanilla_gs.py:784,811) block the host twice per view; caller_and_camera_syncs: plus "
+                                  "the eight intrinsics read-backs ahead of the projection (:736-740,772-773), the first "
+                                  "of which drains the stream; `value` = no read-backs"),
             "ms_per_step_median": round(float(np.median(step_ms)), 4),
             "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, 10)), 4),
                                     round(float(np.percentile(step_ms, 90)), 4)],
@@ -724,6 +911,7 @@ def main():
             },
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "parity_vs_oracle": parity,
             "cpu_baseline_one_thread_60k_gaussian_subset": cpu1,
             "kernels": per_kernel,
             "kernel_events": f"HIP events around each native call on every {args.event_every}th timed step" if args.event_every > 1 else "HIP events around each native call on every timed step",

@@ -423,11 +423,12 @@ def single_process_vis_counts(vis_counts: torch.Tensor, first_visible: Optional[
 
 
 def allreduce_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tensor,
-                            max_2dsize: torch.Tensor, group=None, first_visible: Optional[torch.Tensor] = None) -> None:
+                            max_2dsize: torch.Tensor, group=None, first_visible: Optional[torch.Tensor] = None,
+                            force: bool = False) -> None:
     """Keep the densification statistics (vanilla_gs.py:351-372) identical on
     every rank AND equal to what one process seeing all ranks' views would hold: sum, sum (with
     `single_process_vis_counts`), max.  In place."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return
     single_process_vis_counts(vis_counts, first_visible, dist.get_rank(group))
     packed = torch.stack([xys_grad_norm, vis_counts.to(xys_grad_norm.dtype)])

@@ -32,11 +32,17 @@ class CameraTensors:
     projmat: torch.Tensor  # [4,4] = P @ V
     campos: torch.Tensor  # [3]
 
+    # [fx, fy, cx, cy, width, height] on the device: the toolkit's `Cameras` keeps its intrinsics there and
+    # `get_outputs` reads them back one `.item()` at a time (vanilla_gs.py:736-740,772-773) -- `caller_syncs="camera"`
+    scalars: Optional[torch.Tensor] = None
+
     @staticmethod
     def from_numpy(cam, device) -> "CameraTensors":
         t = lambda a: torch.from_numpy(a).to(device)
         return CameraTensors(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
-                             t(cam.viewmat), t(cam.projmat), t(cam.campos))
+                             t(cam.viewmat), t(cam.projmat), t(cam.campos),
+                             torch.tensor([cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height], dtype=torch.float32,
+                                          device=device))
 
 
 def render_view(
@@ -58,12 +64,28 @@ def render_view(
     sh_exchange=None,  # (parallel.GradientExchange, names, leaves) with names / leaves = ("features_dc",
                        # "features_rest") / those parameters, or ("sh_coeffs",) / ([N,K,3],): data parallel, the SH
                        # gradient is formed from the ranks' gathered colour cotangents (GradientExchange, `sh_views`)
+    caller_syncs=False,  # True: block the host where the UNCHANGED models do -- `if (self.radii).sum() == 0`
+                         # (vanilla_gs.py:784) and `assert (num_tiles_hit > 0).any()` (:811); "camera": also the
+                         # intrinsics read back from the device ahead of the projection (:736-740, :772-773).
+                         # False: the same ops with no read-back -- what a caller that WAS changed could do
 ) -> Dict[str, Optional[torch.Tensor]]:
     H, W = cam.height, cam.width
+    if caller_syncs == "camera" and cam.scalars is not None:
+        # cx.item(), cy.item(), math.atan(width / (2 fx)), math.atan(height / (2 fy)), width.item(), height.item(),
+        # fx.item(), fy.item(): eight read-backs, the first of which drains the stream (the previous iteration's
+        # optimizer step included)
+        sc = cam.scalars
+        _ = (sc[2].item(), sc[3].item(), float(sc[4] / (2 * sc[0])), float(sc[5] / (2 * sc[1])), sc[4].item(),
+             sc[5].item(), sc[0].item(), sc[1].item())
     xys, depths, radii, conics, comp, num_tiles_hit, cov3d = project_gaussians(
         means3d, scales, 1, quats, cam.viewmat[:3, :], cam.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
         H, W, BLOCK_WIDTH,
     )
+    if caller_syncs and (radii).sum() == 0:  # vanilla_gs.py:784-794: nothing on screen, the background
+        rgb = background.repeat(H, W, 1)
+        return {"rgb": rgb, "alpha": background.new_zeros(H, W, 1), "depth": background.new_ones(H, W, 1) * 10,
+                "xys": xys, "radii": radii, "depths": depths, "conics": conics, "num_tiles_hit": num_tiles_hit,
+                "rgbs": None}
     if retain_xys_grad and xys.requires_grad:
         xys.retain_grad()  # densification reads xys.grad (vanilla_gs.py:352-353,797-798)
 
@@ -89,6 +111,9 @@ def render_view(
         rgbs = sh_fn()
     if not split:
         rgbs = torch.clamp(rgbs + 0.5, min=0.0)
+
+    if caller_syncs:
+        assert (num_tiles_hit > 0).any()  # vanilla_gs.py:811 (a second blocking read-back)
 
     if rasterize_mode == "antialiased":
         opac = opacities * comp[:, None]

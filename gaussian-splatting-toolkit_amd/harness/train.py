@@ -69,6 +69,43 @@ def orbit_cameras(n_views: int, width: int, height: int, radius: float = 6.0, fo
     return cams
 
 
+def rescale_camera(cam, d: int):
+    """`camera.rescale_output_resolution(1 / d)` (gs_toolkit/cameras/cameras.py:1176-1213: fx, fy, cx, cy scaled,
+    width and height scaled and truncated to integers) followed by what `get_outputs` derives from the rescaled
+    camera (vanilla_gs.py:736-742: the fields of view from the NEW width / fx, the projection matrix from those)."""
+    if d == 1:
+        return cam
+    f = 1.0 / d
+    fx, fy, cx, cy = cam.fx * f, cam.fy * f, cam.cx * f, cam.cy * f
+    W, H = int(cam.width * f), int(cam.height * f)
+    fovx, fovy = 2.0 * math.atan(W / (2.0 * fx)), 2.0 * math.atan(H / (2.0 * fy))
+    P = S.projection_matrix(0.001, 1000.0, fovx, fovy) @ cam.viewmat
+    return S.Camera(W, H, fx, fy, cx, cy, cam.viewmat, P.astype(np.float32))
+
+
+def downscale_factor(step: int, num_downscales: int, resolution_schedule: int) -> int:
+    """`_get_downscale_factor` while training (vanilla_gs.py:646-657): 2^max(num_downscales - step // schedule, 0)."""
+    return 2 ** max(num_downscales - step // max(resolution_schedule, 1), 0)
+
+
+def downscale_image(image: torch.Tensor, d: int) -> torch.Tensor:
+    """`_downscale_if_required` (vanilla_gs.py:659-670): `TF.resize(image.permute(2, 0, 1), [H // d, W // d],
+    antialias=None)` -- for tensors that is bilinear interpolation without antialiasing."""
+    if d <= 1:
+        return image
+    newsize = [image.shape[0] // d, image.shape[1] // d]
+    return F.interpolate(image.permute(2, 0, 1)[None], size=newsize, mode="bilinear", align_corners=False,
+                         antialias=False)[0].permute(1, 2, 0)
+
+
+def composite_with_background(image: torch.Tensor, background: torch.Tensor) -> torch.Tensor:
+    """vanilla_gs.py:870-881: a ground-truth image with an alpha channel is composited over the step's background."""
+    if image.shape[2] == 4:
+        alpha = image[..., -1].unsqueeze(-1).repeat((1, 1, 3))
+        return alpha * image[..., :3] + (1 - alpha) * background
+    return image
+
+
 def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale_lo=0.01, scale_hi=0.06,
                kind: str = "ball", tex_cell: float = 0.04, objects=(48, 0.18, 0.45)):
     """Raw (pre-activation) Gaussians around the origin.  kind="ball": semi-transparent
@@ -218,7 +255,7 @@ class GaussianParams(torch.nn.Module):
                 self.gauss[k] = torch.nn.Parameter(new[k])
 
     def render(self, cam: CameraTensors, background, sh_degree_to_use: int, render_depth=False,
-               retain_xys_grad=False, clamp_rgb=True, sh_exchange=None):
+               retain_xys_grad=False, clamp_rgb=True, sh_exchange=None, caller_syncs=False):
         g = self.gauss
         if self.split_sh and g["features_dc"].is_cuda and g["features_rest"].shape[1] in (3, 8, 15):
             coeffs = (g["features_dc"], g["features_rest"])  # gs_fused.spherical_harmonics_split
@@ -235,7 +272,7 @@ class GaussianParams(torch.nn.Module):
             opac, dirs = torch.sigmoid(g["opacities"]), None
         return render_view(g["means"], scales, quats, opac, coeffs, cam, background, sh_degree_to_use,
                            render_depth=render_depth, retain_xys_grad=retain_xys_grad, viewdirs=dirs,
-                           clamp_rgb=clamp_rgb,
+                           clamp_rgb=clamp_rgb, caller_syncs=caller_syncs,
                            sh_exchange=None if sh_exchange is None else (
                                sh_exchange, ("features_dc", "features_rest"), (g["features_dc"], g["features_rest"])))
 
@@ -319,6 +356,22 @@ class TrainConfig:
     scene_objects: tuple = (48, 0.18, 0.45)  # scene "objects": number of spheres, radius range
     cam_radius: float = 6.0               # radius of the camera orbit
     scene_extent: float = 1.5             # radius of the ball the scene fills
+    # the reference's coarse-to-fine schedule (vanilla_gs.py:48-53, 646-669): the first `resolution_schedule`
+    # iterations render at 1 / 2^num_downscales of the resolution, the next at half of that factor, ... (reference
+    # defaults: 2 and 2000, i.e. 480x270 -> 960x540 -> 1920x1080 at steps 2000 and 4000; 0 here = full size from step 0)
+    num_downscales: int = 0
+    resolution_schedule: int = 2000
+    # "random": a fresh `torch.rand(3)` background every training step (vanilla_gs.py:50, 688-690 -- the reference's
+    # default), the ground truth then carries an alpha channel and is composited over it (:870-881, a
+    # nerfstudio-synthetic / blender-style RGBA dataset); "fixed": scene.BACKGROUND, RGB ground truth
+    background_color: str = "fixed"
+    # block the host where the unchanged models do (pipeline.render_view `caller_syncs`): False, True (the two
+    # read-backs of get_outputs, vanilla_gs.py:784,811) or "camera" (plus the intrinsics' .item() calls)
+    caller_syncs: object = False
+    # run the data-parallel machinery (gradient exchange, sharded Adam, statistics all-reduce) on a process group of
+    # ONE rank too: every collective then goes through the backend as an identity -- how the RCCL code path is
+    # exercised on a single-GPU box (tests/test_gpu_nccl.py)
+    force_exchange: bool = False
 
 
 def _sh_views_backward_autograd():
@@ -344,16 +397,40 @@ def _sh_views_backward_autograd():
 def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     """Fit a perturbed copy of a hidden scene to its own renders.  Returns timing
     and quality numbers; every rank ends with identical parameters."""
+    dp = world > 1 or (cfg.force_exchange and dist.is_available() and dist.is_initialized())
     cams_np = orbit_cameras(cfg.num_views, cfg.width, cfg.height, radius=cfg.cam_radius)
     cams = [CameraTensors.from_numpy(c, device) for c in cams_np]
+    # the coarse-to-fine schedule's cameras, one set per downscale factor
+    factors = sorted({downscale_factor(s_, cfg.num_downscales, cfg.resolution_schedule)
+                      for s_ in range(0, max(cfg.iters, 1), max(min(cfg.resolution_schedule, cfg.iters), 1))} | {1})
+    cams_by_d = {d: (cams if d == 1 else [CameraTensors.from_numpy(rescale_camera(c, d), device) for c in cams_np])
+                 for d in factors}
     bg = torch.tensor(S.BACKGROUND, device=device)
+    random_bg = cfg.background_color == "random"
+    if cfg.background_color not in ("random", "fixed"):
+        raise ValueError(f"unknown background_color {cfg.background_color!r}")
+    # (the reference seeds every rank differently, scripts/train.py:54: the backgrounds differ per rank, as there)
+    bg_gen = torch.Generator(device=device).manual_seed(cfg.seed + 977 * (rank + 1)) if random_bg else None
 
     mk = lambda: blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree, kind=cfg.scene,
                             scale_lo=cfg.scene_scale[0], scale_hi=cfg.scene_scale[1], tex_cell=cfg.tex_cell,
                             objects=cfg.scene_objects, extent=cfg.scene_extent)
     truth = GaussianParams(mk(), device)
     with torch.no_grad():
-        gt = [truth.render(c, bg, cfg.sh_degree)["rgb"] for c in cams]
+        if random_bg:
+            # RGBA ground truth with straight (un-premultiplied) colour, as a blender-style dataset stores it:
+            # rendered over black, C = sum c_i a_i T_i and A = 1 - T, colour = C / A
+            zero = torch.zeros(3, device=device)
+            gt_rgba, gt = [], []
+            for c in cams:
+                o = truth.render(c, zero, cfg.sh_degree, clamp_rgb=False)
+                a = o["alpha"]
+                gt_rgba.append(torch.cat((torch.where(a > 0, o["rgb"] / a.clamp_min(1e-12), torch.zeros_like(o["rgb"]))
+                                          .clamp(0, 1), a), dim=-1))
+                gt.append(composite_with_background(gt_rgba[-1], bg))  # evaluation: over the fixed background
+        else:
+            gt_rgba = None
+            gt = [truth.render(c, bg, cfg.sh_degree)["rgb"] for c in cams]
 
     raw = mk()
     rng = np.random.default_rng(cfg.seed + 1)
@@ -386,7 +463,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     else:
         optims = {k: torch.optim.Adam([model.gauss[k]], lr=lr, eps=1e-15) for k, lr in LRS.items()}
     sharded = None
-    if cfg.sharded_adam and world > 1:
+    if cfg.sharded_adam and dp:
         from .parallel import ShardedAdam
 
         if cfg.fused_adam and device.type == "cuda":
@@ -395,7 +472,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             make = lambda groups: FusedAdam(groups, eps=1e-15)
         else:
             make = lambda groups: torch.optim.Adam(groups, eps=1e-15)
-        sharded = ShardedAdam({k: model.gauss[k] for k in PARAM_NAMES}, LRS, make)
+        sharded = ShardedAdam({k: model.gauss[k] for k in PARAM_NAMES}, LRS, make, force=cfg.force_exchange)
         optims = {}
     fused_clamp = False
     if cfg.fused_loss and device.type == "cuda":
@@ -443,7 +520,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     losses = []
     # gradient exchange: started per parameter from autograd hooks (overlaps the rest of the
     # backward), SH bands above the warm-up degree left out
-    exchange = GradientExchange({k: model.gauss[k] for k in PARAM_NAMES}, average=True)
+    exchange = GradientExchange({k: model.gauss[k] for k in PARAM_NAMES}, average=True, force=cfg.force_exchange)
     # a replayed HIP graph fires no hooks, and a hook during capture would put a collective INTO the
     # graph (and reduce every gradient twice): under use_graph the exchange is started after the replay
     exchange.use_hooks = not cfg.use_graph
@@ -453,13 +530,13 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     exchanged_bytes = []
     if device.type == "cuda":
         torch.cuda.synchronize(device)
-    if world > 1:
+    if dp:
         dist.barrier()
     t0 = time.perf_counter()
     use_fused = (cfg.fused_render or cfg.use_graph) and device.type == "cuda" and cfg.split_sh and cfg.fused_loss \
         and cfg.sh_degree in (0, 1, 2, 3)
     # (through the one native call per view as well, but not under graph replay: no hooks there)
-    sh_views = world > 1 and cfg.sh_exchange == "views" and exchange.enabled and exchange.use_hooks
+    sh_views = dp and cfg.sh_exchange == "views" and exchange.enabled and exchange.use_hooks
     if sh_views and device.type != "cuda":
         exchange.sh_views_backward = _sh_views_backward_autograd()  # no native kernel here: autograd of the SH op
     fstats = caps = vgraph = vkey = None
@@ -490,32 +567,47 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
 
     phase_marks = []
     first_pending, first_vis = True, None
+    rebuilds0 = _list_rebuilds()
+    bg_static = bg.clone() if (random_bg and cfg.use_graph) else None  # a replayed graph reads its background here
     for step in range(start_step, cfg.iters):
         ph = None
         v = view_for_rank(step, rank, world, cfg.num_views)
         deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
         exchange.active_rows["features_rest"] = (deg + 1) ** 2 - 1
+        # this step's resolution (vanilla_gs.py:646-657, 719-720), background (:688-690) and ground truth
+        # (:859-868 downscaled every step, :870-881 composited over the step's background)
+        d = downscale_factor(step, cfg.num_downscales, cfg.resolution_schedule)
+        cam = cams_by_d[d][v]
+        max_dim = max(cam.width, cam.height)  # `max(self.last_size)` of after_train / refinement_after
+        if random_bg:
+            bg_step = torch.rand(3, device=device, generator=bg_gen)
+            target = composite_with_background(downscale_image(gt_rgba[v], d), bg_step)
+            if bg_static is not None:
+                bg_static.copy_(bg_step)
+                bg_step = bg_static
+        else:
+            bg_step, target = bg, downscale_image(gt[v], d)
         if use_fused:
-            cam = cams[v]
-            spec = ViewSpec(cfg.height, cfg.width, cam.fx, cam.fy, cam.cx, cam.cy, deg)
+            spec = ViewSpec(cam.height, cam.width, cam.fx, cam.fy, cam.cx, cam.cy, deg)
             fstats.enabled = not (cfg.densify and step >= rcfg.stop_split_at)
+            fstats.max_dim = max_dim
             g_ = model.gauss
             if cfg.use_graph:
                 # `generation` counts the refinements that swapped parameter tensors: N can come out
                 # unchanged (k culled, k duplicated) while every tensor the graph points at is gone
                 key = (spec, model.num_points, caps.capacity, fstats.enabled, generation)
                 if vkey != key:  # new SH degree, N changed by refinement, or larger lists: capture again
-                    vgraph = ViewGraph({k: g_[k] for k in PARAM_NAMES}, spec, caps.capacity, graph_loss, bg,
-                                       [(cfg.height, cfg.width, 3)], stats=fstats)
-                    vgraph.capture(cam.viewmat, cam.projmat, cam.campos, (gt[v],))
+                    vgraph = ViewGraph({k: g_[k] for k in PARAM_NAMES}, spec, caps.capacity, graph_loss, bg_step,
+                                       [(cam.height, cam.width, 3)], stats=fstats)
+                    vgraph.capture(cam.viewmat, cam.projmat, cam.campos, (target,))
                     vkey = key
                 else:
                     # the count of the previous replay is in pinned memory by now
                     if not vgraph.fits():
                         overflow_views += 1
                         caps.capacity = ((int(1.5 * int(vgraph.count_host[0])) + (1 << 20)) >> 20) << 20
-                loss, out = vgraph.replay(cam.viewmat, cam.projmat, cam.campos, (gt[v],))
-                if world > 1:
+                loss, out = vgraph.replay(cam.viewmat, cam.projmat, cam.campos, (target,))
+                if dp:
                     exchange.start_all()
             else:
                 zero_grads()
@@ -525,9 +617,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                                                     (g_["features_dc"], g_["features_rest"]), g_["means"], cam.campos,
                                                     cfg.sh_degree, deg) if sh_views else None
                 out = render_gaussians(g_["means"], g_["scales"], g_["quats"], g_["opacities"], g_["features_dc"],
-                                       g_["features_rest"], cam.viewmat, cam.projmat, cam.campos, bg, spec, used,
+                                       g_["features_rest"], cam.viewmat, cam.projmat, cam.campos, bg_step, spec, used,
                                        count_out=slot, stats=fstats, sh_collector=collector)
-                loss = loss_fn(out["rgb"], gt[v])
+                loss = loss_fn(out["rgb"], target)
                 loss.backward()
                 caps.submitted(slot, used, device)
                 if caps.overflowed():
@@ -537,12 +629,12 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             ph = _phase_marks(5) if (cfg.phase_every and step % cfg.phase_every == 0 and device.type == "cuda") else None
             if ph:
                 ph[0].record()
-            out = model.render(cams[v], bg, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp,
-                               sh_exchange=exchange if sh_views else None)
+            out = model.render(cam, bg_step, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp,
+                               sh_exchange=exchange if sh_views else None, caller_syncs=cfg.caller_syncs)
             rgb = out["rgb"]
             if ph:
                 ph[1].record()
-            loss = loss_fn(rgb, gt[v])
+            loss = loss_fn(rgb, target)
             if ph:
                 ph[2].record()
             loss.backward()
@@ -572,7 +664,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             first_vis = (out["radii"] > 0).to(torch.int32)
         first_pending = False
         stats_first = False
-        if world > 1 and sharded is None:
+        if dp and sharded is None:
             b = exchange.finish()
             if not exchanged_bytes or exchanged_bytes[-1][1] != b:
                 exchanged_bytes.append((step, b))
@@ -591,7 +683,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                 exchanged_bytes.append((step, b))
         if ph:
             ph[4].record()
-            phase_marks.append(ph)
+            phase_marks.append((d, ph))
         # refinement_after: every refine_every iterations, after the optimizer step
         # (TrainingCallback(update_every_num_iters=refine_every), vanilla_gs.py:610-616)
         if cfg.densify and step % rcfg.refine_every == 0 and step > rcfg.warmup_length:
@@ -599,8 +691,9 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             if branch != "none" or reset:
                 if use_fused:
                     xys_grad_norm, vis_counts, max_2dsize = fstats.as_tuple()
-                if world > 1 and branch == "densify":
-                    allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize, first_visible=first_vis)
+                if dp and branch == "densify":
+                    allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize, first_visible=first_vis,
+                                            force=cfg.force_exchange)
                 old = {k: model.gauss[k] for k in PARAM_NAMES}
                 moments = {}
                 for o in optims.values():
@@ -641,18 +734,26 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             save_checkpoint(cfg.checkpoint_dir, step, model, optims, sharded=sharded, write=rank == 0)
         if cfg.log_every and step % cfg.log_every == 0:
             losses.append(float(loss.detach()))
-    if world > 1:
+    if dp:
         dist.barrier()
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     psnr1 = evaluate()
-    phases = None
+    phases = phases_by_res = None
     if phase_marks:
         names = ("render", "loss", "backward", "stats_exchange_optimizer")
-        ms = np.array([[m[i].elapsed_time(m[i + 1]) for i in range(4)] for m in phase_marks])
-        phases = {k: round(float(np.median(ms[:, i])), 4) for i, k in enumerate(names)}
-        phases["samples"] = len(phase_marks)
+
+        def med(marks):
+            ms = np.array([[m[i].elapsed_time(m[i + 1]) for i in range(4)] for m in marks])
+            out = {k: round(float(np.median(ms[:, i])), 4) for i, k in enumerate(names)}
+            out["samples"] = len(marks)
+            return out
+
+        phases = med([m for _, m in phase_marks])
+        if len(factors) > 1:  # the coarse-to-fine schedule: one set of medians per resolution
+            phases_by_res = {f"{cfg.width // d_}x{cfg.height // d_}": med([m for dd, m in phase_marks if dd == d_])
+                             for d_ in sorted({dd for dd, _ in phase_marks}, reverse=True)}
     checksum = float(sum(p.detach().double().sum() for p in model.param_list()))
     return {"iters": cfg.iters - start_step, "start_step": start_step, "seconds": elapsed,
             "iters_per_s": (cfg.iters - start_step) / elapsed, "psnr_start": psnr0,
@@ -662,7 +763,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             # (step, bytes) whenever the per-step exchange volume changed: SH warm-up, refinement
             "allreduce_bytes": exchanged_bytes,
             "render": ("hip graph per view" if cfg.use_graph else "one fused op") if use_fused else "separate ops",
-            "list_overflow_views": overflow_views, "phase_ms_median": phases,
+            "list_overflow_views": overflow_views + (_list_rebuilds() - rebuilds0), "phase_ms_median": phases,
+            "phase_ms_median_by_resolution": phases_by_res,
+            "schedule": {"num_downscales": cfg.num_downscales, "resolution_schedule": cfg.resolution_schedule,
+                         "background_color": cfg.background_color, "caller_syncs": cfg.caller_syncs},
             "update": "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
             ("all-reduce (geometry) + all-gathered colour cotangents (SH) + Adam" if sh_views else "all-reduce + Adam"),
             "init": cfg.init,
@@ -671,6 +775,15 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
 
 def _phase_marks(n):
     return [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+
+
+def _list_rebuilds() -> int:
+    """Views whose device-sized tile lists came out too small and were built again (rasterizer.rasterize counts
+    them; 0 where that module's native library is not loaded: CPU stand-ins)."""
+    import sys
+
+    mod = sys.modules.get("rasterizer.rasterize")
+    return int(mod.counters["list_rebuilds"]) if mod is not None and hasattr(mod, "counters") else 0
 
 
 # the refinement backend (module-level so that CPU tests can substitute stand-ins)

@@ -543,6 +543,105 @@ def _deep_knobs():
     return _deep_cache["v"]
 
 
+class _RasterDesc(C.Structure):  # gsr_raster_desc (include/gsraster.h)
+    _fields_ = ([(k, C.c_int) for k in ("num_points", "img_height", "img_width", "capacity", "deep_tile_threshold")]
+                + [("extra_background", C.c_float)]
+                + [(k, C.c_void_p) for k in ("xys", "depths", "radii", "conics", "colors", "extra", "opac", "background",
+                                             "order_ready", "reach_records", "counts", "order", "cum", "ids",
+                                             "tile_bins", "count_out", "sort_ws")]
+                + [("sort_ws_bytes", C.c_size_t), ("bin_ws", C.c_void_p), ("bin_ws_bytes", C.c_size_t)]
+                + [(k, C.c_void_p) for k in ("out_img", "out_extra", "final_Ts", "final_idx", "out_alpha", "zero_ptr")]
+                + [("zero_bytes", C.c_size_t)])
+
+
+_raster_plan_cache = {}
+
+
+def _raster_plan(n: int, capacity: int, tb, have_order: bool):
+    """Byte offsets of the scratch regions of one `rasterize_gaussians_forward` call inside ONE allocation
+    (records | order | counts | cum | sort workspace | partition workspace, each 256-byte aligned)."""
+    key = (n, capacity, tb[0], tb[1], have_order)
+    plan = _raster_plan_cache.get(key)
+    if plan is None:
+        lib = _lib()
+        lean = not lists_need_counts(n, capacity, tb, device_sized=True)
+        al = lambda b: (int(b) + 255) & ~255
+        rec_b = al(n * int(lib.gsr_reach_record_bytes()))
+        sort_b = 0 if (have_order and lean) else int(lib.gsr_depth_order_workspace_bytes(C.c_int(n), C.c_int(1)))
+        bin_b = int(lib.gsr_bin_sorted_workspace_bytes(C.c_int(n), C.c_int(capacity), C.c_int(tb[0]), C.c_int(tb[1])))
+        off, o = {}, 0
+        for name, size in (("records", rec_b), ("order", 0 if (have_order and lean) else al(4 * n)),
+                           ("counts", 0 if lean else al(4 * n)), ("cum", 0 if lean else al(4 * n)),
+                           ("sort_ws", al(sort_b)), ("bin_ws", al(bin_b))):
+            off[name] = (o, size)
+            o += size
+        plan = (lean, off, max(o, 256), sort_b, bin_b)
+        if len(_raster_plan_cache) > 64:
+            _raster_plan_cache.clear()
+        _raster_plan_cache[key] = plan
+    return plan
+
+
+def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, background, img_height: int,
+                                img_width: int, capacity: int, count_out: Tensor, want_alpha: bool = False, zero=None,
+                                order_ready: Optional[Tensor] = None, extra: Optional[Tensor] = None,
+                                extra_background: float = 0.0, composite: bool = True, checked: bool = False):
+    """``gsr_rasterize_gaussians_forward``: reach records + depth order + device-sized tile lists + compositing of
+    16x16 tiles / 3 channels in ONE native call (what ``_RasterizeGaussians.forward`` runs on the device,
+    rasterize.py:89-170 of the reference) -> (gaussian_ids_sorted i32[capacity], tile_bins i32[T,2], out_img,
+    final_Ts, final_idx, alpha or None[, out_extra]).  ``count_out`` (int32[1], pinned or device) receives the number
+    of list entries the view needs: above ``capacity`` the lists were cut and the caller builds them again.
+    ``order_ready``: the depth order of these depths / radii if the caller already has it (the sort is skipped).
+    ``composite=False``: the lists only -> (gaussian_ids_sorted, tile_bins); ``colors`` / ``background`` unused."""
+    n = xys.size(0)
+    dev = xys.device
+    for t, dt, width in () if checked else ((xys, _f32, 2), (depths, _f32, 1), (radii, _i32, 1), (conics, _f32, 3), (opacities, _f32, 1)) + (
+            ((colors, _f32, 3), (background, _f32, None)) if composite else ()):
+        if t.dtype != dt or t.device != dev or not t.is_contiguous() or (width is not None and t.numel() != n * width):
+            raise RuntimeError("rasterize_gaussians_forward: float32 / int32 contiguous tensors of one device with N rows "
+                               "expected (xys [N,2], depths [N], radii [N], conics [N,3], colors [N,3], opacities [N,1])")
+    if (composite and background.numel() != 3) or n < 1 or capacity < 1:
+        raise RuntimeError("rasterize_gaussians_forward: background [3], N >= 1 and capacity >= 1 expected")
+    tb = ((img_width + 15) // 16, (img_height + 15) // 16, 1)
+    if order_ready is not None and lists_need_counts(n, capacity, tb, device_sized=True):
+        order_ready = None  # lists with counts sort the counts along: the ready-made order is of no use
+    lean, off, total, sort_b, bin_b = _raster_plan(n, capacity, tb, order_ready is not None)
+    H, W = int(img_height), int(img_width)
+    with torch.cuda.device(dev):
+        ws = torch.empty((total,), dtype=torch.uint8, device=dev)
+        ids = torch.empty((capacity,), dtype=_i32, device=dev)
+        bins = torch.empty((tb[0] * tb[1], 2), dtype=_i32, device=dev)
+        img = Ts = idx = alpha = out_extra = None
+        if composite:
+            img = torch.empty((H, W, 3), dtype=_f32, device=dev)
+            # final_Ts | final_idx | alpha [| extra]: one allocation, three (four) [H,W] planes
+            planes = torch.empty((2 + int(want_alpha) + int(extra is not None), H, W), dtype=_f32, device=dev)
+            Ts, idx = planes[0], planes[1].view(_i32)
+            alpha = planes[2] if want_alpha else None
+            out_extra = planes[2 + int(want_alpha)] if extra is not None else None
+        base = ws.data_ptr()
+        at = lambda name: (base + off[name][0]) if off[name][1] else None
+        p = lambda t: None if t is None else t.data_ptr()
+        zero_bytes = 0
+        if zero is not None:
+            zero_bytes = zero.numel() * 4
+            if zero_bytes == 0:
+                zero = None
+        desc = _RasterDesc(n, H, W, int(capacity), deep_tile_threshold(capacity, tb[0] * tb[1]), float(extra_background),
+                           xys.data_ptr(), depths.data_ptr(), radii.data_ptr(), conics.data_ptr(),
+                           p(colors) if composite else None, p(extra), opacities.data_ptr(),
+                           p(background) if composite else None, p(order_ready), at("records"),
+                           at("counts"), at("order"), at("cum"), ids.data_ptr(), bins.data_ptr(), count_out.data_ptr(),
+                           at("sort_ws"), sort_b, at("bin_ws"), bin_b, p(img), p(out_extra), p(Ts),
+                           p(idx), p(alpha), p(zero), zero_bytes)
+        _call("gsr_rasterize_gaussians_forward", C.byref(desc), _stream(dev))
+    if not composite:
+        return ids, bins
+    if extra is not None:
+        return ids, bins, img, Ts, idx, alpha, out_extra
+    return ids, bins, img, Ts, idx, alpha
+
+
 def rasterize_forward_ex(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
                          colors, opacities, background, want_alpha=False, zero=None):
     """``gsr_rasterize_forward_ex`` (16x16 tiles, 3 channels): -> (out_img, final_Ts, final_idx, alpha or None);

@@ -62,6 +62,7 @@ SYMBOLS = (
     "gsr_rasterize_forward_round",
     "gsr_rasterize_backward_two",
     "gsr_view_forward",
+    "gsr_rasterize_gaussians_forward",
     "gsr_view_backward",
     "gsr_rasterize_backward_rgbd",
     "gsr_activate_forward",

@@ -12,6 +12,13 @@ from torch.autograd import Function
 
 import rasterizer.cuda as _C
 
+
+def _ahead(*args):
+    from rasterizer.rasterize import speculate_lists  # (imported late: rasterize imports this package's siblings)
+
+    speculate_lists(*args)
+
+
 _Out = Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]
 
 
@@ -29,6 +36,9 @@ class _ProjectGaussians(Function):
         # the native tuple starts with cov3d, the public one ends with it
         cov3d, xys, depths, radii, conics, compensation, num_tiles_hit = _C.project_gaussians_forward(
             n, means3d, scales, glob_scale, quats, *camera, block_width, clip_thresh)
+        # everything this view's tile lists depend on exists now: start building them on the side stream, next to
+        # whatever the caller does before it calls rasterize_gaussians (rasterize.py, "lists built ahead of time")
+        _ahead(xys, depths, radii, conics, num_tiles_hit, img_height, img_width, block_width)
         ctx.static = (n, glob_scale) + camera[2:]
         # Outputs nobody differentiates through (depths, compensation, cov3d in an RGB
         # pass) reach backward() as None rather than as N-sized zero tensors; the

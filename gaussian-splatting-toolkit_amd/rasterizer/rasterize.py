@@ -18,6 +18,7 @@ the same memory), and an in-place update bumps the version and misses.
 import os
 import threading
 import time
+import weakref
 from typing import Optional
 
 import torch
@@ -32,8 +33,18 @@ import rasterizer.cuda as _C
 # a forward needs later (the deterministic backward's `aux`) travels with the call, in
 # thread-local storage, never through this dictionary.
 _bin_cache = {"key": None, "value": None, "keepalive": None, "reach": None}
-_state_lock = threading.Lock()  # guards the list cache and the sizing dictionaries below
+# guards the list cache, the sizing dictionaries below (`_count_hint`, `_last_capacity`, `_two_hint`) and the pinned
+# slot pool; re-entrant: a hint update may hand a slot back to the pool
+_state_lock = threading.RLock()
 _tls = threading.local()
+# views whose device-sized lists came out too small and were built again (harness.train reports the delta per run)
+# list constructions by kind (tests and harness.train read these; never reset by the package):
+#   list_builds_exact / _device_sized   lists built inside rasterize_gaussians, sized by a read-back / by the previous view
+#   list_builds_ahead                   lists built ahead of time on the side stream (`speculate_lists`)
+#   ahead_hits / ahead_misses           ... and whether the rasterize call that followed could use them
+#   ahead_orders_used                   only the depth order of the side stream was used
+counters = {"list_rebuilds": 0, "list_builds_exact": 0, "list_builds_device_sized": 0, "list_builds_ahead": 0,
+            "ahead_hits": 0, "ahead_misses": 0, "ahead_orders_used": 0}
 
 
 def _cache_snapshot():
@@ -86,10 +97,16 @@ def _speculation_enabled() -> bool:
 
 
 def _note_count(device, num_points, tile_bounds, num_intersects):
-    _count_hint[(device, tile_bounds)] = (num_points, num_intersects)
+    with _state_lock:
+        _count_hint[(device, tile_bounds)] = (num_points, num_intersects)
 
 
 def _speculative_capacity(device, num_points, tile_bounds, exact):
+    with _state_lock:
+        return _speculative_capacity_locked(device, num_points, tile_bounds, exact)
+
+
+def _speculative_capacity_locked(device, num_points, tile_bounds, exact):
     hint = _count_hint.get((device, tile_bounds))
     # the device-sized lists need the single-pass tile scatter: any grid with the exact
     # lists' per-band counts (block_width 16), up to 16384 tiles otherwise
@@ -138,12 +155,33 @@ def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
         return None
     if os.environ.get("GSR_TILE_SORT", "")[:1] in ("s", "b"):
         return None
+    with _state_lock:
+        plan = _two_round_plan_locked(device, num_points, tile_bounds, mode)
+    if plan == "count_culled":
+        # The prefix has to start behind the culled Gaussians (they sit at the FRONT of the depth order, key 0): their
+        # number travels to the host through a pinned slot, like the list counts -- no blocking read-back.  The view
+        # that asks (the first two-round candidate, and every 32nd after it) takes one round; the answer is there
+        # for the next one.
+        if radii is not None:
+            culled = (radii <= 0).sum(dtype=torch.int32).reshape(1)
+            pend = _PendingCount(device)
+            _C.publish_int32(culled, pend.buf)
+            pend.mark()
+            with _state_lock:
+                _two_hint.setdefault((device, tile_bounds), {})["culled_pending"] = (pend, num_points)
+        with _state_lock:
+            th = _two_hint.setdefault((device, tile_bounds), {})
+            plan = _two_round_plan_locked(device, num_points, tile_bounds, mode, asked=True) if "culled_frac" in th else None
+    return plan
+
+
+def _two_round_plan_locked(device, num_points, tile_bounds, mode, asked=False):
     hint = _count_hint.get((device, tile_bounds))
     if hint is None or hint[0] < 1 or hint[1] < 1:
         return None
     key = (device, tile_bounds)
     th = _two_hint.setdefault(key, {})
-    if th.get("cooldown", 0) > 0:  # the filter dropped too little last time: single rounds for a while
+    if not asked and th.get("cooldown", 0) > 0:  # the filter dropped too little last time: single rounds for a while
         th["cooldown"] -= 1
         return None
     n_last, count_last = hint
@@ -162,13 +200,18 @@ def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
         # the nearest Gaussians are the largest on screen: they hold ~3x their share of the entries
         f = target * tiles / full / 3.0
     f = min(0.5, max(0.02, f))
-    th["views"] = th.get("views", 0) + 1
-    if "culled_frac" not in th or th["views"] % 32 == 0:
-        # culled Gaussians sit at the FRONT of the depth order (key 0): the prefix has to start behind them.  Known
-        # read back on the first two-round view and every 32nd after it (one sync)
-        if radii is None:
-            return None
-        th["culled_frac"] = float((radii <= 0).sum().item()) / max(num_points, 1)
+    pend = th.get("culled_pending")
+    if pend is not None:
+        val = pend[0].peek()
+        if val is not None:
+            th["culled_frac"] = float(val) / max(pend[1], 1)
+            th["culled_pending"] = None
+    if not asked:
+        th["views"] = th.get("views", 0) + 1
+        if th.get("culled_pending") is None and ("culled_frac" not in th or th["views"] % 32 == 0):
+            return "count_culled"
+    if "culled_frac" not in th:
+        return None
     culled = int(th["culled_frac"] * num_points)
     n1 = culled + int(f * (num_points - culled))
     n1 = min(max(256, (n1 + 255) & ~255), num_points)
@@ -194,15 +237,20 @@ def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
 
 
 def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, plan, remember,
-                     round1):
+                     round1, order_ready=None):
     """-> (None, ids, bins1, finish); `round1(ids, bins1, tile_flags)` composites the prefix lists (raw state)."""
     dev = xys.device
     n, n1, cap1, cap2 = xys.size(0), plan["n1"], plan["cap1"], plan["cap2"]
-    records, order = _records_and_order(xys, radii, conics, opacity, depths, tile_bounds, extra_rows=1)
+    if order_ready is not None:  # the depth order was built ahead of time on the side stream
+        (_, records), order = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False, extra_rows=1), order_ready
+        counters["ahead_orders_used"] += 1
+    else:
+        records, order = _records_and_order(xys, radii, conics, opacity, depths, tile_bounds, extra_rows=1)
     with torch.cuda.device(dev):
         ids = torch.empty((cap1 + cap2,), dtype=torch.int32, device=dev)
         flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=dev)
     p1, p2, p4 = (_PendingCount(dev) for _ in range(3))
+    counters["list_builds_device_sized"] += 1
     bins1 = _C.tile_lists_subrange(order[:n1], cap1, records, tile_bounds, ids[:cap1], p1.buf)
     round1(ids, bins1, flags)
     with torch.cuda.device(dev):
@@ -217,28 +265,12 @@ def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bo
 
     def finish():
         c1, c2, unfinished = p1.resolve(), p2.resolve(), p4.resolve()
-        th = _two_hint.setdefault(plan["key"], {})
-        th.update(count1=c1, count2=c2, f_used=plan["f"], unfinished=unfinished)
-        # The filter works per Gaussian: one unfinished tile keeps every Gaussian whose box holds it, so a few per
-        # cent of unfinished tiles keep most of a scene of large splats.  Lengthen the prefix until (almost) no tile
-        # is left; otherwise steer it towards `target` entries per tile in round 1.
-        if unfinished > 0.3 * plan["tiles"]:
-            # nothing saturates here (background shows through, or the count hint came from another scene): with
-            # most tiles unfinished hardly anything was filtered, so c1 + c2 IS the full count -- single rounds for
-            # a while, sized from it
-            th["fails"] = min(th.get("fails", 0) + 1, 7)
-            th["cooldown"] = 25 << th["fails"]  # 50, 100, ... 3200 views between attempts while they keep failing
-            th.pop("f", None)
-            _note_count(xys.device, n, tile_bounds, c1 + c2)
-        elif unfinished > 0.003 * plan["tiles"]:
-            th["f"] = min(0.5, 1.5 * plan["f"])
-            if plan["f"] >= 0.5 and c2 > 0.5 * max(plan["full"] - c1, 1.0):
-                th["cooldown"] = 50  # the scene does not saturate behind any prefix: single rounds for a while
-        else:
-            th["fails"] = 0
-            th["f"] = max(0.02, plan["f"] * min(1.25, max(0.8, plan["target"] * plan["tiles"] / max(c1, 1))))
+        with _state_lock:
+            note = _two_round_feedback(plan, c1, c2, unfinished)
+        if note is not None:
+            _note_count(xys.device, n, tile_bounds, note)
         if c1 > cap1 or c2 > cap2:  # a guess was too small: this view falls back to one exact round
-            th.pop("count1", None), th.pop("count2", None)
+            counters["list_rebuilds"] += 1
             nn, i2, b2, _ = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width,
                                          True, remember, speculate=False, round1=None)
             return nn, i2, b2, True
@@ -248,51 +280,249 @@ def _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bo
     return None, ids, bins1, finish
 
 
+def _two_round_feedback(plan, c1, c2, unfinished):
+    """(under `_state_lock`) steer the next view's prefix from this view's counts -> a full count to note, or None"""
+    note = None
+    th = _two_hint.setdefault(plan["key"], {})
+    th.update(count1=c1, count2=c2, f_used=plan["f"], unfinished=unfinished)
+    # The filter works per Gaussian: one unfinished tile keeps every Gaussian whose box holds it, so a few per
+    # cent of unfinished tiles keep most of a scene of large splats.  Lengthen the prefix until (almost) no tile
+    # is left; otherwise steer it towards `target` entries per tile in round 1.
+    if unfinished > 0.3 * plan["tiles"]:
+        # nothing saturates here (background shows through, or the count hint came from another scene): with
+        # most tiles unfinished hardly anything was filtered, so c1 + c2 IS the full count -- single rounds for
+        # a while, sized from it
+        th["fails"] = min(th.get("fails", 0) + 1, 7)
+        th["cooldown"] = 25 << th["fails"]  # 50, 100, ... 3200 views between attempts while they keep failing
+        th.pop("f", None)
+        note = c1 + c2
+    elif unfinished > 0.003 * plan["tiles"]:
+        th["f"] = min(0.5, 1.5 * plan["f"])
+        if plan["f"] >= 0.5 and c2 > 0.5 * max(plan["full"] - c1, 1.0):
+            th["cooldown"] = 50  # the scene does not saturate behind any prefix: single rounds for a while
+    else:
+        th["fails"] = 0
+        th["f"] = max(0.02, plan["f"] * min(1.25, max(0.8, plan["target"] * plan["tiles"] / max(c1, 1))))
+    if c1 > plan["cap1"] or c2 > plan["cap2"]:
+        th.pop("count1", None), th.pop("count2", None)
+    return note
+
+
 class _PendingCount:
-    """The real number of list entries on its way to the host: a kernel of
-    `gsr_bin_sorted_dev` writes it straight into pinned (device-mapped) host memory
-    -- no copy operation in the stream -- and `resolve` waits for the event recorded
-    behind that call."""
+    """One int32 on its way from a kernel to the host: the kernel (`gsr_bin_sorted_dev`'s count, `gsr_publish_int32`)
+    writes it straight into pinned (device-mapped) host memory -- no copy operation in the stream -- and `resolve`
+    reads it there.
 
-    SLOTS = 16  # pinned slots per device, handed out round-robin: a count in flight keeps
-    # its own slot, so forwards interleaved on one device (side streams, an eval thread)
-    # cannot overwrite each other's published count
+    Slots come from a per-device free list and go back to it only once no kernel can still write them: when
+    `resolve` / `peek` has SEEN the value (each slot has exactly one writer, which writes once), or, for a slot
+    dropped unread (an exception between the launch and `finish()`), when the event recorded behind the launch has
+    fired -- otherwise the slot is retired for good.  A new owner can therefore never read a previous owner's late
+    write as its own count (interleaved forwards of several threads / streams on one device included)."""
 
+    CHUNK = 64            # pinned int32 slots allocated at a time
     PENDING = -2147483647  # what a slot holds until the kernel has written it (no count is ever that)
+    POLL_S = 2e-3         # `resolve` polls this long before it blocks on the event (INTEGRATION.md, "threads")
 
     def __init__(self, device):
         with _state_lock:
-            ring = _pinned_count.get(device)
-            if ring is None:
-                pinned = torch.empty(self.SLOTS, dtype=torch.int32, pin_memory=True)
-                ring = _pinned_count[device] = [pinned, 0, pinned.numpy()]  # the same memory, cheap to poll
-            slot = ring[1]
-            ring[1] = (slot + 1) % self.SLOTS
-        self.buf = ring[0][slot:slot + 1]
-        self._np = ring[2][slot:slot + 1]
+            pool = _pinned_count.get(device)
+            if pool is None:
+                pool = _pinned_count[device] = []
+            if not pool:
+                pinned = torch.empty(self.CHUNK, dtype=torch.int32, pin_memory=True)
+                view = pinned.numpy()  # the same memory, cheap to poll
+                pool.extend((pinned[k:k + 1], view[k:k + 1]) for k in range(self.CHUNK))
+            self._slot = pool.pop()
+        self.buf, self._np = self._slot
         self._np[0] = self.PENDING
         self.device = device
         self.event = None
+        self._value = None
 
     def mark(self):
         self.event = torch.cuda.Event()
         self.event.record(torch.cuda.current_stream(self.device))
 
+    def _release(self):
+        slot, self._slot = self._slot, None
+        if slot is not None:
+            with _state_lock:
+                _pinned_count[self.device].append(slot)
+
+    def __del__(self):
+        try:  # dropped unread: reusable only if its writer is known to have run
+            if self._slot is not None and self.event is not None and self.event.query():
+                self._release()
+        except Exception:
+            pass
+
+    def peek(self) -> Optional[int]:
+        """The value if it has arrived (the slot is then released), else None; never blocks."""
+        if self._slot is None:
+            return self._value
+        v = int(self._np[0])
+        if v == self.PENDING:
+            return None
+        self._value = v
+        self._release()
+        return v
+
     def resolve(self) -> int:
         # The value lands in host memory the moment the publishing kernel writes it -- earlier than the event
-        # behind the whole call fires, and without the wake-up latency of a blocking wait: poll it (the host has
-        # nothing else to do here, and every microsecond it wakes up earlier is GPU work queued earlier).  A value
-        # that does not arrive within 2 ms is waited for the ordinary way.
+        # behind the whole call fires, and without the wake-up latency of a blocking wait: poll it (every
+        # microsecond the host wakes up earlier is GPU work queued earlier).  `time.sleep(0)` between two looks
+        # releases the GIL, so other Python threads (the toolkit's viewer thread waiting on `train_lock`) run while
+        # this one waits.  A value that does not arrive within POLL_S is waited for the ordinary way.
         t0 = time.perf_counter()
-        while self._np[0] == self.PENDING:
-            if time.perf_counter() - t0 > 2e-3:
-                self.event.synchronize()
+        count = self.peek()
+        while count is None:
+            if time.perf_counter() - t0 > self.POLL_S:
+                if self.event is not None:
+                    self.event.synchronize()
+                count = self.peek()
+                if count is None:
+                    raise RuntimeError("rasterize_gaussians: the list count was never published (the launch that "
+                                       "writes it did not run; an earlier asynchronous HIP error?)")
                 break
-        count = int(self._np[0])
+            time.sleep(0)
+            count = self.peek()
         if count < 0:  # the int32 count wrapped (more than 2^31 - 1 intersections)
             raise RuntimeError("rasterize_gaussians: the number of (Gaussian, tile) intersections does not fit the "
                                "int32 lists (the reference's cum_tiles_hit is int32 as well)")
         return count
+
+
+# ---- lists built ahead of time, while the caller is busy elsewhere ---------------------------------------------
+# The unchanged models block the host twice between `project_gaussians` and `rasterize_gaussians`
+# (`if (self.radii).sum() == 0`, vanilla_gs.py:784; `assert (num_tiles_hit > 0).any()`, :811): each read-back
+# drains the stream and leaves the GPU idle until the host has woken up and queued the next kernels -- 165 us of a
+# 1.0-ms step at 1 M Gaussians (profiles/r04_*).  Everything the tile lists depend on exists as soon as the projection has
+# run: xys / depths / radii / conics, the image size, and the opacities -- which the models form as
+# `torch.sigmoid(self.opacities)` AFTER the second read-back, but whose recipe (a pure unary op on a leaf) is known from
+# the previous view.  So `project_gaussians` ends by queueing this view's list construction on a SIDE stream, where
+# it runs through both read-backs and next to the SH evaluation; `rasterize_gaussians` then finds its lists ready
+# (checked by provenance, the same rule the list cache uses: same storage at the same version, or the same pure op
+# on the same leaf at the same version -- never by hoping) and goes straight to compositing.  Where the opacities
+# cannot be predicted (another recipe, no previous view) only the depth order is built ahead.
+# GSR_SPECULATE=0 switches this off, =sort limits it to the depth order.
+_spec = {}
+_UNARY_FN = {"SigmoidBackward0": torch.sigmoid, "ExpBackward0": torch.exp, "TanhBackward0": torch.tanh,
+             "AbsBackward0": torch.abs, "NegBackward0": torch.neg}
+_spec_knobs = {}
+
+
+def _speculation_mode() -> str:
+    if not _spec_knobs:
+        _spec_knobs["mode"] = {"0": "0", "off": "0", "sort": "sort"}.get(os.environ.get("GSR_SPECULATE", "lists"), "lists")
+        _spec_knobs["min_points"] = int(os.environ.get("GSR_SPECULATE_MIN", "65536"))
+    return _spec_knobs["mode"]
+
+
+def _note_opacity_recipe(device, opacity) -> None:
+    """Remember how the caller formed `opacity` -- for the NEXT view's lists (see above)."""
+    fn = opacity.grad_fn
+    recipe = None
+    if fn is None:
+        recipe = ("same", weakref.ref(opacity))  # a leaf / constant handed in as it is
+    elif _producer_signature(opacity) is not None:
+        recipe = ("unary", type(fn).__name__, weakref.ref(fn.next_functions[0][0].variable), tuple(opacity.shape))
+    with _state_lock:
+        st = _spec.get(device)
+        if st is not None:
+            st["recipe"] = recipe
+        else:
+            _spec[device] = {"stream": None, "recipe": recipe, "entry": None}
+
+
+def announce_opacity(opacity) -> None:
+    """Tell the rasterizer which tensor the next `rasterize_gaussians` on this device will receive as `opacity`, when
+    it already exists before `project_gaussians` runs but autograd provenance cannot show it (the output of a custom
+    op: `gs_fused.activate_gaussians` calls this).  The lists built ahead of time are then built for it; a rasterize
+    call that receives another tensor (or this one at another version) drops them, as always."""
+    if opacity.is_cuda:
+        with _state_lock:
+            st = _spec.setdefault(opacity.device, {"stream": None, "recipe": None, "entry": None})
+            st["recipe"] = ("same", weakref.ref(opacity))
+
+
+def speculate_lists(xys, depths, radii, conics, num_tiles_hit, img_height, img_width, block_width) -> None:
+    """(called by `project_gaussians` once the projection is queued) start this view's depth order -- and, where the
+    opacities are predictable, its tile lists -- on the side stream."""
+    mode = _speculation_mode()
+    n = xys.size(0)
+    if mode == "0" or block_width != 16 or not xys.is_cuda or n < _spec_knobs["min_points"] or _deterministic["on"] \
+            or not _speculation_enabled() or os.environ.get("GSR_TILE_SORT", "")[:1] == "b":
+        return
+    dev = xys.device
+    if torch.cuda.is_current_stream_capturing():
+        return
+    tile_bounds = ((img_width + 15) // 16, (img_height + 15) // 16, 1)
+    with _state_lock:
+        st = _spec.setdefault(dev, {"stream": None, "recipe": None, "entry": None})
+        recipe = st["recipe"]
+        th = _two_hint.get((dev, tile_bounds))
+        two_recent = th is not None and th.get("count1") is not None and th.get("cooldown", 0) == 0
+    if st["stream"] is None:
+        st["stream"] = torch.cuda.Stream(dev)
+    side, main = st["stream"], torch.cuda.current_stream(dev)
+    opacity_src = osig = None
+    capacity = None
+    if mode == "lists" and recipe is not None and not two_recent:
+        if recipe[0] == "same":
+            t = recipe[1]()
+            if t is not None and t.is_cuda and t.numel() == n and t.dtype == torch.float32 and t.is_contiguous():
+                opacity_src = ("same", t)
+        else:
+            leaf = recipe[2]()
+            if leaf is not None and leaf.is_cuda and leaf.numel() == n and leaf.dtype == torch.float32:
+                opacity_src = ("unary", leaf, recipe[1], recipe[3])
+                osig = (recipe[1], id(leaf), leaf._version, leaf.data_ptr(), tuple(leaf.shape))
+        if opacity_src is not None:
+            capacity = _speculative_capacity(dev, n, tile_bounds, True)
+    key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
+    entry = {"key": key, "keep": (xys, depths, radii, num_tiles_hit, conics)}
+    side.wait_stream(main)  # behind the projection (and whatever the caller queued before it)
+    with torch.no_grad(), torch.cuda.stream(side):
+        if opacity_src is not None and capacity is not None:
+            if opacity_src[0] == "same":
+                opac = opacity_src[1].detach()
+                oversion = opacity_src[1]._version
+            else:
+                opac = _UNARY_FN[opacity_src[2]](opacity_src[1].detach()).reshape(opacity_src[3]).contiguous()
+                oversion = opac._version
+            pending = _PendingCount(dev)
+            ids, bins = _C.rasterize_gaussians_forward(xys, depths, radii, conics, None, opac.view(n, 1), None, img_height,
+                                                       img_width, capacity, pending.buf, composite=False, checked=True)
+            entry.update(ids=ids, bins=bins, pending=pending, capacity=capacity,
+                         reach=(conics.detach(), opac, conics._version, oversion, None, osig))
+            counters["list_builds_ahead"] += 1
+        else:
+            entry["order"], _ = _C.depth_order(depths, radii, None)
+        done = torch.cuda.Event()
+        done.record(side)
+    entry["done"] = done
+    if "pending" in entry:
+        entry["pending"].event = done
+    # The inputs were allocated on the caller's stream and are read on this one.  Instead of `record_stream` on each
+    # (five calls per view) the entry -- and `retired`, once it has been taken -- holds references to them until
+    # the NEXT view's call, and by then the caller's stream has waited for `done` (when the entry was taken, or
+    # below): memory handed back after that point cannot be reused ahead of the side stream's reads.
+    entry["keep"] += (opacity_src[1],) if opacity_src is not None else ()
+    with _state_lock:
+        old, st["entry"] = st["entry"], entry
+        st["retired"] = None
+    if old is not None:
+        main.wait_event(old["done"])  # an entry nobody took: whatever follows on the caller's stream stays behind it
+
+
+def _take_speculation(device, key):
+    with _state_lock:
+        st = _spec.get(device)
+        if st is None or st["entry"] is None or st["entry"]["key"] != key:
+            return None
+        entry, st["entry"] = st["entry"], None
+        st["retired"] = entry["keep"]
+    return entry
 
 
 # unary, parameter-free ops: the same op on the same leaf at the same version = the same values
@@ -385,8 +615,23 @@ def rasterize_gaussians(
     )
 
 
+def _is_two(aux) -> bool:
+    return isinstance(aux, tuple) and len(aux) == 3 and aux[0] == "two"
+
+
+class FusedForward:
+    """What `build_tile_lists` needs to run the compositing in the SAME native call as the list construction
+    (`gsr_rasterize_gaussians_forward`, 16x16 tiles / 3 channels): the colours, background and output wishes of
+    the caller; `outputs` = (out_img, final_Ts, final_idx, alpha) once that has happened."""
+
+    def __init__(self, colors, background, img_height, img_width, want_alpha, zero):
+        self.colors, self.background, self.want_alpha, self.zero = colors, background, want_alpha, zero
+        self.img_size = (img_width, img_height)
+        self.outputs = None
+
+
 def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width,
-                     round1=None):
+                     round1=None, fuse: Optional[FusedForward] = None):
     """The per-tile depth-sorted lists every compositing call walks.
 
     -> ``(num_intersects, gaussian_ids_sorted, tile_bins, finish)``.  Either the count is
@@ -401,7 +646,10 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     (``_C.rasterize_forward_round``).  On deep scenes the lists then come in two segments: ``bins`` is the
     first, ``last_list_aux()`` returns ``("two", bins2, idx_base)``, and ``round1`` has already been called
     on the first segment when this function returns -- the caller runs round 2 (and, for lists from the
-    cache, both rounds)."""
+    cache, both rounds).
+
+    ``fuse`` (optional, `FusedForward`): where the lists are device-sized single-round ones the compositing runs in
+    the same native call and ``fuse.outputs`` holds its results; the caller composites itself when it is None."""
     num_points = xys.size(0)
     _tls.aux = None  # (what the PREVIOUS call of this thread left: every path below sets its own)
     tile_bounds = ((img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width, 1)
@@ -422,7 +670,43 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
             _bin_cache.update(entry)
         _tls.aux = aux
 
+    order_ready = None
+    if exact:
+        _note_opacity_recipe(xys.device, opacity)
+        ahead = _take_speculation(xys.device, key)
+        if ahead is not None:
+            main = torch.cuda.current_stream(xys.device)
+            main.wait_event(ahead["done"])
+            if "ids" in ahead and not _deterministic["on"] and _same_reach_inputs(conics, opacity, ahead["reach"]) is True:
+                # this view's lists were built on the side stream while the caller was busy (or blocked)
+                counters["ahead_hits"] += 1
+                ids, bins, pending, capacity = ahead["ids"], ahead["bins"], ahead["pending"], ahead["capacity"]
+                ids.record_stream(main), bins.record_stream(main)
+
+                def finish_ahead():
+                    num_intersects = pending.resolve()
+                    _note_count(xys.device, num_points, tile_bounds, num_intersects)
+                    if num_intersects > capacity:  # the guess was too small: build the lists again, sized exactly
+                        counters["list_rebuilds"] += 1
+                        n, i2, b2, _ = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds,
+                                                    block_width, exact, remember, speculate=False)
+                        return n, i2, b2, True
+                    remember(num_intersects, ids, bins, None)
+                    return num_intersects, ids, bins, False
+
+                return None, ids, bins, finish_ahead
+            if "order" in ahead:
+                order_ready = ahead["order"]
+                order_ready.record_stream(main)
+            else:
+                counters["ahead_misses"] += 1  # other opacities than predicted: the lists are of no use
+
     snap = _cache_snapshot()
+    if snap["key"] == key and round1 is None and _is_two(snap["value"][3]):
+        # two-segment lists (a deep scene's RGB pass) cached, but THIS caller composites one segment only (N-D
+        # colours, another block width ...): walking `bins1` alone would silently drop everything behind the
+        # prefix -- build single-round lists
+        snap = {"key": None}
     if snap["key"] == key:
         same = _same_reach_inputs(conics, opacity, snap["reach"]) if exact else True
         cached = snap["value"]
@@ -451,17 +735,17 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
             _tls.aux = cached[3]
             return None, cached[1], cached[2], verify
     return _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember,
-                        round1=round1)
+                        round1=round1, fuse=fuse, order_ready=order_ready)
 
 
 def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, exact, remember,
-                 speculate=True, round1=None):
+                 speculate=True, round1=None, fuse=None, order_ready=None):
     num_points = xys.size(0)
     if round1 is not None and speculate:
         plan = _two_round_plan(xys.device, num_points, tile_bounds, exact, radii)
         if plan is not None:
             return _build_two_round(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds, block_width, plan,
-                                    remember, round1)
+                                    remember, round1, order_ready=order_ready)
     # fused binning: same `gaussian_ids_sorted` / `tile_bins` as
     # compute_cumulative_intersects + bin_and_sort_gaussians (bit for bit
     # when not `exact`: tests/test_gpu_kernels.py::
@@ -473,20 +757,55 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
     banded = exact and (det or os.environ.get("GSR_TILE_SORT", "")[:1] == "b")
     capacity = _speculative_capacity(xys.device, num_points, tile_bounds, exact) if speculate else None
 
+    if fuse is not None and exact and capacity is not None and not banded and not det and \
+            os.environ.get("GSR_ONE_CALL", "1") != "0":
+        # records + depth order + device-sized lists + compositing: ONE native call (with or without counts, as
+        # gsr_bin_sorted_needs_counts decides in there); the count comes back through the pinned slot
+        pending = _PendingCount(xys.device)
+        img_w, img_h = fuse.img_size
+        ids, bins, *outs = _C.rasterize_gaussians_forward(
+            xys, depths, radii, conics, fuse.colors, opacity, fuse.background, img_h, img_w, capacity, pending.buf,
+            want_alpha=fuse.want_alpha, zero=fuse.zero, order_ready=order_ready)
+        pending.mark()
+        fuse.outputs = tuple(outs)
+        counters["list_builds_device_sized"] += 1
+        if order_ready is not None:
+            counters["ahead_orders_used"] += 1
+
+        def finish_one():
+            num_intersects = pending.resolve()
+            _note_count(xys.device, num_points, tile_bounds, num_intersects)
+            if num_intersects > capacity:  # the guess was too small: build the lists again, sized exactly
+                counters["list_rebuilds"] += 1
+                fuse.outputs = None
+                n, i2, b2, _ = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds,
+                                            block_width, exact, remember, speculate=False)
+                return n, i2, b2, True
+            remember(num_intersects, ids, bins, None)
+            return num_intersects, ids, bins, False
+
+        return None, ids, bins, finish_one
+
     if exact and capacity is not None and not banded and \
             not _C.lists_need_counts(num_points, capacity, tile_bounds, device_sized=True, want_slots=det):
         # The two-level partition counts its entries itself: records only, the depth order only,
         # and the number of entries comes back through the pinned slot (`count_out`).
-        records, order = _records_and_order(xys, radii, conics, opacity, depths, tile_bounds)
+        if order_ready is not None:
+            (_, records), order = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False), order_ready
+            counters["ahead_orders_used"] += 1
+        else:
+            records, order = _records_and_order(xys, radii, conics, opacity, depths, tile_bounds)
         pending = _PendingCount(xys.device)
         ids, bins = _C.bin_sorted(num_points, capacity, order, None, xys, radii, tile_bounds, block_width, records,
                                   device_sized=True, count_out=pending.buf)
         pending.mark()
+        counters["list_builds_device_sized"] += 1
 
         def finish_lean():
             num_intersects = pending.resolve()
             _note_count(xys.device, num_points, tile_bounds, num_intersects)
             if num_intersects > capacity:  # the guess was too small: build the lists again, sized exactly
+                counters["list_rebuilds"] += 1
                 n, i2, b2, _ = _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds,
                                             block_width, exact, remember, speculate=False)
                 return n, i2, b2, True
@@ -520,6 +839,7 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
                                f"int32 lists (the reference's cum_tiles_hit is int32 as well)")
         _note_count(xys.device, num_points, tile_bounds, num_intersects)
         ids, bins = build(num_intersects) if num_intersects >= 1 else (None, None)
+        counters["list_builds_exact"] += 1
         remember(num_intersects, ids, bins, build.aux)
         return num_intersects, ids, bins, None
 
@@ -531,6 +851,7 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
     _C.publish_int32(cum_sorted[-1:], pending.buf)
     pending.mark()
     ids, bins = build(capacity, device_sized=True)
+    counters["list_builds_device_sized"] += 1
 
     def finish():
         nonlocal ids, bins
@@ -538,6 +859,8 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
         _note_count(xys.device, num_points, tile_bounds, num_intersects)
         rebuilt = num_intersects > capacity  # the guess was too small: build the lists again
         if rebuilt:
+            counters["list_rebuilds"] += 1
+            counters["list_builds_exact"] += 1
             ids, bins = build(num_intersects)
         remember(num_intersects, ids, bins, build.aux)
         return num_intersects, ids, bins, rebuilt
@@ -591,16 +914,18 @@ class _RasterizeGaussians(Function):
                                        out_alpha=alpha_out[0])
             return state[0], state[1], state[2]
 
-        def is_two(aux):
-            return isinstance(aux, tuple) and len(aux) == 3 and aux[0] == "two"
+        is_two = _is_two
 
+        fuse = FusedForward(colors, background, img_height, img_width, return_alpha, acc) if fused else None
         num_intersects, gaussian_ids_sorted, tile_bins, finish = build_tile_lists(
             xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width,
-            round1=round1 if fused else None)
+            round1=round1 if fused else None, fuse=fuse)
         two = is_two(last_list_aux()) and fused
         two_aux = last_list_aux() if two else None
         if finish is not None:
-            if two and state:      # round 1 ran inside build_tile_lists
+            if fuse is not None and fuse.outputs is not None:  # composited by the call that built the lists
+                out_img, final_Ts, final_idx, alpha_out[0] = fuse.outputs
+            elif two and state:      # round 1 ran inside build_tile_lists
                 out_img, final_Ts, final_idx = round2(gaussian_ids_sorted, two_aux)
             elif two:              # cached two-segment lists used speculatively
                 flags = torch.zeros((tile_bounds[0] * tile_bounds[1],), dtype=torch.int32, device=xys.device)

@@ -579,6 +579,46 @@ typedef struct gsr_view_grads {
 } gsr_view_grads;
 
 int gsr_view_forward(const gsr_view_desc *view, gsr_stream_t stream);
+
+/* ---- the forward of rasterize_gaussians as ONE call ------------------------------------------
+ * What `_RasterizeGaussians.forward` runs on the device (gs_toolkit/gs_components/rasterizer/rasterize.py:89-170:
+ * bin_and_sort_gaussians, utils.py:128-182, then rasterize_forward) for 16 x 16 tiles and 3 colour channels: reach
+ * records + depth order, device-sized tile lists, compositing (with alpha = 1 - T, the backward's cleared
+ * accumulators, and optionally one extra channel, as gsr_rasterize_forward_ex / _rgbd).  The same exported functions
+ * in the same order as the Python package would call them one by one; nothing is allocated in here.  The unchanged
+ * models read `(num_tiles_hit > 0).any()` back right in front of this op (vanilla_gs.py:811): the GPU idles from
+ * that read-back until the first launch below, so the host time in between is kept to one call.
+ *   counts / cum   both NULL: lists without counts (gsr_bin_sorted_needs_counts() == 0); else i32[n] each
+ *   order_ready    NULL, or the depth order already built for these depths / radii (gsr_depth_order(depths, radii,
+ *                  NULL...), e.g. on another stream while the caller was busy): the sort is skipped and only the
+ *                  records are written (needs counts == NULL); `order` / sort_ws may then be NULL
+ *   reach_records  [n x gsr_reach_record_bytes()], 16-byte aligned;  order i32[n]
+ *   sort_ws/bin_ws gsr_depth_order_workspace_bytes(n, 1) / gsr_bin_sorted_workspace_bytes(n, capacity, ..)
+ *   ids i32[capacity], tile_bins i32[T,2], count_out i32[1] (device or pinned): entries needed (> capacity: cut)
+ *   extra / out_extra  NULL, or [n] / [P]: one more channel composited with the same weights (the depths)
+ *   out_img == NULL    the lists only: no compositing (colors / background / final_* / out_alpha / zero_ptr unused);
+ *                      the caller composites later with gsr_rasterize_forward_ex -- how the Python package builds
+ *                      a view's lists on a side stream while the models wait for their read-backs */
+typedef struct gsr_raster_desc {
+  int num_points, img_height, img_width, capacity, deep_tile_threshold;
+  float extra_background;
+  const float *xys, *depths;
+  const int32_t *radii;
+  const float *conics, *colors, *extra, *opac, *background;
+  const int32_t *order_ready;
+  void *reach_records;
+  int32_t *counts, *order, *cum, *ids, *tile_bins, *count_out;
+  void *sort_ws;
+  size_t sort_ws_bytes;
+  void *bin_ws;
+  size_t bin_ws_bytes;
+  float *out_img, *out_extra, *final_Ts;
+  int32_t *final_idx;
+  float *out_alpha;
+  void *zero_ptr;
+  size_t zero_bytes;
+} gsr_raster_desc;
+int gsr_rasterize_gaussians_forward(const gsr_raster_desc *desc, gsr_stream_t stream);
 int gsr_view_backward(const gsr_view_desc *view, const gsr_view_grads *grads, gsr_stream_t stream);
 
 /* ---- per-Gaussian activations (caller-side glue) ----------

@@ -22,6 +22,12 @@ def cu(a, grad=False):
     return t.requires_grad_(True) if grad else t
 
 
+def _list_builds(R):
+    """list constructions so far, of any kind (rasterizer.rasterize.counters)"""
+    c = R.counters
+    return c["list_builds_exact"] + c["list_builds_device_sized"] + c["list_builds_ahead"]
+
+
 def npy(t):
     return t.detach().cpu().numpy()
 
@@ -155,21 +161,11 @@ def test_depth_pass_and_binning_cache():
     import rasterizer.cuda as C
 
     R._bin_cache["key"] = None
-    calls = {"n": 0}
-    orig = C.bin_sorted
-
-    def counting(*a, **k):
-        calls["n"] += 1
-        return orig(*a, **k)
-
-    C.bin_sorted = counting
-    try:
-        out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
-                          params["sh_coeffs"], CameraTensors.from_numpy(cam, DEV),
-                          cu(np.array(S.BACKGROUND, np.float32)), 1, render_depth=True)
-    finally:
-        C.bin_sorted = orig
-    assert calls["n"] == 1
+    before = _list_builds(R)
+    out = render_view(params["means3d"], params["scales"], params["quats"], params["opacities"],
+                      params["sh_coeffs"], CameraTensors.from_numpy(cam, DEV),
+                      cu(np.array(S.BACKGROUND, np.float32)), 1, render_depth=True)
+    assert _list_builds(R) - before == 1
     depth = out["depth"]
     assert depth.shape == (96, 160, 1) and torch.isfinite(depth).all()
     # oracle depth image
@@ -292,6 +288,108 @@ def test_random_view_sequences_with_two_round_lists_forced():
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count(": ok") == 80
+
+
+def test_lists_built_ahead_of_time_are_used_only_with_proven_opacities():
+    """`project_gaussians` queues the view's list construction on a side stream from the SECOND view on, when the
+    opacities are `torch.sigmoid(leaf)` of the same leaf as in the previous view (rasterize.py, "lists built ahead
+    of time"): the rasterize call that follows uses those lists (counter `ahead_hits`) and gives bit-identical
+    images; a leaf written in place between projection and rasterisation, or other opacities, drop them."""
+    from rasterizer import project_gaussians, rasterize_gaussians
+    from rasterizer import rasterize as R
+
+    cam = S.make_camera(640, 360)
+    n = 200_000
+    sc = S.make_scene(n, cam, sh_degree=0, seed=11, scale_lo=0.004, scale_hi=0.04)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    logits = torch.logit(cu(sc["opacities"]).clamp(1e-3, 1 - 1e-3)).requires_grad_(True)
+    colors = torch.rand(n, 3, device=DEV)
+    means, scales, quats = cu(sc["means3d"], True), cu(sc["scales"]), cu(sc["quats"])
+
+    def view(after_projection=None, opacity=None, mode=None):
+        if mode is not None:
+            R._spec_knobs["mode"] = mode
+        R._speculation_mode()
+        R._bin_cache["key"] = None
+        g = project_gaussians(means, scales, 1.0, quats, ct.viewmat[:3], ct.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+                              cam.height, cam.width, 16)
+        if after_projection is not None:
+            after_projection()
+        op = torch.sigmoid(logits) if opacity is None else opacity
+        img = rasterize_gaussians(g[0], g[1], g[2], g[3], g[5], colors, op, cam.height, cam.width, 16)
+        gr = torch.autograd.grad((img * img).sum(), (means, logits), allow_unused=True)
+        return img.detach(), gr
+
+    R._speculation_mode()
+    saved = R._spec_knobs["mode"]
+    try:
+        ref, gref = view(mode="0")
+        c0 = dict(R.counters)
+        first, _ = view(mode="lists")       # no recipe yet (the reference view ran with speculation off) ...
+        second, g2 = view()                 # ... now there is: lists built ahead, and used
+        c1 = dict(R.counters)
+        assert c1["list_builds_ahead"] - c0["list_builds_ahead"] >= 1 and c1["ahead_hits"] - c0["ahead_hits"] >= 1
+        assert torch.equal(first, ref) and torch.equal(second, ref)
+        assert (g2[0] - gref[0]).abs().max() <= 1e-5 * gref[0].abs().max()
+        assert (g2[1] - gref[1]).abs().max() <= 1e-5 * gref[1].abs().max()
+
+        def touch():
+            with torch.no_grad():
+                logits.mul_(1.0)  # same values, new version: provenance no longer proves anything
+
+        third, _ = view(after_projection=touch)
+        c2 = dict(R.counters)
+        assert c2["ahead_misses"] - c1["ahead_misses"] == 1 and c2["ahead_hits"] == c1["ahead_hits"]
+        assert torch.equal(third, ref)
+        faint = (torch.sigmoid(logits) * 0.05).detach()
+        view()                                # (restores the recipe)
+        c3 = dict(R.counters)
+        img_faint, _ = view(opacity=faint)    # lists were built for sigmoid(logits): dropped, not used
+        c4 = dict(R.counters)
+        assert c4["ahead_hits"] == c3["ahead_hits"]
+        R._spec_knobs["mode"] = "0"
+        R._bin_cache["key"] = None
+        g = project_gaussians(means, scales, 1.0, quats, ct.viewmat[:3], ct.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
+                              cam.height, cam.width, 16)
+        assert torch.equal(img_faint, rasterize_gaussians(g[0], g[1], g[2], g[3], g[5], colors, faint, cam.height,
+                                                          cam.width, 16).detach())
+        # lists built ahead with a capacity that turns out too small are rebuilt, like any device-sized lists
+        R._spec_knobs["mode"] = "lists"
+        view(), view()
+        key = (means.device, ((cam.width + 15) // 16, (cam.height + 15) // 16, 1))
+        R._count_hint[key] = (n, 8)
+        R._last_capacity.clear()
+        c5 = dict(R.counters)
+        small, _ = view()
+        c6 = dict(R.counters)
+        if c6["ahead_hits"] > c5["ahead_hits"] and R._count_hint[key][1] > (1 << 20):
+            assert c6["list_rebuilds"] - c5["list_rebuilds"] == 1
+        assert torch.equal(small, ref)
+    finally:
+        R._spec_knobs["mode"] = saved
+
+
+def test_caller_read_backs_do_not_change_the_view():
+    """`render_view(caller_syncs=...)` blocks the host where the unchanged models do (vanilla_gs.py:784, :811, and the
+    intrinsics' .item() calls): same image, same gradients, whatever the overlap with the side stream."""
+    cam = S.make_camera(640, 360, yaw=0.1)
+    sc = S.make_scene(150_000, cam, sh_degree=2, seed=4, scale_lo=0.004, scale_hi=0.04)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    outs = []
+    for mode in (False, True, "camera", True, False):
+        params = {k: cu(v, True) for k, v in sc.items()}
+        out = render_view(params["means3d"], params["scales"], params["quats"], torch.sigmoid(params["opacities"]),
+                          params["sh_coeffs"], ct, bg, 2, caller_syncs=mode)
+        (out["rgb"].square().sum() + out["alpha"].sum()).backward()
+        outs.append((out["rgb"].detach(), params["means3d"].grad, params["sh_coeffs"].grad))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0])
+        assert (o[1] - outs[0][1]).abs().max() <= 1e-5 * outs[0][1].abs().max()
+        assert (o[2] - outs[0][2]).abs().max() <= 1e-5 * outs[0][2].abs().max()
+    empty = render_view(cu(sc["means3d"]) * 0 - 5.0, cu(sc["scales"]), cu(sc["quats"]), cu(sc["opacities"]),
+                        cu(sc["sh_coeffs"]), ct, bg, 2, caller_syncs=True)
+    assert torch.equal(empty["rgb"], bg.repeat(cam.height, cam.width, 1))  # vanilla_gs.py:784-794
 
 
 def test_empty_scene_and_all_culled():
@@ -541,14 +639,14 @@ def test_binning_cache_tracks_opacity_and_conics():
     colors = torch.rand(2000, 3, device=DEV)
     opac = cu(sc["opacities"])
     R._bin_cache["key"] = None
-    calls = {"n": 0}
-    orig = C.bin_sorted
 
-    def counting(*a, **k):
-        calls["n"] += 1
-        return orig(*a, **k)
+    class _Calls(dict):  # list constructions since this point (rasterizer.rasterize.counters)
+        base = _list_builds(R)
 
-    C.bin_sorted = counting
+        def __getitem__(self, k):
+            return _list_builds(R) - self.base
+
+    calls = _Calls()
     try:
         a = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac, cam.height, cam.width, 16)
         b = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac.clone(), cam.height, cam.width, 16)
@@ -562,7 +660,7 @@ def test_binning_cache_tracks_opacity_and_conics():
         d = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac, cam.height, cam.width, 16)
         assert torch.equal(c, d)
     finally:
-        C.bin_sorted = orig
+        pass
     # against the oracle with the reference's full lists
     n = 2000
     xn, dn, rn, cn, tn = (t.cpu().numpy() for t in (xys, depths, radii, conics, tiles))
@@ -596,12 +694,18 @@ def test_speculative_list_sizing_never_changes_results(monkeypatch):
         cam.cx, cam.cy, cam.height, cam.width, 16)
     colors = torch.rand(n, 3, device=DEV)
     v = torch.randn(cam.height, cam.width, 3, device=DEV)
-    modes = []
-    orig = C.bin_sorted
+    class _Modes:  # which kinds of list construction ran since clear(): True = device-sized, False = exact
+        def clear(self):
+            self.base = dict(R.counters)
 
-    def spy(*a, **k):
-        modes.append(bool(k.get("device_sized", False)))
-        return orig(*a, **k)
+        def __eq__(self, other):
+            c = R.counters
+            got = [True] * (c["list_builds_device_sized"] - self.base["list_builds_device_sized"]) + \
+                  [False] * (c["list_builds_exact"] - self.base["list_builds_exact"])
+            return got == other
+
+    modes = _Modes()
+    modes.clear()
 
     def run():
         R._bin_cache["key"] = None
@@ -611,7 +715,6 @@ def test_speculative_list_sizing_never_changes_results(monkeypatch):
         (img * v).sum().backward()
         return img.detach(), c.grad, o.grad
 
-    C.bin_sorted = spy
     try:
         R._count_hint.clear()
         R._last_capacity.clear()
@@ -630,7 +733,7 @@ def test_speculative_list_sizing_never_changes_results(monkeypatch):
         assert modes == [True, False]
         assert R._count_hint[key] == (n, count)
     finally:
-        C.bin_sorted = orig
+        pass
     for got in (good, small):
         assert torch.equal(got[0], ref[0])
         for a, b in zip(got[1:], ref[1:]):
@@ -1047,7 +1150,7 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
     seen = []
     orig = R._build_two_round
     monkeypatch.setattr(R, "_build_two_round", lambda *a, **k: (seen.append(1), orig(*a, **k))[1])
-    for view in range(3):
+    for view in range(4):
         R._bin_cache["key"] = None
         out, grads = run()
         assert torch.equal(out["rgb"], ref["rgb"]) and torch.equal(out["alpha"], ref["alpha"]), view
@@ -1055,7 +1158,9 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
             assert torch.equal(out["depth"], ref["depth"]), view
         for a, b in zip(gref, grads):
             assert (a - b).abs().max().item() <= 3e-5 * a.abs().max().item() + 1e-12, view
-    assert len(seen) == 3  # every one of them went through the two-round builder
+    # the first candidate asks for the number of culled Gaussians (through a pinned slot, no read-back) and takes one
+    # round; every view behind it goes through the two-round builder
+    assert len(seen) == 3
     hint = next(iter(R._two_hint.values()))
     assert hint["count1"] > 0 and hint["count1"] + hint["count2"] < 0.9 * R._count_hint[(torch.device(DEV), ((W + 15) // 16, (H + 15) // 16, 1))][1]
     # a shallow view right behind a two-round one takes the single walk again -- with ITS lists (the per-call

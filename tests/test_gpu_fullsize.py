@@ -76,9 +76,26 @@ def grad_close(mine, ref, abs_sum=None, name="", stable=None):
 
 @pytest.mark.timeout(900)
 def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
-    W, H, n, deg = 1920, 1080, 200_000, 3
+    _forward_backward_vs_oracle(200_000, 0.005, 0.05, STABLE_VISIBLE_FLOOR, "config2_stable_fraction.json")
+
+
+# bench.py's default workload (BASELINE's headline: 1 M Gaussians, SH degree 3, 1920x1080; SURVEY 8d's scale range
+# halved, as bench.py states): the share of decision-stable visible Gaussians measured in round 4 minus 10 %
+STABLE_VISIBLE_FLOOR_1M = 0.02
+
+
+@pytest.mark.timeout(1500)
+def test_bench_default_1m_sh3_vs_oracle():
+    """The TIMED workload itself against the oracle, with config 2's assertions: projection bit-identical, image and
+    alpha within 1e-4 on decision-stable pixels, every parameter's gradient within 1e-3 (forward.cu:278-395,
+    backward.cu:133-303).  bench.py reports the same comparison in its line (`parity_vs_oracle`)."""
+    _forward_backward_vs_oracle(1_000_000, 0.0025, 0.025, STABLE_VISIBLE_FLOOR_1M, "bench_default_stable_fraction.json")
+
+
+def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file):
+    W, H, deg = 1920, 1080, 3
     cam = S.make_camera(W, H)
-    sc = S.make_scene(n, cam, sh_degree=deg, seed=42, scale_lo=0.005, scale_hi=0.05)
+    sc = S.make_scene(n, cam, sh_degree=deg, seed=42, scale_lo=scale_lo, scale_hi=scale_hi)
     bg = np.array(S.BACKGROUND, np.float32)
     v_img, v_alpha = S.make_cotangents(cam)
 
@@ -129,7 +146,7 @@ def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
     frac = float((stable & visible).sum()) / float(visible.sum())
     report = {"gaussians": n, "visible": int(visible.sum()), "stable_visible": int((stable & visible).sum()),
               "stable_fraction_of_visible": round(frac, 4), "ambiguous_pixels": round(float(amb.mean()), 5),
-              "floor": STABLE_VISIBLE_FLOOR}
+              "floor": stable_floor}
     print("config2 stable Gaussians:", report)
     try:
         import json
@@ -137,7 +154,7 @@ def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
 
         out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
-        with open(os.path.join(out_dir, "config2_stable_fraction.json"), "w") as fh:
+        with open(os.path.join(out_dir, report_file), "w") as fh:
             json.dump(report, fh)
     except OSError:
         pass
@@ -151,11 +168,11 @@ def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
     report["visible_within_1e-3_rel"] = {"xys": round(float(ok_xy.mean()), 4), "opacities": round(float(ok_op.mean()), 4)}
     print("config2 stable Gaussians:", report)
     try:
-        with open(os.path.join(out_dir, "config2_stable_fraction.json"), "w") as fh:
+        with open(os.path.join(out_dir, report_file), "w") as fh:
             json.dump(report, fh)
     except (OSError, NameError):
         pass
-    assert frac > STABLE_VISIBLE_FLOOR, report
+    assert frac > stable_floor, report
     assert ok_xy.mean() > WITHIN_FLOOR and ok_op.mean() > WITHIN_FLOOR, report
     grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable)
     grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable)

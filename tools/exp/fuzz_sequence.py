@@ -29,8 +29,32 @@ def main():
         sc = S.make_scene(n, cam, sh_degree=0, seed=n, scale_lo=lo, scale_hi=hi)
         scenes.append((cam, {k: torch.from_numpy(v).to(DEV) for k, v in sc.items()}))
     bad = 0
+    leaves = {}  # persistent opacity parameters, as a model has them: (scene, n, factor, kind) -> leaf
 
-    def run(idx, frac, ofac, yaw, want_alpha, second, speculate):
+    def opacity_for(idx, n, ofac, mode, sc):
+        """How the caller forms the opacities.  "clone": a fresh tensor every call (no provenance); "sigmoid": the
+        models' `torch.sigmoid(self.opacities)` of a persistent leaf -- what lets `project_gaussians` build the lists
+        ahead of time; "sigmoid_touched": the same, but the leaf is written in place (same values, new version) between
+        projection and rasterisation: the lists built ahead must be dropped; "leaf": a persistent leaf handed in as is.
+        -> (tensor to differentiate, opacity, touch())"""
+        if mode == "clone":
+            o = (sc["opacities"][:n] * ofac).clone().requires_grad_(True)
+            return o, o, None
+        key = (idx, n, ofac, "leaf" if mode == "leaf" else "logit")
+        if key not in leaves:
+            o = (sc["opacities"][:n] * ofac).clamp(1e-4, 1 - 1e-4)
+            leaves[key] = (o.clone() if mode == "leaf" else torch.log(o / (1 - o))).requires_grad_(True)
+        leaf = leaves[key]
+        if mode == "leaf":
+            return leaf, leaf, None
+
+        def touch():
+            with torch.no_grad():
+                leaf.mul_(1.0)
+
+        return leaf, None, (touch if mode == "sigmoid_touched" else None)
+
+    def run(idx, frac, ofac, yaw, want_alpha, second, speculate, omode="clone"):
         cam0, sc = scenes[idx]
         cam = S.make_camera(cam0.width, cam0.height, yaw=yaw)
         ct = CameraTensors.from_numpy(cam, DEV)
@@ -39,10 +63,14 @@ def main():
         if not speculate:
             R._bin_cache["key"] = None
         means = sc["means3d"][:n].clone().requires_grad_(True)
-        opac = (sc["opacities"][:n] * ofac).clone().requires_grad_(True)
+        wrt, opac, touch = opacity_for(idx, n, ofac, omode, sc)
         xys, depths, radii, conics, comp, tiles, _ = project_gaussians(
             means, sc["scales"][:n], 1.0, sc["quats"][:n], ct.viewmat[:3], ct.projmat, cam.fx, cam.fy, cam.cx, cam.cy,
             cam.height, cam.width, 16)
+        if touch is not None:
+            touch()
+        if opac is None:
+            opac = torch.sigmoid(wrt)  # formed AFTER the projection, as the models do (vanilla_gs.py:829)
         g = torch.Generator(device="cpu").manual_seed(idx * 7 + 1)
         colors = torch.rand(n, 3, generator=g).to(DEV).requires_grad_(True)
         out = rasterize_gaussians(xys, depths, radii, conics, tiles, colors, opac, cam.height, cam.width, 16,
@@ -62,7 +90,7 @@ def main():
                                             cam.height, cam.width, 16, background=torch.zeros(3, device=DEV))
             loss = loss + depth_img.sum() * 0.1
             depth_img = depth_img.detach()
-        grads = torch.autograd.grad(loss, (means, opac, colors))
+        grads = torch.autograd.grad(loss, (means, wrt, colors))
         return rgb.detach(), None if alpha is None else alpha.detach(), grads, depth_img
 
     for k in range(calls):
@@ -72,17 +100,22 @@ def main():
         yaw = float(rng.choice([0.0, 0.0, 0.1, -0.2]))
         want_alpha = bool(rng.integers(2))
         second = int(rng.integers(3))
-        a = run(idx, frac, ofac, yaw, want_alpha, second, True)
-        b = run(idx, frac, ofac, yaw, want_alpha, second, False)
+        omode = str(rng.choice(["clone", "sigmoid", "sigmoid", "sigmoid_touched", "leaf"]))
+        if rng.integers(4) == 0 and k > 0:
+            idx, frac, ofac = last  # the same scene again: the recipe AND the count hint of the previous call fit
+        last = (idx, frac, ofac)
+        a = run(idx, frac, ofac, yaw, want_alpha, second, True, omode)
+        b = run(idx, frac, ofac, yaw, want_alpha, second, False, omode)
         ok = torch.equal(a[0], b[0]) and (a[1] is None or torch.equal(a[1], b[1]))
         ok = ok and (a[3] is None or torch.equal(a[3], b[3]))
         for ga, gb in zip(a[2], b[2]):
             ok = ok and float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max()) + 1e-12
         spec = specs[idx]
         print(f"call {k}: scene {idx} ({int(spec[0] * frac)} Gaussians, {spec[1]}x{spec[2]}) opacity x{ofac} yaw {yaw} "
-              f"alpha={want_alpha} second={second}: {'ok' if ok else 'MISMATCH'}", flush=True)
+              f"alpha={want_alpha} second={second} opacity={omode}: {'ok' if ok else 'MISMATCH'}", flush=True)
         bad += 0 if ok else 1
     os.environ["GSR_NO_SPECULATION"] = "0"
+    print("lists:", dict(R.counters))
     print("mismatches:", bad)
     sys.exit(1 if bad else 0)
 
