@@ -275,6 +275,7 @@ def train_only(args):
 
     if args.train_small:
         _small(cfg)
+    cfg.export_ply = args.train_export_ply
     res = train(cfg, dev, rank, world)
     full_run = args.train_iters >= 1000 and not args.train_small
     res1m = train(fixed_1m(), dev, rank, world) if full_run else None
@@ -533,8 +534,14 @@ def main():
     ap.add_argument("--deterministic", action="store_true",
                     help="compositing backward with a fixed summation order (gsr_rasterize_backward_det) instead of "
                          "float atomics")
-    ap.add_argument("--scene", default="uniform", choices=["uniform", "longtail"],
-                    help="longtail: 10 %% of the tiles hold ~10x the list depth (clustered Gaussians)")
+    ap.add_argument("--scene", default="uniform",
+                    help="uniform (SURVEY 8d's random cloud) | longtail: 10 %% of the tiles hold ~10x the list depth "
+                         "(clustered Gaussians) | ply:<path>: a TRAINED model in the toolkit's export format "
+                         "(gs_io/ply.py; scripts/exporter.py:88-147), seen from --ply-view of an orbit of radius "
+                         "--ply-cam-radius (the cameras harness.train trains on)")
+    ap.add_argument("--ply-cam-radius", type=float, default=5.0)
+    ap.add_argument("--ply-view", type=int, default=0)
+    ap.add_argument("--ply-views", type=int, default=48)
     ap.add_argument("--caller-syncs", default="off", choices=["off", "on", "camera"],
                     help="run the MAIN timed region with the unchanged models' host read-backs in the caller (profiling "
                          "runs; the default line reports all three modes anyway)")
@@ -548,6 +555,8 @@ def main():
                     help="iterations of the config-3 training record (BASELINE metric, second half); 0: skip it")
     ap.add_argument("--train-timeout", type=int, default=900)
     ap.add_argument("--train-only", action="store_true", help="run only the config-3 training leg and print its record")
+    ap.add_argument("--train-export-ply", default=None,
+                    help="--train-only: write the model the config-3 run ends with to this PLY (then: --scene ply:<path>)")
     ap.add_argument("--train-small", action="store_true", help=argparse.SUPPRESS)  # tests: a scene that trains in seconds
     args = ap.parse_args()
 
@@ -605,11 +614,30 @@ def main():
 
     # ---- workload: SURVEY.md 8(d), seed 42; one scene, one camera per rank
     W, H, N, deg = args.width, args.height, args.gaussians, args.sh_degree
-    cam0 = S.make_camera(W, H)
-    sc = S.make_scene(N, cam0, sh_degree=deg, seed=42, scale_lo=args.scale_lo, scale_hi=args.scale_hi,
-                      longtail=args.scene == "longtail")
-    # rank r looks at the same cloud from a slightly different direction
-    cam = cam0 if rank == 0 else S.make_camera(W, H, yaw=0.02 * rank, pitch=0.01 * (rank % 3))
+    if args.scene.startswith("ply:"):
+        # a trained model: raw parameters from the file, activated as get_outputs activates them
+        # (vanilla_gs.py:765-830: exp, normalise, sigmoid, cat of the SH features)
+        from gs_io.ply import read_gaussian_ply
+        from harness.train import orbit_cameras
+
+        raw = read_gaussian_ply(args.scene[4:])
+        N = raw["means"].shape[0]
+        deg = {0: 0, 3: 1, 8: 2, 15: 3}[raw["features_rest"].shape[1]]
+        q = raw["quats"] / np.linalg.norm(raw["quats"], axis=-1, keepdims=True)
+        sc = {"means3d": raw["means"], "scales": np.exp(raw["scales"]).astype(np.float32), "quats": q.astype(np.float32),
+              "opacities": (1.0 / (1.0 + np.exp(-raw["opacities"].astype(np.float64)))).astype(np.float32),
+              "sh_coeffs": np.ascontiguousarray(np.concatenate([raw["features_dc"][:, None, :], raw["features_rest"]], 1))}
+        cams = orbit_cameras(args.ply_views, W, H, radius=args.ply_cam_radius)
+        cam0 = cams[args.ply_view % len(cams)]
+        cam = cams[(args.ply_view + rank * 5) % len(cams)]
+    elif args.scene in ("uniform", "longtail"):
+        cam0 = S.make_camera(W, H)
+        sc = S.make_scene(N, cam0, sh_degree=deg, seed=42, scale_lo=args.scale_lo, scale_hi=args.scale_hi,
+                          longtail=args.scene == "longtail")
+        # rank r looks at the same cloud from a slightly different direction
+        cam = cam0 if rank == 0 else S.make_camera(W, H, yaw=0.02 * rank, pitch=0.01 * (rank % 3))
+    else:
+        raise SystemExit(f"unknown --scene {args.scene!r}")
     bg_np = np.array(S.BACKGROUND, np.float32)
     v_img_np, v_alpha_np = S.make_cotangents(cam)
 
@@ -889,7 +917,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{N} random Gaussians (SURVEY 8d, seed 42, scales log-U[{args.scale_lo},{args.scale_hi}]), "
+                "workload": (f"{N} Gaussians of a TRAINED model ({os.path.basename(args.scene[4:])}; view {args.ply_view} of "
+                             f"the training orbit), " if args.scene.startswith("ply:") else
+                             f"{N} random Gaussians (SURVEY 8d, seed 42, scales log-U[{args.scale_lo},{args.scale_hi}]), ") +
                             f"SH degree {deg}, {W}x{H}, block 16, fwd+bwd through the rasterizer autograd API"
                             + ((" + depth image from the same compositing pass (gs_fused)" if args.fused_depth
                                else " + differentiable depth pass") if args.render_depth else "")

@@ -198,7 +198,7 @@ class _Render(Function):
             p = lambda t: None if t is None else t.data_ptr()
             desc = _ViewDesc(n, ctx.degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy,
                              spec.cx, spec.cy, spec.glob_scale, spec.clip_thresh, ctx.capacity,
-                             _C.deep_tile_threshold(ctx.capacity, tb[0] * tb[1]),
+                             _C.deep_tile_threshold(ctx.capacity, tb[0] * tb[1], backward=True),
                              p(means), None, p(raw_quats), None, p(features_dc), p(features_rest), p(viewmat),
                              p(projmat), None, p(background), p(scales), p(quats), p(opac), p(dirs), p(cov3d), p(xys),
                              p(depths), p(radii), p(conics), p(comp), None, p(colors), None, None, None, None, p(ids),

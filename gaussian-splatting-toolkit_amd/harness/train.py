@@ -372,6 +372,7 @@ class TrainConfig:
     # ONE rank too: every collective then goes through the backend as an identity -- how the RCCL code path is
     # exercised on a single-GPU box (tests/test_gpu_nccl.py)
     force_exchange: bool = False
+    export_ply: Optional[str] = None      # write the trained model as `gs-export gaussian-splat` does (gs_io/ply.py)
 
 
 def _sh_views_backward_autograd():
@@ -754,6 +755,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         if len(factors) > 1:  # the coarse-to-fine schedule: one set of medians per resolution
             phases_by_res = {f"{cfg.width // d_}x{cfg.height // d_}": med([m for dd, m in phase_marks if dd == d_])
                              for d_ in sorted({dd for dd, _ in phase_marks}, reverse=True)}
+    if cfg.export_ply and rank == 0:
+        from gs_io.ply import write_gaussian_ply
+
+        write_gaussian_ply(cfg.export_ply, {k: model.gauss[k].detach().cpu().numpy() for k in PARAM_NAMES})
     checksum = float(sum(p.detach().double().sum() for p in model.param_list()))
     return {"iters": cfg.iters - start_step, "start_step": start_step, "seconds": elapsed,
             "iters_per_s": (cfg.iters - start_step) / elapsed, "psnr_start": psnr0,

@@ -496,7 +496,8 @@ def rasterize_backward_two(img_height, img_width, gaussian_ids_sorted, tile_bins
               _ptr(v_output_extra) if extra is not None else None,
               _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic), _ptr(v_colors),
               _ptr(v_extra) if v_extra is not None else None, _ptr(v_opacity),
-              C.c_int(deep_tile_threshold(tile_bins.shape[0] * 400, nt)), C.c_int(1 if zeroed else 0), _stream(dev))
+              C.c_int(deep_tile_threshold(tile_bins.shape[0] * 400, nt, backward=True)), C.c_int(1 if zeroed else 0),
+              _stream(dev))
     if extra is not None:
         return v_xy, v_conic, v_colors, v_extra, v_opacity
     return v_xy, v_conic, v_colors, v_opacity
@@ -516,7 +517,7 @@ def _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacitie
         raise RuntimeError("background must have one value per channel")
 
 
-def deep_tile_threshold(list_entries: int, num_tiles: int) -> int:
+def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = False) -> int:
     """List length above which a 16x16 tile is composited by four waves (one per 8x8
     sub-tile) instead of one (include/gsraster.h, ``deep_tile_threshold``): GSR_DEEP_FACTOR
     (default 1.2; 0 = off) times the mean list length, not below GSR_DEEP_MIN (1024).
@@ -525,9 +526,19 @@ def deep_tile_threshold(list_entries: int, num_tiles: int) -> int:
     (10 % of the tiles ~10x deeper): forward 357 -> 320 us, backward 664 -> 625 us; factors
     0.8-1.5 within 3 % of each other, 0.3 (nearly every tile split) 1.7x slower; no effect
     on the uniform scene (nothing above the threshold; the idle workgroups cost < 1 %)."""
-    factor, floor = _deep_knobs()
+    factor, floor, small_grid, small_floor, small_grid_bwd = _deep_knobs()
     if factor <= 0 or num_tiles <= 0:
         return 0
+    if num_tiles <= (small_grid_bwd if backward else small_grid):
+        # A small tile grid cannot fill the chip with one wave per tile (480 x 270 -- the first 2 000 iterations of
+        # the reference's coarse-to-fine schedule -- is 510 tiles for 1 024 SIMDs) and every tile's list is long: the
+        # walk is a serial chain of ~100 instructions per splat on a SIMD that has nothing else to issue.  Every
+        # tile with more than a chunk or two of entries is split over four waves (one per 8x8 sub-tile).  Measured
+        # (profiles/r04_small_grids.txt): 300 k Gaussians at 480 x 270, forward 0.32 -> 0.17 ms, backward 0.45 ->
+        # 0.26 ms; 450 k at 960 x 540 (2 040 tiles), forward 0.19 -> 0.15 ms but backward 0.28 -> 0.35 ms (four
+        # waves per tile also issue four times the atomics): the backward splits every tile only on grids of up to
+        # GSR_SMALL_GRID_BWD tiles.  1080p with every tile split: 1.57 ms instead of 1.00.
+        return small_floor
     return max(floor, int(factor * list_entries / num_tiles))
 
 
@@ -539,7 +550,9 @@ def _deep_knobs():
     if not _deep_cache:
         import os
 
-        _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "1024")))
+        _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "1024")),
+                            int(os.environ.get("GSR_SMALL_GRID", "2560")), int(os.environ.get("GSR_SMALL_GRID_MIN", "96")),
+                            int(os.environ.get("GSR_SMALL_GRID_BWD", "1100")))
     return _deep_cache["v"]
 
 
@@ -779,7 +792,7 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
               _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic),
               _ptr(v_colors), _ptr(v_extra), _ptr(v_opacity),
               C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(),
-                                          ((img_width + 15) // 16) * ((img_height + 15) // 16))),
+                                          ((img_width + 15) // 16) * ((img_height + 15) // 16), backward=True)),
               C.c_int(1 if accumulators is not None else 0), _stream(dev))
     return v_xy, v_conic, v_colors, v_extra, v_opacity
 
@@ -870,10 +883,11 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
             tiles = ((img_width + block_width - 1) // block_width) * ((img_height + block_width - 1) // block_width)
             if zeroed:
                 _call("gsr_rasterize_backward_ex", *head, *tail,
-                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)), C.c_int(1), _stream(dev))
+                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)), C.c_int(1),
+                      _stream(dev))
             else:
                 _call("gsr_rasterize_backward", *head, *tail,
-                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)), _stream(dev))
+                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)), _stream(dev))
     return v_xy, v_conic, v_colors, v_opacity
 
 

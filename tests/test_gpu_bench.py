@@ -89,6 +89,9 @@ def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks():
         assert t and "error" not in t, t
         assert t["iters"] == 160 and t["iters_per_s"] > 0 and t["n_gpus"] == (2 if extra else 1)
         assert t["gaussians"]["start"] == 8000 and t["refinements"] >= 2
-        assert t["psnr"]["end"] > t["psnr"]["start"] + 2.0, t
+        assert t["psnr"]["end"] > t["psnr"]["start"] + 1.0, t   # (half of the 160 iterations run at reduced resolution)
+        assert t["schedule"]["num_downscales"] == 2 and t["schedule"]["background_color"] == "random"
+        assert len(t["phase_ms_median_by_resolution"]) == 3, t["phase_ms_median_by_resolution"]
+        assert t["iters_per_s_with_caller_syncs"] > 0 and t["list_overflow_views"] == 0
         if extra:
             assert t["replicas_identical"] is True and t["allreduce_bytes_step_bytes"], t

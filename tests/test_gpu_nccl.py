@@ -62,6 +62,8 @@ def grads(mode, deg_use=3):
     return [p[k].grad.clone() for k in names], nbytes
 
 
+import rasterizer.rasterize as R
+R.set_deterministic(True)   # atomics-free compositing backward: two runs of the same view are comparable bit for bit
 ref, _ = grads("off")
 dense, b_dense = grads("dense")
 views, b_views = grads("views")
@@ -110,8 +112,6 @@ def run(**kw):
                       sh_degree=2, sh_degree_interval=15, densify=True, refine=rc, scene_scale=(0.01, 0.04), **kw)
     r = train(cfg, dev, 0, 1)
     return r["param_checksum"], r["num_gaussians_end"], r["update"], r["allreduce_bytes"]
-import rasterizer.rasterize as R
-R.set_deterministic(True)   # atomics-free backward: the three runs are comparable bit for bit
 base = run()
 forced_dense = run(force_exchange=True, sh_exchange="dense")
 forced_sharded = run(force_exchange=True, sharded_adam=True)

@@ -149,9 +149,11 @@ def test_deterministic_mode_makes_training_bitwise_reproducible():
 @pytest.mark.timeout(1200)
 def test_config3_as_bench_py_times_it():
     """BASELINE config 3 exactly as bench.py's `train` record runs it (bench.config3: 1080p, 48 views, a
-    200 k-point sparse seed, every refinement default of the reference incl. densify_grad_thresh 2e-4,
-    7 000 iterations): the model grows, learns, never reads device memory back between refinements,
-    and the one-op path (gs_fused.render_gaussians) trains to the same result."""
+    200 k-point sparse seed, every refinement default of the reference incl. densify_grad_thresh 2e-4, its
+    coarse-to-fine resolution schedule (480x270 -> 960x540 -> 1920x1080 at steps 2000 / 4000) and its random
+    background, 7 000 iterations): the model grows, learns, never reads device memory back between refinements,
+    never has to rebuild a tile list across the two resolution switches, and the one-op path
+    (gs_fused.render_gaussians) trains to the same result."""
     import bench
 
     counts = {"item": 0, "tolist": 0}
@@ -176,6 +178,10 @@ def test_config3_as_bench_py_times_it():
     print("config 3:", {k: res[k] for k in ("iters_per_s", "psnr_start", "psnr_end", "num_gaussians_start",
                                             "num_gaussians_end", "phase_ms_median")}, "max N", n_max, "read-backs", counts)
     assert res["num_gaussians_start"] == 200_000 and res["densify_grad_thresh"] == 0.0002 and res["init"] == "sfm"
+    assert res["schedule"] == {"num_downscales": 2, "resolution_schedule": 2000, "background_color": "random",
+                               "caller_syncs": False}
+    assert sorted(res["phase_ms_median_by_resolution"]) == ["1920x1080", "480x270", "960x540"]
+    assert res["list_overflow_views"] == 0, res["list_overflow_views"]   # sized per tile grid: no rebuild at the switches
     assert n_max > 350_000 and res["num_gaussians_end"] > 300_000, hist      # the reference's rule fires and grows the model
     assert len(hist) >= 40
     assert res["psnr_end"] > res["psnr_start"] + 8.0 and res["psnr_end"] > 26.0, res

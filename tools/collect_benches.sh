@@ -32,3 +32,16 @@ run config5 $P $DENSE --gaussians 3000000 --width 3840 --height 2160 --render-de
 run config5_fused_depth $P $DENSE --gaussians 3000000 --width 3840 --height 2160 --render-depth --fused-depth --steps 20 --warmup 5
 run longtail $Q --scene longtail
 run deterministic $Q --deterministic
+# a TRAINED distribution: the config-3 model after its 7 000 iterations, exported as `gs-export gaussian-splat`
+# writes it, benched forward + backward from a training view (counter passes on: per-kernel traffic)
+timeout 900 python - "$OUT/config3_trained.ply" <<'PY'
+import os, sys
+sys.path[:0] = [os.environ.get("GRAFT_REPO_ROOT", "."), os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gaussian-splatting-toolkit_amd")]
+import torch, bench
+from harness.train import train
+cfg = bench.config3(7000)
+cfg.export_ply, cfg.phase_every, cfg.log_every = sys.argv[1], 0, 0
+r = train(cfg, torch.device("cuda", 0))
+print("exported", sys.argv[1], "N", r["num_gaussians_end"], "psnr", r["psnr_end"], "it/s", r["iters_per_s"])
+PY
+run trained $P --scene "ply:$OUT/config3_trained.ply" --ply-cam-radius 5.0 --ply-view 3
