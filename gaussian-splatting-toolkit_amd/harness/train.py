@@ -373,6 +373,13 @@ class TrainConfig:
     # exercised on a single-GPU box (tests/test_gpu_nccl.py)
     force_exchange: bool = False
     export_ply: Optional[str] = None      # write the trained model as `gs-export gaussian-splat` does (gs_io/ply.py)
+    # random background only: the step's target as ONE kernel.  The reference downscales the RGBA ground truth and
+    # composites it over the step's background every step (vanilla_gs.py:659-670, 870-881: a resize + four
+    # elementwise kernels over the image).  The resized image does not depend on the step: alpha_ds * rgb_ds and
+    # 1 - alpha_ds (both formed from the RESIZED RGBA, in the reference's order -- resizing does not commute with
+    # the product) are cached per view and resolution and the step runs one `addcmul` with its background.
+    # False: the reference's per-step sequence.
+    fused_target: bool = True
 
 
 def _sh_views_backward_autograd():
@@ -569,6 +576,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     phase_marks = []
     first_pending, first_vis = True, None
     rebuilds0 = _list_rebuilds()
+    target_cache = {}  # (view, downscale factor) -> (resized alpha * rgb [h,w,3], resized 1 - alpha [h,w,1])
     bg_static = bg.clone() if (random_bg and cfg.use_graph) else None  # a replayed graph reads its background here
     for step in range(start_step, cfg.iters):
         ph = None
@@ -582,7 +590,15 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         max_dim = max(cam.width, cam.height)  # `max(self.last_size)` of after_train / refinement_after
         if random_bg:
             bg_step = torch.rand(3, device=device, generator=bg_gen)
-            target = composite_with_background(downscale_image(gt_rgba[v], d), bg_step)
+            if cfg.fused_target:
+                planes = target_cache.get((v, d))
+                if planes is None:
+                    small = downscale_image(gt_rgba[v], d)
+                    a_ = small[..., 3:4]
+                    planes = target_cache[(v, d)] = ((a_ * small[..., :3]).contiguous(), (1 - a_).contiguous())
+                target = torch.addcmul(planes[0], planes[1], bg_step)
+            else:
+                target = composite_with_background(downscale_image(gt_rgba[v], d), bg_step)
             if bg_static is not None:
                 bg_static.copy_(bg_step)
                 bg_step = bg_static

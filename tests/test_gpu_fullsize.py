@@ -81,7 +81,7 @@ def test_config2_200k_sh3_1080p_forward_backward_vs_oracle():
 
 # bench.py's default workload (BASELINE's headline: 1 M Gaussians, SH degree 3, 1920x1080; SURVEY 8d's scale range
 # halved, as bench.py states): the share of decision-stable visible Gaussians measured in round 4 minus 10 %
-STABLE_VISIBLE_FLOOR_1M = 0.02
+STABLE_VISIBLE_FLOOR_1M = 0.155  # measured 0.1728 (150 152 of 869 029 visible Gaussians), round 4
 
 
 @pytest.mark.timeout(1500)
@@ -459,7 +459,12 @@ def test_config5_full_size_fused_rgbd_equals_two_passes_without_host_sync(c5):
                                H, W, 16, background=torch.zeros(3, device=DEV))[..., 0]
     torch.autograd.backward([rgb2, dep2], [v_img, v_dep])
     g2 = [t.grad.clone() for t in (x, c, o, d)]
-    # second view onwards: no host read-back of the count on the critical path
+    # steady state (a view that sized its lists from the previous one; the two-round plan has the culled count,
+    # which travels through a pinned slot and takes one view to arrive): no host read-back on the critical path
+    x, c, o, d = leaves()
+    rasterize_gaussians_rgbd(x, c5["depths"], c5["radii"], c5["conics"], c5["tiles"], c, d, o, H, W, background=bg)
+    x, c, o, d = leaves()
+    rasterize_gaussians_rgbd(x, c5["depths"], c5["radii"], c5["conics"], c5["tiles"], c, d, o, H, W, background=bg)
     items = {"n": 0}
     orig = torch.Tensor.item
 

@@ -748,7 +748,7 @@ def test_deep_tiles_split_over_four_waves_give_identical_results(rgbd, monkeypat
     v_ext = torch.rand(H, W, device=DEV) * 2 - 1
 
     def run(threshold):
-        monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles: threshold)
+        monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
         if rgbd:
             f = C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors), cu(depths),
                                          cu(sc["opacities"]), bg, 0.0)

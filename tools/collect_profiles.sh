@@ -12,13 +12,20 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-pmc --train-iters 0 --event-every 0"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-pmc --train-iters 0 --event-every 0 --no-synced-regions"
 
 rm -rf /tmp/prof_kt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $BENCH --steps 25 --warmup 5 > "$OUT/prof_kt.log" 2>&1
 python "$ROOT/tools/summarize_prof.py" /tmp/prof_kt "$OUT/${TAG}_kernel_trace_summary.json" > "$OUT/${TAG}_kernel_trace_summary.txt"
 cp "$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv" 2>/dev/null
 python "$ROOT/tools/step_seq.py" /tmp/prof_kt "$OUT/${TAG}_step_sequence.txt"
+# the same step with the unchanged models' two host read-backs in the caller (vanilla_gs.py:784,811): where the GPU
+# idles, with the tile lists built ahead of time on the side stream (default) and without (GSR_SPECULATE=0)
+for SP in lists 0; do
+  rm -rf /tmp/prof_sync
+  GSR_SPECULATE=$SP timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_sync -- $BENCH --steps 20 --warmup 5 --caller-syncs on --no-synced-regions > "$OUT/prof_sync_$SP.log" 2>&1
+  python "$ROOT/tools/step_seq.py" /tmp/prof_sync "$OUT/${TAG}_step_sequence_caller_syncs_speculate_$SP.txt"
+done
 
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$C

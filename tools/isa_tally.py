@@ -65,8 +65,11 @@ def innermost_loop(lines):
     for i, l in enumerate(lines):
         if not l.startswith(".LBB"):
             continue
-        ctx = l + (lines[i + 1] if i + 1 < len(lines) and lines[i + 1].lstrip().startswith(";") else "")
-        m = re.search(r"Loop Header: Depth=(\d+)", ctx)
+        ctx, k = l, i + 1
+        while k < len(lines) and lines[k].lstrip().startswith(";") and k < i + 6:  # the loop comments span lines
+            ctx += lines[k]
+            k += 1
+        m = re.search(r"This (?:Inner )?Loop Header: Depth=(\d+)", ctx)
         if not m:
             continue
         label, depth = l.split(":")[0], int(m.group(1))
@@ -76,8 +79,9 @@ def innermost_loop(lines):
         while k + 1 < len(lines) and not lines[k + 1].startswith(".LBB"):
             k += 1
         body = lines[i:k + 1]
-        if any(x.strip().startswith("ds_") for x in body) and (
-                best is None or depth > best[2] or (depth == best[2] and len(body) > len(best[1]))):
+        # the walk over the staged splats: reads them from LDS and evaluates exp(-sigma)
+        if any(x.strip().startswith("ds_") for x in body) and any(x.strip().startswith("v_exp_f32") for x in body) and (
+                best is None or depth > best[2] or (depth == best[2] and len(body) < len(best[1]))):
             best = (label, body, depth)
     return best[0], best[1]
 
