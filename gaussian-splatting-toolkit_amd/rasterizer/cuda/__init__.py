@@ -41,6 +41,26 @@ def _ptr(t: Tensor) -> C.c_void_p:
     return C.c_void_p(t.data_ptr())
 
 
+class _Already:
+    """(no-op context: the tensors' device is the current one already)"""
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_ALREADY = _Already()
+
+
+def _on(dev):
+    """`torch.cuda.device(dev)` -- allocations and launches go to the inputs' device -- without the context
+    manager's ~3 us when that device is current already (a dozen wrappers per view)."""
+    idx = dev.index
+    return _ALREADY if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+
 def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -79,7 +99,7 @@ def project_gaussians_forward(
         raise RuntimeError("means3d/scales/quats do not match num_points")
     dev = means3d.device
     _opt0 = lambda t: None if t is None else _ptr(t)
-    with torch.cuda.device(dev):
+    with _on(dev):
         cov3d = cov3d_precomp if precomp else torch.empty((n, 6), dtype=_f32, device=dev)
         xys = torch.empty((n, 2), dtype=_f32, device=dev)
         depths = torch.empty((n,), dtype=_f32, device=dev)
@@ -120,7 +140,7 @@ def project_gaussians_backward(
                       (v_compensation, "v_compensation"))
     )
     _opt = lambda t: None if t is None else _ptr(t)
-    with torch.cuda.device(dev):
+    with _on(dev):
         v_cov2d = torch.empty((n, 3), dtype=_f32, device=dev)
         v_cov3d = torch.empty((n, 6), dtype=_f32, device=dev)
         v_mean3d = torch.empty((n, 3), dtype=_f32, device=dev)
@@ -151,7 +171,7 @@ def compute_sh_forward(num_points: int, degree: int, degrees_to_use: int, viewdi
     _check(viewdirs, "viewdirs", _f32)
     _check(coeffs, "coeffs", _f32)
     dev = coeffs.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         colors = torch.empty((n, 3), dtype=_f32, device=dev)
         _call("gsr_sh_forward", C.c_uint(n), C.c_uint(degree), C.c_uint(degrees_to_use),
               _ptr(viewdirs), _ptr(coeffs), _ptr(colors), _stream(dev))
@@ -169,7 +189,7 @@ def compute_sh_backward(num_points: int, degree: int, degrees_to_use: int, viewd
     _check(viewdirs, "viewdirs", _f32)
     v_colors = _check(v_colors.contiguous(), "v_colors", _f32)
     dev = viewdirs.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         v_coeffs = torch.empty((n, _num_sh_bases(degree), 3), dtype=_f32, device=dev)
         _call("gsr_sh_backward", C.c_uint(n), C.c_uint(degree), C.c_uint(degrees_to_use),
               _ptr(viewdirs), _ptr(v_colors), _ptr(v_coeffs), _stream(dev))
@@ -182,7 +202,7 @@ def cumsum_tiles(num_tiles_hit: Tensor) -> Tensor:
     _check(num_tiles_hit, "num_tiles_hit", _i32)
     n = num_tiles_hit.numel()
     dev = num_tiles_hit.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         cum = torch.empty_like(num_tiles_hit)
         nbytes = int(_lib().gsr_cumsum_workspace_bytes(C.c_int(n)))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
@@ -203,7 +223,7 @@ def map_gaussian_to_intersects(
     _check(cum_tiles_hit, "cum_tiles_hit", _i32)
     dev = xys.device
     I = int(num_intersects)
-    with torch.cuda.device(dev):
+    with _on(dev):
         # zero-filled like the reference: slots not claimed by any splat stay 0
         isect_ids = torch.zeros((I,), dtype=_i64, device=dev)
         gaussian_ids = torch.zeros((I,), dtype=_i32, device=dev)
@@ -220,7 +240,7 @@ def sort_intersects(isect_ids: Tensor, gaussian_ids: Tensor, num_tiles: int) -> 
     _check(gaussian_ids, "gaussian_ids", _i32)
     I = isect_ids.numel()
     dev = isect_ids.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         keys = torch.empty_like(isect_ids)
         vals = torch.empty_like(gaussian_ids)
         nbytes = int(_lib().gsr_sort_workspace_bytes(C.c_int(I)))
@@ -236,7 +256,7 @@ def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: Tensor,
     _check(isect_ids_sorted, "isect_ids_sorted", _i64)
     dev = isect_ids_sorted.device
     nt = int(tile_bounds[0]) * int(tile_bounds[1])
-    with torch.cuda.device(dev):
+    with _on(dev):
         tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
         _call("gsr_tile_bin_edges", C.c_int(int(num_intersects)), _ptr(isect_ids_sorted),
               C.c_int(nt), _ptr(tile_bins), _stream(dev))
@@ -259,7 +279,7 @@ def depth_order(depths: Tensor, radii: Tensor, num_tiles_hit: Optional[Tensor]) 
         if n and (num_tiles_hit.numel() != bands * n or bands < 1):
             raise RuntimeError("depth_order: num_tiles_hit must hold N (or bands * N) counts")
     dev = depths.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         order = torch.empty((n,), dtype=_i32, device=dev)
         cum = torch.empty((bands * n,), dtype=_i32, device=dev) if num_tiles_hit is not None else None
         nbytes = int(_lib().gsr_depth_order_workspace_bytes(C.c_int(n), C.c_int(bands)))
@@ -294,7 +314,7 @@ def publish_int32(src: Tensor, dst: Tensor) -> None:
     if dst.dtype != _i32 or dst.numel() < 1:
         raise RuntimeError("publish_int32: dst must be int32")
     dev = src.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         _call("gsr_publish_int32", _ptr(src), _ptr(dst), _stream(dev))
 
 
@@ -315,7 +335,7 @@ def count_reach(xys: Tensor, radii: Tensor, conics: Tensor, opacities: Tensor,
     if xys.numel() != 2 * n or conics.numel() != 3 * n or opacities.numel() != n:
         raise RuntimeError("count_reach: xys [N,2], conics [N,3], opacities [N,1] expected")
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         cnt = torch.empty((int(bands) * n,), dtype=_i32, device=dev) if counts else None
         recs = torch.empty((n + int(extra_rows), int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
         if extra_rows:
@@ -339,7 +359,7 @@ def reach_records_depth_order(xys: Tensor, radii: Tensor, conics: Tensor, opacit
     if xys.numel() != 2 * n or conics.numel() != 3 * n or opacities.numel() != n or depths.numel() != n:
         raise RuntimeError("reach_records_depth_order: xys [N,2], conics [N,3], opacities [N,1], depths [N] expected")
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         recs = torch.empty((n + int(extra_rows), int(_lib().gsr_reach_record_bytes())), dtype=torch.uint8, device=dev)
         if extra_rows:
             recs[n:].zero_()  # (as in count_reach: the dummy culled record)
@@ -382,7 +402,7 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     I = int(num_intersects)
     nt = int(tile_bounds[0]) * int(tile_bounds[1])
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         ids = torch.empty((I,), dtype=_i32, device=dev)
         tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
         nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(int(num_points)), C.c_int(I),
@@ -417,7 +437,7 @@ def tile_lists_subrange(order_sub: Tensor, capacity: int, reach_records: Tensor,
     n = order_sub.numel()
     nt = int(tile_bounds[0]) * int(tile_bounds[1])
     dev = ids_out.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         bins = torch.empty((nt, 2), dtype=_i32, device=dev)
         nbytes = int(_lib().gsr_tile_lists_subrange_workspace_bytes(C.c_int(n), C.c_int(int(capacity)),
                                                                    C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
@@ -436,7 +456,7 @@ def saturation_filter(order_sub: Tensor, reach_records: Tensor, dummy_index: int
     _check(order_sub, "order", _i32)
     _check(tile_flags, "tile_flags", _i32)
     dev = tile_flags.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty_like(order_sub)
         nbytes = int(_lib().gsr_saturation_filter_workspace_bytes(C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
@@ -456,7 +476,7 @@ def rasterize_forward_round(rnd: int, tile_bounds, img_size, gaussian_ids_sorted
     W, H = int(img_size[0]), int(img_size[1])
     dev = xys.device
     nt = tile_bounds[0] * tile_bounds[1]
-    with torch.cuda.device(dev):
+    with _on(dev):
         _call("gsr_rasterize_forward_round", C.c_int(int(rnd)), C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
               C.c_uint(W), C.c_uint(H), _ptr(gaussian_ids_sorted), _ptr(tile_bins), C.c_int(int(idx_base)), _ptr(xys),
               _ptr(conics), _ptr(colors), _ptr(extra) if extra is not None else None, _ptr(opacities),
@@ -480,7 +500,7 @@ def rasterize_backward_two(img_height, img_width, gaussian_ids_sorted, tile_bins
     n = xys.size(0)
     k = 10 if extra is not None else 9
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         zeroed = accumulators is not None
         if zeroed and (accumulators.numel() != n * k or accumulators.dtype != _f32 or not accumulators.is_contiguous()):
             raise RuntimeError("rasterize_backward_two: accumulators must be backward_accumulators(n, 3 or 4, device)")
@@ -620,7 +640,7 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
         order_ready = None  # lists with counts sort the counts along: the ready-made order is of no use
     lean, off, total, sort_b, bin_b = _raster_plan(n, capacity, tb, order_ready is not None)
     H, W = int(img_height), int(img_width)
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = torch.empty((total,), dtype=torch.uint8, device=dev)
         ids = torch.empty((capacity,), dtype=_i32, device=dev)
         bins = torch.empty((tb[0] * tb[1], 2), dtype=_i32, device=dev)
@@ -671,7 +691,7 @@ def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_b
     channels = colors.size(1)
     W, H = int(img_size[0]), int(img_size[1])
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         out_img = torch.empty((H, W, channels), dtype=_f32, device=dev)
         final_Ts = torch.empty((H, W), dtype=_f32, device=dev)
         final_idx = torch.empty((H, W), dtype=_i32, device=dev)
@@ -714,7 +734,7 @@ def rasterize_forward_scan(tile_bounds, img_size, gaussian_ids_sorted, tile_bins
     _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
     W, H = int(img_size[0]), int(img_size[1])
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         img = torch.empty((H, W, 3), dtype=_f32, device=dev)
         Ts = torch.empty((H, W), dtype=_f32, device=dev)
         idx = torch.empty((H, W), dtype=_i32, device=dev)
@@ -744,7 +764,7 @@ def rasterize_forward_rgbd(tile_bounds, img_size, gaussian_ids_sorted, tile_bins
         raise RuntimeError("rasterize_forward_rgbd expects colors [N,3] and extra [N]")
     W, H = int(img_size[0]), int(img_size[1])
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         img = torch.empty((H, W, 3), dtype=_f32, device=dev)
         ext = torch.empty((H, W), dtype=_f32, device=dev)
         Ts = torch.empty((H, W), dtype=_f32, device=dev)
@@ -777,7 +797,7 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
         v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
     n = xys.size(0)
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         if accumulators is not None and (accumulators.numel() != n * 10 or accumulators.dtype != _f32 or
                                          not accumulators.is_contiguous()):
             raise RuntimeError("rasterize_backward_rgbd: accumulators must be backward_accumulators(n, 4, device)")
@@ -820,7 +840,7 @@ def rasterize_backward_det(img_height, img_width, gaussian_ids_sorted, tile_bins
     bands = cum_sorted.numel() // n if n else 1
     dev = xys.device
     _o = lambda t: None if t is None else _ptr(t)
-    with torch.cuda.device(dev):
+    with _on(dev):
         v_xy = torch.empty((n, 2), dtype=_f32, device=dev)
         v_conic = torch.empty((n, 3), dtype=_f32, device=dev)
         v_colors = torch.empty((n, 3), dtype=_f32, device=dev)
@@ -860,7 +880,7 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
         v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
     n, channels = xys.size(0), colors.size(1)
     dev = xys.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         # four contiguous tensors carved out of one allocation: the library
         # zero-fills them with a single memset when they are back to back
         zeroed = accumulators is not None and not nd and block_width == 16
@@ -917,7 +937,7 @@ def compute_cov2d_bounds(num_pts: int, cov2d: Tensor) -> Tuple[Tensor, Tensor]:
     _check(cov2d, "cov2d", _f32)
     n = int(num_pts)
     dev = cov2d.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         conics = torch.empty((n, cov2d.size(1)), dtype=_f32, device=dev)
         radii = torch.empty((n, 1), dtype=_f32, device=dev)
         _call("gsr_cov2d_bounds", C.c_int(n), _ptr(cov2d), _ptr(conics), _ptr(radii), _stream(dev))

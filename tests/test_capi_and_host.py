@@ -213,3 +213,38 @@ def test_header_is_plain_c(tmp_path):
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src),
                            "-o", str(tmp_path / "use_header.o")])
+
+
+def test_descriptor_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors of the descriptor structs (`gsr_raster_desc`, `gsr_view_desc`, `gsr_view_grads`) must have
+    the C compiler's size and field offsets: a mismatch would hand the library shifted pointers."""
+    import ctypes as C
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    import rasterizer.cuda as RC
+    from gs_fused.render import _ViewDesc, _ViewGrads
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = (("gsr_raster_desc", RC._RasterDesc), ("gsr_view_desc", _ViewDesc), ("gsr_view_grads", _ViewGrads))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gsraster.h"', "int main(void) {"]
+    for cname, cls in structs:
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    want = {}
+    for line in out.splitlines():
+        s, f, v = line.split()
+        want[(s, f)] = int(v)
+    for cname, cls in structs:
+        assert C.sizeof(cls) == want[(cname, "size")], cname
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == want[(cname, fname)], (cname, fname)

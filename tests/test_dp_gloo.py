@@ -382,3 +382,44 @@ def test_a_rank_without_colour_cotangent_joins_the_gather_with_zeros():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert results[0][1] == results[1][1] == [2.0, 0.0]
+
+
+def _caps_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness import parallel as P
+
+    caps = P.collective_capabilities(None, torch.device("cpu"))
+    again = P.collective_capabilities(None, torch.device("cpu"))
+    # the exchange built on these answers still averages correctly (SUM + one division where AVG is missing)
+    p = torch.zeros(8, 3, requires_grad=True)
+    ex = P.GradientExchange({"means": p}, average=True).attach()
+    (p * float(rank + 1)).sum().backward()
+    ex.finish()
+    q.put((rank, caps, again is caps, ex._avg_in_collective, float(p.grad.mean())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_capabilities_are_probed_once_and_agree_across_ranks():
+    """`collective_capabilities` replaces the try/except around asynchronous collectives: one synchronous probe on a
+    16-byte message when the exchange is constructed.  gloo: no ReduceOp.AVG (so the exchange sums and divides); the
+    answer is cached and the same on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_caps_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, c0, cached0, avg0, g0), (_, c1, cached1, avg1, g1) = results
+    assert c0 == c1 and cached0 and cached1
+    assert c0["avg"] is False and avg0 is False and avg1 is False
+    assert set(c0) == {"avg", "gather_into_tensor", "reduce_scatter_tensor"}
+    assert g0 == g1 == 1.5
