@@ -720,6 +720,13 @@ def main():
     raster_launches = 2 if (args.render_depth and not args.fused_depth) else 1
     staged_fwd, staged_bwd = (int(v) // raster_launches for v in staged.tolist())
 
+    # A full pass of Python's cyclic collector over the ~170 k objects torch leaves tracked takes ~30 ms: inside a
+    # 100-ms timed region that is 0.3 ms per step of pure artefact (tools/exp/gc_frames.py: it decided whether the
+    # forward-only bench read 0.50 or 0.67 ms).  Collect NOW, so that none falls due inside the region; the collector
+    # stays on.
+    import gc
+
+    gc.collect()
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     bracketed_steps = 0
@@ -794,6 +801,7 @@ def main():
             continue
         for _ in range(min(3, args.warmup)):
             step(mode)
+        gc.collect()
         barrier()
         ts = time.perf_counter()
         for _ in range(args.steps):

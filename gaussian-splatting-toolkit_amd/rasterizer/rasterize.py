@@ -175,6 +175,26 @@ def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
     return plan
 
 
+def _two_round_candidate(device, num_points, tile_bounds) -> bool:
+    """(under `_state_lock`; changes nothing) would `_two_round_plan` consider two rounds for this view?  The same
+    switches and thresholds: lists built ahead of time (one round) must not pre-empt them on deep scenes."""
+    mode = os.environ.get("GSR_TWO_ROUND", "auto")
+    if mode in ("0", "off") or os.environ.get("GSR_TILE_SORT", "")[:1] in ("s", "b"):
+        return False
+    hint = _count_hint.get((device, tile_bounds))
+    if hint is None or hint[0] < 1 or hint[1] < 1:
+        return False
+    if _two_hint.get((device, tile_bounds), {}).get("cooldown", 0) > 0:
+        return False
+    if mode == "1":
+        return True
+    tiles = tile_bounds[0] * tile_bounds[1]
+    full = hint[1] * (num_points / hint[0])
+    return not (full / tiles < float(os.environ.get("GSR_TWO_ROUND_DEPTH", "1500"))
+                or full - float(os.environ.get("GSR_TWO_ROUND_LEN", "500")) * tiles < float(os.environ.get("GSR_TWO_ROUND_SAVED", "45e6"))
+                or num_points < 100_000)
+
+
 def _two_round_plan_locked(device, num_points, tile_bounds, mode, asked=False):
     hint = _count_hint.get((device, tile_bounds))
     if hint is None or hint[0] < 1 or hint[1] < 1:
@@ -308,6 +328,9 @@ def _two_round_feedback(plan, c1, c2, unfinished):
     return note
 
 
+_POLL_YIELD = os.environ.get("GSR_POLL_YIELD", "1") != "0"  # (A/B knob: 0 = spin without yielding the GIL)
+
+
 class _PendingCount:
     """One int32 on its way from a kernel to the host: the kernel (`gsr_bin_sorted_dev`'s count, `gsr_publish_int32`)
     writes it straight into pinned (device-mapped) host memory -- no copy operation in the stream -- and `resolve`
@@ -384,7 +407,8 @@ class _PendingCount:
                     raise RuntimeError("rasterize_gaussians: the list count was never published (the launch that "
                                        "writes it did not run; an earlier asynchronous HIP error?)")
                 break
-            time.sleep(0)
+            if _POLL_YIELD:
+                time.sleep(0)
             count = self.peek()
         if count < 0:  # the int32 count wrapped (more than 2^31 - 1 intersections)
             raise RuntimeError("rasterize_gaussians: the number of (Gaussian, tile) intersections does not fit the "
@@ -404,7 +428,12 @@ class _PendingCount:
 # (checked by provenance, the same rule the list cache uses: same storage at the same version, or the same pure op
 # on the same leaf at the same version -- never by hoping) and goes straight to compositing.  Where the opacities
 # cannot be predicted (another recipe, no previous view) only the depth order is built ahead.
-# GSR_SPECULATE=0 switches this off, =sort limits it to the depth order.
+# WHEN: only while the caller is seen to block.  A caller without read-backs keeps the GPU's queue full; there is no
+# idle time to fill, and lists on a second stream merely compete with the SH kernel (bench default: +-0; 200 k
+# Gaussians / dense scales, where nothing is left to overlap with: +8 %).  The signal is the caller's stream itself: if
+# it is IDLE when `rasterize_gaussians` is entered, the host was blocked (or is the bottleneck) and the GPU had
+# nothing to do -- an exponential average of that observation above 1/2 switches the side stream on.
+# GSR_SPECULATE=auto (default) | lists (always) | sort (depth order only, always) | 0 (never).
 _spec = {}
 _UNARY_FN = {"SigmoidBackward0": torch.sigmoid, "ExpBackward0": torch.exp, "TanhBackward0": torch.tanh,
              "AbsBackward0": torch.abs, "NegBackward0": torch.neg}
@@ -413,7 +442,8 @@ _spec_knobs = {}
 
 def _speculation_mode() -> str:
     if not _spec_knobs:
-        _spec_knobs["mode"] = {"0": "0", "off": "0", "sort": "sort"}.get(os.environ.get("GSR_SPECULATE", "lists"), "lists")
+        _spec_knobs["mode"] = {"0": "0", "off": "0", "sort": "sort", "lists": "lists"}.get(
+            os.environ.get("GSR_SPECULATE", "auto"), "auto")
         _spec_knobs["min_points"] = int(os.environ.get("GSR_SPECULATE_MIN", "65536"))
     return _spec_knobs["mode"]
 
@@ -460,14 +490,22 @@ def speculate_lists(xys, depths, radii, conics, num_tiles_hit, img_height, img_w
     with _state_lock:
         st = _spec.setdefault(dev, {"stream": None, "recipe": None, "entry": None})
         recipe = st["recipe"]
-        th = _two_hint.get((dev, tile_bounds))
-        two_recent = th is not None and th.get("count1") is not None and th.get("cooldown", 0) == 0
+        if mode == "auto":
+            if st.get("idle", 1.0) <= 0.5:  # the caller keeps the queue full: nothing to hide work behind
+                return
+            mode = "lists"
+        # deep scenes take two-round lists, whose first launch writes the reach records while
+        # it sorts: nothing is built ahead there (a ready-made order would cost them a records launch of their own:
+        # 3 M Gaussians at 4K, 2.71 -> 2.76 ms)
+        two_recent = _two_round_candidate(dev, n, tile_bounds)
+    if two_recent:
+        return
     if st["stream"] is None:
         st["stream"] = torch.cuda.Stream(dev)
     side, main = st["stream"], torch.cuda.current_stream(dev)
     opacity_src = osig = None
     capacity = None
-    if mode == "lists" and recipe is not None and not two_recent:
+    if mode == "lists" and recipe is not None:
         if recipe[0] == "same":
             t = recipe[1]()
             if t is not None and t.is_cuda and t.numel() == n and t.dtype == torch.float32 and t.is_contiguous():
@@ -673,6 +711,12 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     order_ready = None
     if exact:
         _note_opacity_recipe(xys.device, opacity)
+        if _speculation_mode() == "auto" and num_points >= _spec_knobs["min_points"]:
+            # was the GPU out of work when the caller got here?  (see "WHEN" above)
+            idle = 1.0 if torch.cuda.current_stream(xys.device).query() else 0.0
+            with _state_lock:
+                st = _spec.setdefault(xys.device, {"stream": None, "recipe": None, "entry": None})
+                st["idle"] = 0.75 * st.get("idle", 1.0) + 0.25 * idle
         ahead = _take_speculation(xys.device, key)
         if ahead is not None:
             main = torch.cuda.current_stream(xys.device)

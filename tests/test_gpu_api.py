@@ -269,8 +269,10 @@ def test_random_view_sequences_equal_unspeculated_calls():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (GSR_SPECULATE=lists: lists are built ahead of time on the side stream whenever the opacities are predictable,
+    # not only while the caller is seen to block -- the fuzz must cover that path on every call)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_sequence.py"), "80", "17"],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, GSR_SPECULATE="lists"))
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count(": ok") == 80
 

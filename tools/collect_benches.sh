@@ -34,7 +34,7 @@ run longtail $Q --scene longtail
 run deterministic $Q --deterministic
 # a TRAINED distribution: the config-3 model after its 7 000 iterations, exported as `gs-export gaussian-splat`
 # writes it, benched forward + backward from a training view (counter passes on: per-kernel traffic)
-timeout 900 python - "$OUT/config3_trained.ply" <<'PY'
+timeout 900 python - /tmp/config3_trained.ply <<'PY'
 import os, sys
 sys.path[:0] = [os.environ.get("GRAFT_REPO_ROOT", "."), os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gaussian-splatting-toolkit_amd")]
 import torch, bench
@@ -44,4 +44,4 @@ cfg.export_ply, cfg.phase_every, cfg.log_every = sys.argv[1], 0, 0
 r = train(cfg, torch.device("cuda", 0))
 print("exported", sys.argv[1], "N", r["num_gaussians_end"], "psnr", r["psnr_end"], "it/s", r["iters_per_s"])
 PY
-run trained $P --scene "ply:$OUT/config3_trained.ply" --ply-cam-radius 5.0 --ply-view 3
+run trained $P --scene "ply:/tmp/config3_trained.ply" --ply-cam-radius 5.0 --ply-view 3

@@ -21,7 +21,7 @@ cp "$(find /tmp/prof_kt -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kerne
 python "$ROOT/tools/step_seq.py" /tmp/prof_kt "$OUT/${TAG}_step_sequence.txt"
 # the same step with the unchanged models' two host read-backs in the caller (vanilla_gs.py:784,811): where the GPU
 # idles, with the tile lists built ahead of time on the side stream (default) and without (GSR_SPECULATE=0)
-for SP in lists 0; do
+for SP in auto 0; do
   rm -rf /tmp/prof_sync
   GSR_SPECULATE=$SP timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_sync -- $BENCH --steps 20 --warmup 5 --caller-syncs on --no-synced-regions > "$OUT/prof_sync_$SP.log" 2>&1
   python "$ROOT/tools/step_seq.py" /tmp/prof_sync "$OUT/${TAG}_step_sequence_caller_syncs_speculate_$SP.txt"

@@ -63,11 +63,14 @@ def step(record):
 
 for _ in range(20):
     step(False)
+import gc
+
+gc.collect()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     step(True)
 torch.cuda.synchronize()
 total = (time.perf_counter() - t0) / steps * 1e6
-print(f"mode {mode} GSR_SPECULATE={os.environ.get('GSR_SPECULATE', 'lists')}: {total:.1f} us per step; host us per phase: "
+print(f"mode {mode} GSR_SPECULATE={os.environ.get('GSR_SPECULATE', 'auto')}: {total:.1f} us per step; host us per phase: "
       + ", ".join(f"{n} {a / steps * 1e6:.1f}" for n, a in zip(names, acc)) + f"; counters {R.counters}")

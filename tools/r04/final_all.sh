@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 1500 python -m pytest tests -m gpu -q --timeout 420 > gpurun_out/r04_pytest_gpu_final.log 2>&1; echo "pytest rc $?"; tail -6 gpurun_out/r04_pytest_gpu_final.log
+timeout 1500 python -m pytest tests -m gpu -q --timeout 420 > gpurun_out/r04_pytest_gpu_final.log 2>&1; echo "pytest rc $?"; tail -4 gpurun_out/r04_pytest_gpu_final.log
 bash tools/r04/final.sh
+du -sh gpurun_out

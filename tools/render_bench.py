@@ -65,6 +65,9 @@ def main():
 
     for k in range(20):
         out = frame(k)
+    import gc
+
+    gc.collect()  # (a full collection falling into a 100-ms timed loop costs 0.15 ms per frame: tools/exp/gc_frames.py)
     torch.cuda.synchronize()
     t = time.perf_counter()
     for k in range(a.frames):
