@@ -675,6 +675,26 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
     return ids, bins, img, Ts, idx, alpha
 
 
+def composite_prepared(tile_bounds, img_width: int, img_height: int, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                       opacities, background, out_img, planes, want_alpha: bool, zero=None):
+    """``gsr_rasterize_forward_ex`` into caller-owned outputs, for callers that have validated their tensors and
+    allocated ``out_img`` [H,W,3] and ``planes`` [3,H,W] (final_Ts | final_idx as int32 | alpha) ahead of time: the
+    shortest host path to the compositing launch (rasterize.py, "lists built ahead of time")
+    -> (out_img, final_Ts, final_idx, alpha or None)."""
+    dev = xys.device
+    Ts, idx = planes[0], planes[1].view(_i32)
+    alpha = planes[2] if want_alpha else None
+    zero_bytes = zero.numel() * 4 if zero is not None else 0
+    with _on(dev):
+        _call("gsr_rasterize_forward_ex", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(16),
+              C.c_uint(int(img_width)), C.c_uint(int(img_height)), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys),
+              _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(background), _ptr(out_img), _ptr(Ts), _ptr(idx),
+              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])),
+              _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero_bytes else None, C.c_size_t(zero_bytes),
+              _stream(dev))
+    return out_img, Ts, idx, alpha
+
+
 def rasterize_forward_ex(tile_bounds, block, img_size, gaussian_ids_sorted, tile_bins, xys, conics,
                          colors, opacities, background, want_alpha=False, zero=None):
     """``gsr_rasterize_forward_ex`` (16x16 tiles, 3 channels): -> (out_img, final_Ts, final_idx, alpha or None);

@@ -519,6 +519,12 @@ def speculate_lists(xys, depths, radii, conics, num_tiles_hit, img_height, img_w
             capacity = _speculative_capacity(dev, n, tile_bounds, True)
     key = _geometry_key(xys, depths, radii, num_tiles_hit, img_height, img_width, block_width)
     entry = {"key": key, "keep": (xys, depths, radii, num_tiles_hit, conics)}
+    if opacity_src is not None and capacity is not None:
+        # the compositing's outputs, allocated NOW (on the caller's stream): four allocations less between the
+        # models' second read-back and the compositing launch
+        with torch.cuda.device(dev):
+            entry["outs"] = (torch.empty((img_height, img_width, 3), dtype=torch.float32, device=dev),
+                             torch.empty((3, img_height, img_width), dtype=torch.float32, device=dev))
     side.wait_stream(main)  # behind the projection (and whatever the caller queued before it)
     with torch.no_grad(), torch.cuda.stream(side):
         if opacity_src is not None and capacity is not None:
@@ -666,6 +672,7 @@ class FusedForward:
         self.colors, self.background, self.want_alpha, self.zero = colors, background, want_alpha, zero
         self.img_size = (img_width, img_height)
         self.outputs = None
+        self.prealloc = None  # (out_img, planes) allocated ahead of time, when the lists were
 
 
 def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width,
@@ -711,7 +718,8 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     order_ready = None
     if exact:
         _note_opacity_recipe(xys.device, opacity)
-        if _speculation_mode() == "auto" and num_points >= _spec_knobs["min_points"]:
+        if _speculation_mode() == "auto" and num_points >= _spec_knobs["min_points"] and \
+                not torch.cuda.is_current_stream_capturing():
             # was the GPU out of work when the caller got here?  (see "WHEN" above)
             idle = 1.0 if torch.cuda.current_stream(xys.device).query() else 0.0
             with _state_lock:
@@ -725,7 +733,11 @@ def build_tile_lists(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
                 # this view's lists were built on the side stream while the caller was busy (or blocked)
                 counters["ahead_hits"] += 1
                 ids, bins, pending, capacity = ahead["ids"], ahead["bins"], ahead["pending"], ahead["capacity"]
-                ids.record_stream(main), bins.record_stream(main)
+                # (ids / bins come from the side stream's pool and are read on the caller's: no `record_stream` --
+                # memory goes back to that pool only when autograd drops them, and the pool hands it out again only
+                # inside `speculate_lists`, behind `side.wait_stream(main)`)
+                if fuse is not None:
+                    fuse.prealloc = ahead.get("outs")
 
                 def finish_ahead():
                     num_intersects = pending.resolve()
@@ -936,6 +948,15 @@ class _RasterizeGaussians(Function):
         def composite(ids, bins):
             if not fused:
                 return rasterize_fn(tile_bounds, block, img_size, ids, bins, xys, conics, colors, opacity, background)
+            if fuse.prealloc is not None:  # lists AND output buffers were made ahead of time: straight to the launch
+                (img0, planes), fuse.prealloc = fuse.prealloc, None
+                if colors.dtype == torch.float32 and background.dtype == torch.float32 and opacity.dtype == torch.float32 \
+                        and colors.size(0) == xys.size(0) and opacity.numel() == xys.size(0) and background.numel() == 3 \
+                        and colors.device == xys.device and background.device == xys.device:
+                    img, Ts, idx, alpha_out[0] = _C.composite_prepared(
+                        tile_bounds, img_width, img_height, ids, bins, xys, conics, colors, opacity, background, img0,
+                        planes, return_alpha, zero=acc)
+                    return img, Ts, idx
             img, Ts, idx, alpha_out[0] = _C.rasterize_forward_ex(tile_bounds, block, img_size, ids, bins, xys, conics,
                                                                  colors, opacity, background, want_alpha=return_alpha,
                                                                  zero=acc)
