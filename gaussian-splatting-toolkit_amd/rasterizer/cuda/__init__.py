@@ -100,13 +100,13 @@ def project_gaussians_forward(
     dev = means3d.device
     _opt0 = lambda t: None if t is None else _ptr(t)
     with _on(dev):
-        cov3d = cov3d_precomp if precomp else torch.empty((n, 6), dtype=_f32, device=dev)
-        xys = torch.empty((n, 2), dtype=_f32, device=dev)
-        depths = torch.empty((n,), dtype=_f32, device=dev)
-        radii = torch.empty((n,), dtype=_i32, device=dev)
-        conics = torch.empty((n, 3), dtype=_f32, device=dev)
-        compensation = torch.empty((n,), dtype=_f32, device=dev)
-        num_tiles_hit = torch.empty((n,), dtype=_i32, device=dev)
+        # one allocation, seven outputs (15 words per Gaussian; all of them live until the backward anyway): six
+        # allocator round trips less per view
+        flat = torch.empty((n * (9 if precomp else 15),), dtype=_f32, device=dev)
+        parts = flat.split([2 * n, n, n, 3 * n, n, n] + ([] if precomp else [6 * n]))
+        xys, depths, conics, compensation = parts[0].view(n, 2), parts[1], parts[3].view(n, 3), parts[4]
+        radii, num_tiles_hit = parts[2].view(_i32), parts[5].view(_i32)
+        cov3d = cov3d_precomp if precomp else parts[6].view(n, 6)
         _call(
             "gsr_project_forward", C.c_int(n), _ptr(means3d), _opt0(scales), _cf(glob_scale),
             _opt0(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
@@ -122,17 +122,21 @@ def project_gaussians_backward(
     viewmat: Tensor, projmat: Tensor, fx: float, fy: float, cx: float, cy: float,
     img_height: int, img_width: int, cov3d: Tensor, radii: Tensor, conics: Tensor,
     compensation: Tensor, v_xy: Tensor, v_depth: Tensor, v_conic: Tensor, v_compensation: Tensor,
+    trusted: bool = False,
 ) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     """-> (v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat);
-    replaces ``project_gaussians_backward_tensor`` (bindings.cu:164-216)."""
+    replaces ``project_gaussians_backward_tensor`` (bindings.cu:164-216).  ``trusted``: the first sixteen arguments
+    are the tensors a forward call of this module validated and produced (what the autograd node passes back): only
+    the cotangents are checked."""
     n = int(num_points)
     dev = means3d.device
     precomp = scales is None and quats is None  # covariances were handed in: the chain ends at v_cov3d
-    for t, nm in ((means3d, "means3d"), (viewmat, "viewmat"),
-                  (projmat, "projmat"), (cov3d, "cov3d"), (conics, "conics"),
-                  (compensation, "compensation")) + (() if precomp else ((scales, "scales"), (quats, "quats"))):
-        _check(t, nm, _f32)
-    _check(radii, "radii", _i32)
+    if not trusted:
+        for t, nm in ((means3d, "means3d"), (viewmat, "viewmat"),
+                      (projmat, "projmat"), (cov3d, "cov3d"), (conics, "conics"),
+                      (compensation, "compensation")) + (() if precomp else ((scales, "scales"), (quats, "quats"))):
+            _check(t, nm, _f32)
+        _check(radii, "radii", _i32)
     # cotangents may arrive non-contiguous / expanded from autograd; None = zero
     v_xy, v_depth, v_conic, v_compensation = (
         None if t is None else _check(t.contiguous(), nm, _f32)
@@ -141,11 +145,11 @@ def project_gaussians_backward(
     )
     _opt = lambda t: None if t is None else _ptr(t)
     with _on(dev):
-        v_cov2d = torch.empty((n, 3), dtype=_f32, device=dev)
-        v_cov3d = torch.empty((n, 6), dtype=_f32, device=dev)
-        v_mean3d = torch.empty((n, 3), dtype=_f32, device=dev)
-        v_scale = None if precomp else torch.empty((n, 3), dtype=_f32, device=dev)
-        v_quat = None if precomp else torch.empty((n, 4), dtype=_f32, device=dev)
+        flat = torch.empty((n * (12 if precomp else 19),), dtype=_f32, device=dev)  # one allocation, five outputs
+        parts = flat.split([3 * n, 6 * n, 3 * n] + ([] if precomp else [3 * n, 4 * n]))
+        v_cov2d, v_cov3d, v_mean3d = parts[0].view(n, 3), parts[1].view(n, 6), parts[2].view(n, 3)
+        v_scale = None if precomp else parts[3].view(n, 3)
+        v_quat = None if precomp else parts[4].view(n, 4)
         _call(
             "gsr_project_backward", C.c_int(n), _ptr(means3d), _opt(scales), _cf(glob_scale),
             _opt(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
@@ -179,14 +183,15 @@ def compute_sh_forward(num_points: int, degree: int, degrees_to_use: int, viewdi
 
 
 def compute_sh_backward(num_points: int, degree: int, degrees_to_use: int, viewdirs: Tensor,
-                        v_colors: Tensor) -> Tensor:
+                        v_colors: Tensor, trusted: bool = False) -> Tensor:
     """-> v_coeffs [N,K,3]; replaces ``compute_sh_backward_tensor`` (bindings.cu:79-103)."""
     n = int(num_points)
     if viewdirs.dim() != 2 or viewdirs.size(0) != n or viewdirs.size(1) != 3:
         raise RuntimeError("viewdirs must have dimensions (N, 3)")
     if v_colors.dim() != 2 or v_colors.size(0) != n or v_colors.size(1) != 3:
         raise RuntimeError("v_colors must have dimensions (N, 3)")
-    _check(viewdirs, "viewdirs", _f32)
+    if not trusted:  # (trusted: `viewdirs` is the tensor the forward call validated)
+        _check(viewdirs, "viewdirs", _f32)
     v_colors = _check(v_colors.contiguous(), "v_colors", _f32)
     dev = viewdirs.device
     with _on(dev):
@@ -889,12 +894,13 @@ def backward_accumulators(n: int, channels: int, device) -> Tensor:
 
 def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
                         conics, colors, opacities, background, final_Ts, final_idx, v_output,
-                        v_output_alpha, nd: bool, accumulators: Optional[Tensor] = None):
-    _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
-    if not nd and colors.size(1) != 3:
-        raise RuntimeError("colors must have 2 dimensions")  # message of bindings.cu:494-496
-    _check(final_Ts, "final_Ts", _f32)
-    _check(final_idx, "final_idx", _i32)
+                        v_output_alpha, nd: bool, accumulators: Optional[Tensor] = None, trusted: bool = False):
+    if not trusted:  # (trusted: everything but the two cotangents went through the forward's checks)
+        _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, background)
+        if not nd and colors.size(1) != 3:
+            raise RuntimeError("colors must have 2 dimensions")  # message of bindings.cu:494-496
+        _check(final_Ts, "final_Ts", _f32)
+        _check(final_idx, "final_idx", _i32)
     v_output = _check(v_output.contiguous(), "v_output", _f32)
     if v_output_alpha is not None:  # None = zero cotangent for the alpha output
         v_output_alpha = _check(v_output_alpha.contiguous(), "v_output_alpha", _f32)
@@ -933,13 +939,13 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
 
 def rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,
                        conics, colors, opacities, background, final_Ts, final_idx, v_output,
-                       v_output_alpha, accumulators: Optional[Tensor] = None):
+                       v_output_alpha, accumulators: Optional[Tensor] = None, trusted: bool = False):
     """-> (v_xy, v_conic, v_colors, v_opacity [N,1]);
     replaces ``rasterize_backward_tensor`` (bindings.cu:476-528).  ``accumulators``: a
     :func:`backward_accumulators` buffer already cleared by :func:`rasterize_forward_ex`."""
     return _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins,
                                xys, conics, colors, opacities, background, final_Ts, final_idx,
-                               v_output, v_output_alpha, nd=False, accumulators=accumulators)
+                               v_output, v_output_alpha, nd=False, accumulators=accumulators, trusted=trusted)
 
 
 def nd_rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted, tile_bins, xys,

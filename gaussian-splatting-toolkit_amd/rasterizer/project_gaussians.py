@@ -54,7 +54,7 @@ class _ProjectGaussians(Function):
         n, glob_scale, fx, fy, cx, cy, img_height, img_width = ctx.static
         grads = _C.project_gaussians_backward(
             n, means3d, scales, glob_scale, quats, viewmat, projmat, fx, fy, cx, cy, img_height, img_width,
-            cov3d, radii, conics, compensation, g_xys, g_depths, g_conics, g_compensation)
+            cov3d, radii, conics, compensation, g_xys, g_depths, g_conics, g_compensation, trusted=True)
         g_means, g_scales, g_quats = grads[2:]  # (v_cov2d, v_cov3d) come first and stay internal
         # slots: means3d, scales, glob_scale, quats, then the ten camera / image arguments
         return (g_means, g_scales, None, g_quats) + (None,) * 10

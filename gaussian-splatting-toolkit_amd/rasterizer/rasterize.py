@@ -1073,7 +1073,7 @@ class _RasterizeGaussians(Function):
                     v_xy, v_conic, v_colors, v_opacity = _C.rasterize_backward(
                         ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
                         conics, colors, opacity, background, final_Ts, final_idx, v_out_img, v_out_alpha,
-                        accumulators=acc)
+                        accumulators=acc, trusted=True)
                 else:
                     v_xy, v_conic, v_colors, v_opacity = _C.nd_rasterize_backward(
                         ctx.img_height, ctx.img_width, ctx.block_width, gaussian_ids_sorted, tile_bins, xys,
