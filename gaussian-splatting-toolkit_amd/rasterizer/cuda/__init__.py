@@ -61,6 +61,18 @@ def _on(dev):
     return _ALREADY if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
 
 
+def _carve(sizes, dev):
+    """One float32 allocation cut into 1-D pieces of `sizes` elements, each starting on a 256-byte boundary (what a
+    separate `torch.empty` would give: the kernels read rows as float2 / float4) -- one allocator round trip
+    instead of len(sizes)."""
+    offs, total = [], 0
+    for sz in sizes:
+        offs.append(total)
+        total += (int(sz) + 63) & ~63
+    flat = torch.empty((max(total, 1),), dtype=_f32, device=dev)
+    return [flat[o:o + int(sz)] for o, sz in zip(offs, sizes)]
+
+
 def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -102,8 +114,7 @@ def project_gaussians_forward(
     with _on(dev):
         # one allocation, seven outputs (15 words per Gaussian; all of them live until the backward anyway): six
         # allocator round trips less per view
-        flat = torch.empty((n * (9 if precomp else 15),), dtype=_f32, device=dev)
-        parts = flat.split([2 * n, n, n, 3 * n, n, n] + ([] if precomp else [6 * n]))
+        parts = _carve([2 * n, n, n, 3 * n, n, n] + ([] if precomp else [6 * n]), dev)
         xys, depths, conics, compensation = parts[0].view(n, 2), parts[1], parts[3].view(n, 3), parts[4]
         radii, num_tiles_hit = parts[2].view(_i32), parts[5].view(_i32)
         cov3d = cov3d_precomp if precomp else parts[6].view(n, 6)
@@ -145,8 +156,7 @@ def project_gaussians_backward(
     )
     _opt = lambda t: None if t is None else _ptr(t)
     with _on(dev):
-        flat = torch.empty((n * (12 if precomp else 19),), dtype=_f32, device=dev)  # one allocation, five outputs
-        parts = flat.split([3 * n, 6 * n, 3 * n] + ([] if precomp else [3 * n, 4 * n]))
+        parts = _carve([3 * n, 6 * n, 3 * n] + ([] if precomp else [3 * n, 4 * n]), dev)  # one allocation, five outputs
         v_cov2d, v_cov3d, v_mean3d = parts[0].view(n, 3), parts[1].view(n, 6), parts[2].view(n, 3)
         v_scale = None if precomp else parts[3].view(n, 3)
         v_quat = None if precomp else parts[4].view(n, 4)
