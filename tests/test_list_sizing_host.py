@@ -1,0 +1,86 @@
+"""CPU: the host-side state machine that sizes the tile lists without reading the count back (rasterizer/rasterize.py:
+`_speculative_capacity`, the two-round plan and its culled-count hand-shake, `_two_round_candidate`).  Pure Python --
+no kernel runs; the device is only a dictionary key here."""
+import pytest
+import torch
+
+from rasterizer import rasterize as R
+
+DEV = torch.device("cpu")  # (a key)
+TB = (120, 68, 1)          # 1920 x 1080 at 16 px
+
+
+@pytest.fixture(autouse=True)
+def clean_state(monkeypatch):
+    for d in (R._count_hint, R._last_capacity, R._two_hint):
+        d.clear()
+    for k in ("GSR_NO_SPECULATION", "GSR_TILE_SORT", "GSR_TWO_ROUND", "GSR_TWO_ROUND_DEPTH", "GSR_TWO_ROUND_LEN",
+              "GSR_TWO_ROUND_SAVED"):
+        monkeypatch.delenv(k, raising=False)
+    yield
+    for d in (R._count_hint, R._last_capacity, R._two_hint):
+        d.clear()
+
+
+def test_capacity_comes_from_the_previous_view_with_headroom_and_stays_put():
+    assert R._speculative_capacity(DEV, 1_000_000, TB, True) is None           # no view yet: the exact path
+    R._note_count(DEV, 1_000_000, TB, 4_459_433)
+    cap = R._speculative_capacity(DEV, 1_000_000, TB, True)
+    assert cap >= int(1.25 * 4_459_433) and cap % (1 << 20) == 0                  # 25 % + rounding to whole Mi
+    R._note_count(DEV, 1_000_000, TB, 4_300_000)                                   # a slightly smaller view:
+    assert R._speculative_capacity(DEV, 1_000_000, TB, True) == cap                # ... the buffers keep their size
+    R._note_count(DEV, 1_000_000, TB, 1_500_000)                                   # the need more than halves: shrink
+    assert R._speculative_capacity(DEV, 1_000_000, TB, True) < cap
+    small = R._speculative_capacity(DEV, 1_000_000, TB, True)
+    R._last_capacity.clear()
+    assert R._speculative_capacity(DEV, 2_000_000, TB, True) > small               # the guess scales with N
+    R._note_count(DEV, 1_000_000, TB, 2**31 - 10)
+    assert R._speculative_capacity(DEV, 1_000_000, TB, True) is None                # would not fit int32 lists
+
+
+def test_no_speculation_switch(monkeypatch):
+    R._note_count(DEV, 1_000_000, TB, 4_000_000)
+    monkeypatch.setenv("GSR_NO_SPECULATION", "1")
+    assert R._speculative_capacity(DEV, 1_000_000, TB, True) is None
+
+
+def test_two_round_candidates_are_deep_scenes_only():
+    tiles = TB[0] * TB[1]
+    R._note_count(DEV, 1_000_000, TB, 4_459_433)                 # the bench default: 547 entries per tile
+    assert not R._two_round_candidate(DEV, 1_000_000, TB)
+    R._note_count(DEV, 3_000_000, TB, 33_000_000)                # deep, but too little to save (break-even ~45 M)
+    assert not R._two_round_candidate(DEV, 3_000_000, TB)
+    big = (240, 135, 1)
+    R._note_count(DEV, 3_000_000, big, 97_700_000)               # config 5: 3 M Gaussians at 4K
+    assert R._two_round_candidate(DEV, 3_000_000, big)
+    R._two_hint[(DEV, big)] = {"cooldown": 7}                    # the filter dropped too little last time
+    assert not R._two_round_candidate(DEV, 3_000_000, big)
+    assert tiles == 8160
+
+
+def test_two_round_plan_asks_for_the_culled_count_once_and_then_plans(monkeypatch):
+    big = (240, 135, 1)
+    R._note_count(DEV, 3_000_000, big, 97_700_000)
+    # first candidate view: the plan needs the number of culled Gaussians, which travels through a pinned slot
+    assert R._two_round_plan_locked(DEV, 3_000_000, big, "auto") == "count_culled"
+
+    class Arrived:  # the slot, once the publishing kernel has run
+        def peek(self):
+            return 600_000
+
+    R._two_hint[(DEV, big)]["culled_pending"] = (Arrived(), 3_000_000)
+    plan = R._two_round_plan_locked(DEV, 3_000_000, big, "auto")
+    assert isinstance(plan, dict) and R._two_hint[(DEV, big)]["culled_frac"] == pytest.approx(0.2)
+    assert plan["n1"] > 600_000 and plan["n1"] % 256 == 0        # the prefix starts BEHIND the culled Gaussians
+    assert plan["cap1"] % (1 << 20) == 0 and plan["cap2"] % (1 << 20) == 0 and plan["cap1"] + plan["cap2"] < 2**31 - 1
+    # feedback of a view whose round 1 left nothing unfinished: the prefix is steered towards ~500 entries per tile
+    note = R._two_round_feedback(plan, c1=16_000_000, c2=0, unfinished=0)
+    assert note is None and R._two_hint[(DEV, big)]["count1"] == 16_000_000 and R._two_hint[(DEV, big)]["fails"] == 0
+    # ... and of one where nothing saturated: single rounds for a while, sized from the full count
+    note = R._two_round_feedback(plan, c1=30_000_000, c2=60_000_000, unfinished=20_000)
+    assert note == 90_000_000 and R._two_hint[(DEV, big)]["cooldown"] >= 50
+    assert R._two_round_plan_locked(DEV, 3_000_000, big, "auto") is None   # cooling down
+
+
+def test_cached_two_segment_lists_are_a_miss_for_a_single_segment_caller():
+    assert R._is_two(("two", object(), 123)) and not R._is_two(None) and not R._is_two((1, 2, 3))
