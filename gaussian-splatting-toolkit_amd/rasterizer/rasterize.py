@@ -430,7 +430,7 @@ class _PendingCount:
 # cannot be predicted (another recipe, no previous view) only the depth order is built ahead.
 # WHEN: only while the caller is seen to block.  A caller without read-backs keeps the GPU's queue full; there is no
 # idle time to fill, and lists on a second stream merely compete with the SH kernel (bench default: +-0; 200 k
-# Gaussians / dense scales, where nothing is left to overlap with: +8 %).  The signal is the caller's stream itself: if
+# Gaussians / dense scales, where nothing is left to overlap with: +3 %).  The signal is the caller's stream itself: if
 # it is IDLE when `rasterize_gaussians` is entered, the host was blocked (or is the bottleneck) and the GPU had
 # nothing to do -- an exponential average of that observation above 1/2 switches the side stream on.
 # GSR_SPECULATE=auto (default) | lists (always) | sort (depth order only, always) | 0 (never).
@@ -492,6 +492,9 @@ def speculate_lists(xys, depths, radii, conics, num_tiles_hit, img_height, img_w
         recipe = st["recipe"]
         if mode == "auto":
             if st.get("idle", 1.0) <= 0.5:  # the caller keeps the queue full: nothing to hide work behind
+                stale, st["entry"], st["retired"] = st["entry"], None, None  # (an entry nobody took: let go of its tensors)
+                if stale is not None:
+                    torch.cuda.current_stream(dev).wait_event(stale["done"])
                 return
             mode = "lists"
         # deep scenes take two-round lists, whose first launch writes the reach records while
