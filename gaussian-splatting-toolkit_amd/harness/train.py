@@ -99,11 +99,12 @@ def downscale_image(image: torch.Tensor, d: int) -> torch.Tensor:
 
 
 def composite_with_background(image: torch.Tensor, background: torch.Tensor) -> torch.Tensor:
-    """vanilla_gs.py:870-881: a ground-truth image with an alpha channel is composited over the step's background."""
-    if image.shape[2] == 4:
-        alpha = image[..., -1].unsqueeze(-1).repeat((1, 1, 3))
-        return alpha * image[..., :3] + (1 - alpha) * background
-    return image
+    """What the models do with a ground-truth image that carries an alpha channel (vanilla_gs.py:870-881): straight
+    colour over the step's background, `a * rgb + (1 - a) * background`; an RGB image is returned as it is."""
+    if image.shape[-1] != 4:
+        return image
+    rgb, a = image[..., :3], image[..., 3:4]
+    return a * rgb + (1.0 - a) * background
 
 
 def blob_scene(n: int, seed: int, sh_degree: int = 3, extent: float = 1.5, scale_lo=0.01, scale_hi=0.06,
