@@ -35,6 +35,9 @@ def main():
         n, cu(sc["means3d"]), cu(sc["scales"]), 1.0, cu(sc["quats"]), cu(cam.viewmat[:3]), cu(cam.projmat),
         cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16, 0.01)
     opac = cu(sc["opacities"])
+    if os.environ.get("SORTED"):  # bound of what records in depth order could buy: order == identity
+        perm = torch.argsort(torch.where(radii > 0, depths, torch.full_like(depths, -1.0)), stable=True)
+        xys, depths, radii, conics, opac, tiles = (t[perm].contiguous() for t in (xys, depths, radii, conics, opac, tiles))
     print("reference intersections", int(tiles.sum().item()), "visible", int((radii > 0).sum().item()))
     tb = ((W + 15) // 16, (H + 15) // 16, 1)
 
