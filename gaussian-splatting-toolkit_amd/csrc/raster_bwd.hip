@@ -238,7 +238,17 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
   if (RGBD) v_extra[g] = acc[9];
 }
 
-template <int G, bool RGBD>
+// ---- depth segments -------------------------------------------------------------------
+// A deep tile's walk is a serial chain; on a grid that cannot fill the chip (480 x 270 is 510 tiles) the kernel lasts as
+// long as its deepest tile.  The backward's per-pixel state is two scalars (T, K) and a run of list entries maps it
+// affinely:  T_out = T_in R,  K_out = K_in - T_in S  with R the product of the run's `ra` and S the sum of
+// alpha rho (rgb . v_out), rho the running product inside the run.  So a deep tile's list is cut into `seg_count`
+// segments: a PRE-PASS (raster_bwd_segstate_kernel) computes (R, S) per pixel for segments 1 .. seg_count - 1 in
+// parallel, and the main kernel runs one wave per (tile, sub-tile, segment): segment k applies the maps of the
+// segments behind it to (T_final, K_0) and walks only its own entries.  Same per-entry arithmetic; T reaches a
+// segment as a product of segment products instead of one chain: equal to the single walk to rounding, not bitwise.
+
+template <int G, bool RGBD, bool SEG = false>
 __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
@@ -251,7 +261,8 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const float *__restrict__ extra, const float bg_extra, const float *__restrict__ v_out_extra,
     float *__restrict__ v_extra, const int deep_threshold, const unsigned base_grid,
     float *__restrict__ partials, unsigned char *__restrict__ pflags, const int2 *__restrict__ tile_bins2,
-    const int idx_base2) {
+    const int idx_base2, const int seg_count = 1, const int seg_min = 0,
+    const float2 *__restrict__ seg_state = nullptr) {
   // tile_bins2 (two-round lists, gsr_rasterize_forward_round): a tile's list is its range in tile_bins followed by
   // its range in tile_bins2 (relative to idx_base2 in ids_sorted): walked back to front, second segment first.
   static_assert(!RGBD || G == 4, "the 10-component butterfly exists for groups of 4");
@@ -263,9 +274,28 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   using BF = Butterfly<G>;
 
   int2 range = make_int2(0, 0);
-  const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
+  unsigned blk = blockIdx.x;
+  int seg_k = 0;
+  if constexpr (SEG) {  // block = segment * (4 base_grid) + the block of the unsegmented launch
+    seg_k = (int)(blk / (4u * base_grid));
+    blk -= (unsigned)seg_k * (4u * base_grid);
+  }
+  const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile, allowed = job.allowed;  // allowed: the sub-tiles this wave owns (raster_common.h)
   if (tile < 0) return;
+  int seg_behind = 0;  // segments behind this one whose maps are applied first
+  if constexpr (SEG) {
+    const int len = range.y - range.x;
+    if (allowed == 15 || len <= seg_min) {  // not a deep tile: one walk, by segment 0's block
+      if (seg_k > 0) return;
+    } else {
+      const int sl = seg_len_of(len, seg_count), first = range.x;
+      seg_behind = min(seg_count, (len + sl - 1) / sl) - 1 - seg_k;
+      if (seg_behind < 0) return;
+      range.x = first + seg_k * sl;
+      range.y = min(range.x + sl, range.y);
+    }
+  }
   int2 range2 = make_int2(0, 0);
   if (tile_bins2) {
     range2 = tile_bins2[tile];
@@ -327,6 +357,20 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
                     : Tf * ((v_output_alpha ? in_a[p] : 0.f) -
                             (bg0 * vr[p] + bg1 * vg[p] + bg2 * vb[p] + (RGBD ? bg_extra * ve[p] : 0.f)));
       binf[p] = drawn ? in_idx[p] : -1;
+    }
+  }
+  if constexpr (SEG) {  // the state behind this segment: the maps of the segments after it, farthest first
+    const size_t pixels = (size_t)img_w * img_h;
+    for (int j = seg_k + seg_behind; j > seg_k; --j) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+        if (in_img[p]) {
+          const float2 st = seg_state[(size_t)(j - 1) * pixels + (size_t)row * img_w + col];
+          K[p] -= T[p] * st.y;
+          T[p] *= st.x;
+        }
+      }
     }
   }
   // last sorted index any pixel of sub-tile p still needs (wave-uniform)
@@ -470,6 +514,105 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     }
     __syncthreads();
   }
+  }
+}
+
+// The pre-pass of the depth segments: (R, S) of segment seg_k = 1 + block / (4 base_grid) for every pixel of a deep
+// tile's sub-tile -> seg_state[(seg_k - 1) pixels + pixel].  Same staging, same sigma / alpha / validity expressions as
+// the walk above; no gradients.
+__global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h,
+    const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
+    const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities,
+    const float *__restrict__ final_Ts, const int *__restrict__ final_idx, const float *__restrict__ v_output,
+    const int deep_threshold, const unsigned base_grid, const int seg_count, const int seg_min,
+    float2 *__restrict__ seg_state) {
+  __shared__ SplatA sA[kChunk];
+  __shared__ SplatB sB[kChunk];
+  __shared__ SplatC sC[kChunk];
+  int2 range = make_int2(0, 0);
+  unsigned blk = blockIdx.x;
+  const int seg_k = 1 + (int)(blk / (4u * base_grid));
+  blk -= (unsigned)(seg_k - 1) * (4u * base_grid);
+  const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
+  const int tile = job.tile, allowed = job.allowed;
+  if (tile < 0) return;
+  const int len = range.y - range.x;
+  if (allowed == 15 || len <= seg_min) return;
+  const int sl = seg_len_of(len, seg_count);
+  if (seg_k >= min(seg_count, (len + sl - 1) / sl)) return;
+  range.x += seg_k * sl;
+  range.y = min(range.x + sl, range.y);
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int lane = threadIdx.x;
+  const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
+  const float fx0 = (float)qx, fx1 = (float)(qx + 8);
+  const float fy0 = (float)qy, fy1 = (float)(qy + 8);
+  const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
+
+  float rho[4], S[4], vr[4], vg[4], vb[4];
+  int binf[4];
+  bool in_img[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+    in_img[p] = col < img_w && row < img_h && ((allowed >> p) & 1);
+    const size_t pid = in_img[p] ? (size_t)row * img_w + col : 0;
+    const float Tf = in_img[p] ? final_Ts[pid] : 1.f;
+    const bool drawn = Tf < 1.f;
+    const float r = v_output[3 * pid], g = v_output[3 * pid + 1], b = v_output[3 * pid + 2];
+    const int fi = final_idx[pid];
+    vr[p] = drawn ? r : 0.f;
+    vg[p] = drawn ? g : 0.f;
+    vb[p] = drawn ? b : 0.f;
+    binf[p] = drawn ? fi : -1;
+    rho[p] = 1.f;
+    S[p] = 0.f;
+  }
+  int topp[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) topp[p] = __builtin_amdgcn_readfirstlane(wave_max(binf[p]));
+  const int max_top = max(max(topp[0], topp[1]), max(topp[2], topp[3]));
+  const int top = min(range.y - 1, max_top);
+  for (int hi = top; hi >= range.x; hi -= kChunk) {
+    const int sidx_l = hi - lane;
+    const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics, colors, opacities,
+                                  sA, sB, sC, nullptr, nullptr, nullptr, allowed);
+    __syncthreads();
+    for (int t = 0; t < count; ++t) {
+      const SplatA A = sA[t];
+      const SplatB B = sB[t];
+      const SplatC C = sC[t];
+      const float dx0 = A.x - fx0, dx1 = A.x - fx1;
+      const float dy0 = A.y - fy0, dy1 = A.y - fy1;
+      const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
+      const float cy0 = B.hc * dy0 * dy0, cy1 = B.hc * dy1 * dy1;
+      const float bx0 = A.b * dx0, bx1 = A.b * dx1;
+      const float sig[4] = {(ax0 + cy0) + bx0 * dy0, (ax1 + cy0) + bx1 * dy0,
+                            (ax0 + cy1) + bx0 * dy1, (ax1 + cy1) + bx1 * dy1};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (!((C.mask >> p) & 1) || C.sidx > topp[p]) continue;
+        const float sigma = sig[p];
+        const float vis = __expf(-sigma);
+        const float alpha = fminf(GSR_ALPHA_MAX_BWD, B.opac * vis);
+        const bool valid = (C.sidx <= binf[p]) && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+        const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+        const float rn = rho[p] * ra;
+        const float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
+        const float fac = valid ? alpha * rn : 0.f;
+        rho[p] = valid ? rn : rho[p];
+        S[p] += fac * d;
+      }
+    }
+    __syncthreads();
+  }
+  const size_t pixels = (size_t)img_w * img_h;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+    if (in_img[p]) seg_state[(size_t)(seg_k - 1) * pixels + (size_t)row * img_w + col] = make_float2(rho[p], S[p]);
   }
 }
 
@@ -752,6 +895,58 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
                      v_colors, v_opacity, extra, extra_background, v_output_extra, v_extra, deep, base, (float *)nullptr,
                      (unsigned char *)nullptr, (const int2 *)nullptr, 0);
   GSR_CHECK_LAUNCH("rasterize_backward_rgbd");
+  return GSR_OK;
+}
+
+// ---- depth segments: deep tiles' lists cut into `segments` pieces walked by their own waves -------------------
+GSR_EXPORT size_t gsr_rasterize_backward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments) {
+  if (segments < 2) return 0;
+  return (size_t)(segments - 1) * img_height * img_width * sizeof(float2);
+}
+
+GSR_EXPORT int gsr_rasterize_backward_seg(
+    unsigned img_height, unsigned img_width, int num_points, const int32_t *gaussian_ids_sorted,
+    const int32_t *tile_bins, const float *xys, const float *conics, const float *colors, const float *opacities,
+    const float *background, const float *final_Ts, const int32_t *final_idx, const float *v_output,
+    const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+    int deep_tile_threshold, int accumulators_zeroed, int segments, int segment_min_entries, void *workspace,
+    size_t workspace_bytes, gsr_stream_t stream) {
+  if (segments < 2 || deep_tile_threshold <= 0)
+    return gsr_rasterize_backward_ex(img_height, img_width, 16, num_points, gaussian_ids_sorted, tile_bins, xys, conics,
+                                     colors, opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy,
+                                     v_conic, v_colors, v_opacity, deep_tile_threshold, accumulators_zeroed, stream);
+  GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward_seg: empty image");
+  GSR_REQUIRE(num_points >= 0, "rasterize_backward_seg: num_points < 0");
+  GSR_REQUIRE(segments <= 16, "rasterize_backward_seg: at most 16 segments");
+  if (num_points == 0) return GSR_OK;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background && final_Ts &&
+                  final_idx && v_output && v_xy && v_conic && v_colors && v_opacity,
+              "rasterize_backward_seg: null pointer");
+  GSR_REQUIRE(workspace && workspace_bytes >= gsr_rasterize_backward_seg_workspace_bytes(img_height, img_width, segments) &&
+                  (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
+              "rasterize_backward_seg: workspace too small or not 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulators_zeroed) {
+    int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
+    if (rc != GSR_OK) return rc;
+  }
+  const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
+  const int num_tiles = tiles_x * tiles_y;
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  const int seg_min = segment_min_entries > deep_tile_threshold ? segment_min_entries : deep_tile_threshold;
+  float2 *state = static_cast<float2 *>(workspace);
+  hipLaunchKernelGGL(raster_bwd_segstate_kernel, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s, tiles_x,
+                     num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
+                     opacities, final_Ts, final_idx, v_output, deep_tile_threshold, base, segments, seg_min, state);
+  hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, false, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
+                     opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,
+                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep_tile_threshold,
+                     base, (float *)nullptr, (unsigned char *)nullptr, (const int2 *)nullptr, 0, segments, seg_min,
+                     (const float2 *)state);
+  GSR_CHECK_LAUNCH("rasterize_backward_seg");
   return GSR_OK;
 }
 

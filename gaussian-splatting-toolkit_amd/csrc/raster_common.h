@@ -116,6 +116,10 @@ __device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned bas
   return j;
 }
 
+// Depth segments (raster_fwd.hip / raster_bwd.hip): a split tile's list of `len` entries is cut into at most K runs of
+// whole 64-entry chunks; run k is [k seg_len, (k + 1) seg_len) of the list.
+__device__ __forceinline__ int seg_len_of(const int len, const int K) { return ((len + K * 64 - 1) / (K * 64)) * 64; }
+
 // Stage up to 64 splats (one per `live` lane, sorted index `sidx`) into LDS,
 // dropping the ones that cannot reach the tile; returns how many were kept.
 // Kept splats stay in lane order.  Wave-synchronous (one wave per workgroup).

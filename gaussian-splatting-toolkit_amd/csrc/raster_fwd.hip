@@ -47,7 +47,16 @@ __device__ unsigned long long *g_fwd_staged = nullptr;
 // RGBD: a fourth channel (one scalar per Gaussian, e.g. its depth) is composited in the
 // same pass into its own [H,W] image over background `bg_extra` (the
 // models run a second full pass for the depth image, vanilla_gs.py:840-855).
-template <bool RGBD>
+// ---- depth segments ------------------------------------------------------------------
+// On a tile grid that cannot fill the chip the kernel lasts as long as its deepest tile's serial walk.  The list of a
+// tile that is split over four waves is therefore also cut into up to `seg_count` runs: a PRE-PASS
+// (raster_fwd_segtau_kernel) computes, per pixel, the transmittance product of every run but the last; run k then
+// starts from the product of the runs in front of it and composites its own entries with the unchanged rule -- the
+// stop test `T (1 - alpha) <= 1e-4` sees the true incoming T -- leaving its RAW state (colour sums, signed T, last
+// drawn index); a combine pass adds the runs' colours in list order up to the run in which the pixel finished.
+// Equal to the single walk to rounding (T and C are sums / products of run-wise partial results), not bitwise.
+
+template <bool RGBD, bool SEG = false>
 __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
@@ -57,7 +66,9 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     float *__restrict__ final_Ts, int *__restrict__ final_idx, const float *__restrict__ extra,
     const float bg_extra, float *__restrict__ out_extra, const int deep_threshold, const unsigned base_grid,
     float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr, const unsigned zero_words,
-    const int round, int *__restrict__ tile_flags, const int idx_base) {
+    const int round, int *__restrict__ tile_flags, const int idx_base, const int seg_count = 1, const int seg_min = 0,
+    const float *__restrict__ seg_tau = nullptr, float4 *__restrict__ seg_raw = nullptr,
+    int *__restrict__ seg_last = nullptr) {
   // Two-round compositing (gsr_rasterize_forward_round): the lists of the nearest
   // Gaussians are a PREFIX of every tile's list.  round 1 composites such prefix lists and leaves the per-pixel
   // state of a wave that still has a live pixel RAW -- final_Ts = signed T (< 0: finished), out_img / out_extra = C
@@ -79,10 +90,29 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   __shared__ SplatC sC[kChunk];
 
   int2 range = make_int2(0, 0);
-  const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
+  unsigned blk = blockIdx.x;
+  int seg_k = 0;
+  if constexpr (SEG) {  // block = run * (4 base_grid) + the block of the unsegmented launch
+    seg_k = (int)(blk / (4u * base_grid));
+    blk -= (unsigned)seg_k * (4u * base_grid);
+  }
+  const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile;
   int allowed = job.allowed;
   if (tile < 0) return;
+  bool split = false;
+  if constexpr (SEG) {
+    const int len = range.y - range.x;
+    if (allowed == 15 || len <= seg_min) {  // not split: one walk, by run 0's block
+      if (seg_k > 0) return;
+    } else {
+      const int sl = seg_len_of(len, seg_count);
+      if (seg_k >= min(seg_count, (len + sl - 1) / sl)) return;
+      split = true;
+      range.x += seg_k * sl;
+      range.y = min(range.x + sl, range.y);
+    }
+  }
   if (round == 2) {  // only the sub-tiles round 1 left raw
     allowed &= tile_flags[tile];
     if (allowed == 0) return;
@@ -114,6 +144,14 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       cb[p] = out_img[3 * pid + 2];
       if constexpr (RGBD) ce[p] = out_extra[pid];
       last[p] = final_idx[pid];
+    }
+    if constexpr (SEG) {
+      if (split && inside) {  // the transmittance the runs in front of this one leave (0: finished there)
+        const size_t pixels = (size_t)img_w * img_h, pid = (size_t)row * img_w + col;
+        float t = 1.f;
+        for (int j = 0; j < seg_k; ++j) t *= seg_tau[(size_t)j * pixels + pid];
+        T[p] = t;
+      }
     }
   }
 
@@ -192,6 +230,21 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     }
     return;
   }
+  if constexpr (SEG) {
+    if (split) {  // the run's raw state; the combine pass finishes the pixel
+      const size_t pixels = (size_t)img_w * img_h;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+        if (col < img_w && row < img_h && ((allowed >> p) & 1)) {
+          const size_t at = (size_t)seg_k * pixels + (size_t)row * img_w + col;
+          seg_raw[at] = make_float4(cr[p], cg[p], cb[p], T[p]);
+          seg_last[at] = last[p];
+        }
+      }
+      return;
+    }
+  }
   // wave-uniform -> scalar loads
   const float bg0 = background[0], bg1 = background[1], bg2 = background[2];
 #pragma unroll
@@ -209,6 +262,133 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       if constexpr (RGBD) out_extra[pid] = ce[p] + Tp * bg_extra;
     }
   }
+}
+
+// Pre-pass of the depth segments: the transmittance product of run seg_k = block / (4 base_grid) (every run but a
+// tile's last) for the pixels of a split tile's sub-tile -> seg_tau[seg_k pixels + pixel]; 0 = the pixel finishes
+// inside this run even when it enters it with T = 1 (then it finishes there, or earlier, for any incoming T).
+__global__ __launch_bounds__(64) void raster_fwd_segtau_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h, const int *__restrict__ ids_sorted,
+    const int2 *__restrict__ tile_bins, const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, const int deep_threshold,
+    const unsigned base_grid, const int seg_count, const int seg_min, float *__restrict__ seg_tau) {
+  __shared__ SplatA sA[kChunk];
+  __shared__ SplatB sB[kChunk];
+  __shared__ SplatC sC[kChunk];
+  int2 range = make_int2(0, 0);
+  unsigned blk = blockIdx.x;
+  const int seg_k = (int)(blk / (4u * base_grid));
+  blk -= (unsigned)seg_k * (4u * base_grid);
+  const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
+  const int tile = job.tile, allowed = job.allowed;
+  if (tile < 0) return;
+  const int len = range.y - range.x;
+  if (allowed == 15 || len <= seg_min) return;
+  const int sl = seg_len_of(len, seg_count);
+  if (seg_k >= min(seg_count, (len + sl - 1) / sl) - 1) return;  // (nobody needs the last run's product)
+  range.x += seg_k * sl;
+  range.y = min(range.x + sl, range.y);
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int lane = threadIdx.x;
+  const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
+  const float fx0 = (float)qx, fx1 = (float)(qx + 8);
+  const float fy0 = (float)qy, fy1 = (float)(qy + 8);
+  const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
+  float T[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+    T[p] = (col < img_w && row < img_h && ((allowed >> p) & 1)) ? 1.f : -1.f;
+  }
+  auto live_subtiles = [&]() {
+    int m = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) m |= __any(T[p] > 0.f) ? (1 << p) : 0;
+    return m;
+  };
+  int live = live_subtiles();
+  for (int base = range.x; base < range.y && live != 0; base += kChunk) {
+    const int sidx = base + lane;
+    const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics, colors, opacities, sA,
+                                  sB, sC, nullptr, nullptr, nullptr, allowed);
+    __syncthreads();
+    for (int t = 0; t < count; ++t) {
+      if ((t & 7) == 7) {
+        live = live_subtiles();
+        if (live == 0) break;
+      }
+      const SplatC C = sC[t];
+      const int m = C.mask & live;
+      if (m == 0) continue;
+      const SplatA A = sA[t];
+      const SplatB B = sB[t];
+      const float dx0 = A.x - fx0, dx1 = A.x - fx1;
+      const float dy0 = A.y - fy0, dy1 = A.y - fy1;
+      const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
+      const float cy0 = B.hc * dy0 * dy0, cy1 = B.hc * dy1 * dy1;
+      const float bx0 = A.b * dx0, bx1 = A.b * dx1;
+      const float sig[4] = {(ax0 + cy0) + bx0 * dy0, (ax1 + cy0) + bx1 * dy0,
+                            (ax0 + cy1) + bx0 * dy1, (ax1 + cy1) + bx1 * dy1};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (!(m & (1 << p))) continue;
+        const float sigma = sig[p];
+        const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
+        const float Tp = T[p];
+        const float next_T = Tp * (1.f - alpha);
+        const bool hit = !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+        const bool go = next_T > GSR_T_EPS;
+        const float dead = __uint_as_float(__float_as_uint(Tp) | 0x80000000u);
+        T[p] = hit ? (go ? next_T : dead) : Tp;
+      }
+    }
+    __syncthreads();
+    live = live_subtiles();
+  }
+  const size_t pixels = (size_t)img_w * img_h;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
+    if (col < img_w && row < img_h && ((allowed >> p) & 1))
+      seg_tau[(size_t)seg_k * pixels + (size_t)row * img_w + col] = T[p] > 0.f ? T[p] : 0.f;
+  }
+}
+
+// Combine pass of the depth segments: one thread per pixel of a split tile adds the runs' colour sums in list order
+// up to and including the run in which the pixel finished (signed T < 0), takes that run's T and the largest drawn
+// index, and writes the final values as the single walk does.
+__global__ __launch_bounds__(256) void raster_fwd_segcombine_kernel(
+    const int tiles_x, const int img_w, const int img_h, const int2 *__restrict__ tile_bins,
+    const float *__restrict__ background, const int deep_threshold, const int seg_count, const int seg_min,
+    const float4 *__restrict__ seg_raw, const int *__restrict__ seg_last, float *__restrict__ out_img,
+    float *__restrict__ final_Ts, int *__restrict__ final_idx, float *__restrict__ out_alpha) {
+  const size_t pixels = (size_t)img_w * img_h;
+  const size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= pixels) return;
+  const int row = (int)(pid / img_w), col = (int)(pid - (size_t)row * img_w);
+  const int2 range = tile_bins[(row >> 4) * tiles_x + (col >> 4)];
+  const int len = range.y - range.x;
+  if (!(deep_threshold > 0 && len > deep_threshold) || len <= seg_min) return;
+  const int sl = seg_len_of(len, seg_count);
+  const int nseg = min(seg_count, (len + sl - 1) / sl);
+  float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f;
+  int last = 0;
+  for (int k = 0; k < nseg; ++k) {
+    const float4 r = seg_raw[(size_t)k * pixels + pid];
+    cr += r.x;
+    cg += r.y;
+    cb += r.z;
+    T = r.w;
+    last = max(last, seg_last[(size_t)k * pixels + pid]);
+    if (T < 0.f) break;
+  }
+  const float Tp = fabsf(T);
+  final_Ts[pid] = Tp;
+  if (out_alpha) out_alpha[pid] = 1.f - Tp;
+  final_idx[pid] = last;
+  out_img[3 * pid] = cr + Tp * background[0];
+  out_img[3 * pid + 1] = cg + Tp * background[1];
+  out_img[3 * pid + 2] = cb + Tp * background[2];
 }
 
 // ------------------------------------------------------------- scan mapping
@@ -509,6 +689,65 @@ GSR_EXPORT int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block
                      out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base,
                      out_alpha, static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0);
   GSR_CHECK_LAUNCH("rasterize_forward(tile16)");
+  return GSR_OK;
+}
+
+GSR_EXPORT size_t gsr_rasterize_forward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments) {
+  if (segments < 2) return 0;
+  const size_t px = (size_t)img_height * img_width;
+  // run products (segments - 1 floats, padded to 16 bytes) | raw states (segments float4) | last drawn indices
+  return (((size_t)(segments - 1) * px * 4 + 15) & ~(size_t)15) + (size_t)segments * px * 16 + (size_t)segments * px * 4;
+}
+
+GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
+                                         const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                                         const float *xys, const float *conics, const float *colors,
+                                         const float *opacities, const float *background, float *out_img,
+                                         float *final_Ts, int32_t *final_idx, int deep_tile_threshold,
+                                         float *out_alpha, void *zero_ptr, size_t zero_bytes, int segments,
+                                         int segment_min_entries, void *workspace, size_t workspace_bytes,
+                                         gsr_stream_t stream) {
+  if (segments < 2 || deep_tile_threshold <= 0)
+    return gsr_rasterize_forward_ex(tiles_x, tiles_y, 16, img_width, img_height, gaussian_ids_sorted, tile_bins, xys,
+                                    conics, colors, opacities, background, out_img, final_Ts, final_idx,
+                                    deep_tile_threshold, out_alpha, zero_ptr, zero_bytes, stream);
+  int rc = check_common("rasterize_forward_seg", tiles_x, tiles_y, 16, img_width, img_height, 3);
+  if (rc != GSR_OK) return rc;
+  GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background && out_img &&
+                  final_Ts && final_idx,
+              "rasterize_forward_seg: null pointer");
+  GSR_REQUIRE(segments <= 16, "rasterize_forward_seg: at most 16 segments");
+  GSR_REQUIRE(zero_ptr == nullptr || ((zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0 &&
+                                      zero_bytes < ((size_t)1 << 34)),
+              "rasterize_forward_seg: zero_ptr / zero_bytes must be multiples of 4 (and below 16 GB)");
+  GSR_REQUIRE(workspace && workspace_bytes >= gsr_rasterize_forward_seg_workspace_bytes(img_height, img_width, segments) &&
+                  (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+              "rasterize_forward_seg: workspace too small or not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int num_tiles = tiles_x * tiles_y;
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  const size_t px = (size_t)img_height * img_width;
+  const int seg_min = segment_min_entries > deep_tile_threshold ? segment_min_entries : deep_tile_threshold;
+  char *ws = static_cast<char *>(workspace);
+  float *tau = reinterpret_cast<float *>(ws);
+  float4 *raw = reinterpret_cast<float4 *>(ws + (((size_t)(segments - 1) * px * 4 + 15) & ~(size_t)15));
+  int *lastp = reinterpret_cast<int *>(reinterpret_cast<char *>(raw) + (size_t)segments * px * 16);
+  hipLaunchKernelGGL(raster_fwd_segtau_kernel, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s, tiles_x,
+                     num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
+                     opacities, deep_tile_threshold, base, segments, seg_min, tau);
+  hipLaunchKernelGGL((raster_fwd_tile16_kernel<false, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
+                     opacities, background, out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr,
+                     deep_tile_threshold, base, out_alpha, static_cast<unsigned *>(zero_ptr),
+                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, (const float *)tau, raw,
+                     lastp);
+  hipLaunchKernelGGL(raster_fwd_segcombine_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, tiles_x,
+                     (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), background,
+                     deep_tile_threshold, segments, seg_min, (const float4 *)raw, (const int *)lastp, out_img, final_Ts,
+                     final_idx, out_alpha);
+  GSR_CHECK_LAUNCH("rasterize_forward_seg");
   return GSR_OK;
 }
 

@@ -53,10 +53,11 @@ GSR_EXPORT int gsr_view_forward(const gsr_view_desc *v, gsr_stream_t stream) {
                                        0.f, v->out_img, v->out_depth, v->final_Ts, v->final_idx,
                                        v->deep_tile_threshold, v->out_alpha, v->zero_ptr, v->zero_bytes, stream));
   } else {
-    GSR_TRY(gsr_rasterize_forward_ex(tiles_x, tiles_y, 16, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
-                                     v->tile_bins, v->xys, v->conics, v->colors, v->opac, v->background, v->out_img,
-                                     v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
-                                     v->zero_bytes, stream));
+    GSR_TRY(gsr_rasterize_forward_seg(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
+                                      v->tile_bins, v->xys, v->conics, v->colors, v->opac, v->background, v->out_img,
+                                      v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
+                                      v->zero_bytes, v->segments, v->segment_min_entries, v->seg_ws, v->seg_ws_bytes,
+                                      stream));
   }
   return GSR_OK;
 }
@@ -99,10 +100,11 @@ GSR_EXPORT int gsr_rasterize_gaussians_forward(const gsr_raster_desc *v, gsr_str
                                        v->extra_background, v->out_img, v->out_extra, v->final_Ts, v->final_idx,
                                        v->deep_tile_threshold, v->out_alpha, v->zero_ptr, v->zero_bytes, stream));
   } else {
-    GSR_TRY(gsr_rasterize_forward_ex(tiles_x, tiles_y, 16, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
-                                     v->tile_bins, v->xys, v->conics, v->colors, v->opac, v->background, v->out_img,
-                                     v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
-                                     v->zero_bytes, stream));
+    GSR_TRY(gsr_rasterize_forward_seg(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
+                                      v->tile_bins, v->xys, v->conics, v->colors, v->opac, v->background, v->out_img,
+                                      v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
+                                      v->zero_bytes, v->segments, v->segment_min_entries, v->seg_ws, v->seg_ws_bytes,
+                                      stream));
   }
   return GSR_OK;
 }
@@ -123,10 +125,11 @@ GSR_EXPORT int gsr_view_backward(const gsr_view_desc *v, const gsr_view_grads *g
                                         v_colors, v_extra, v_opac, v->deep_tile_threshold, g->accumulators_zeroed,
                                         stream));
   } else {
-    GSR_TRY(gsr_rasterize_backward_ex((unsigned)v->img_height, (unsigned)v->img_width, 16, n, v->ids, v->tile_bins,
-                                      v->xys, v->conics, v->colors, v->opac, v->background, v->final_Ts,
-                                      v->final_idx, g->v_img, g->v_alpha, v_xy, v_conic, v_colors, v_opac,
-                                      v->deep_tile_threshold, g->accumulators_zeroed, stream));
+    GSR_TRY(gsr_rasterize_backward_seg((unsigned)v->img_height, (unsigned)v->img_width, n, v->ids, v->tile_bins,
+                                       v->xys, v->conics, v->colors, v->opac, v->background, v->final_Ts,
+                                       v->final_idx, g->v_img, g->v_alpha, v_xy, v_conic, v_colors, v_opac,
+                                       v->deep_tile_threshold, g->accumulators_zeroed, v->segments,
+                                       v->segment_min_entries, v->seg_ws, v->seg_ws_bytes, stream));
   }
   if (g->stats_first != nullptr)
     GSR_TRY(gsr_densify_stats_dev(n, v_xy, v->radii, g->stats_inv_size, g->stats_first, g->xys_grad_norm,

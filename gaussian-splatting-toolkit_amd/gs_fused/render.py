@@ -49,7 +49,8 @@ class _ViewDesc(C.Structure):  # gsr_view_desc (include/gsraster.h)
                                              "count_out", "sort_ws")]
                 + [("sort_ws_bytes", C.c_size_t), ("bin_ws", C.c_void_p), ("bin_ws_bytes", C.c_size_t)]
                 + [(k, C.c_void_p) for k in ("out_img", "out_depth", "final_Ts", "final_idx", "out_alpha", "zero_ptr")]
-                + [("zero_bytes", C.c_size_t)])
+                + [("zero_bytes", C.c_size_t), ("segments", C.c_int), ("segment_min_entries", C.c_int),
+                   ("seg_ws", C.c_void_p), ("seg_ws_bytes", C.c_size_t)])
 
 
 class _ViewGrads(C.Structure):  # gsr_view_grads
@@ -58,6 +59,18 @@ class _ViewGrads(C.Structure):  # gsr_view_grads
                 + [(k, C.c_void_p) for k in ("xys_grad_norm", "vis_counts", "max_2dsize", "tmp_v_cov2d", "tmp_v_cov3d",
                                              "tmp_v_scales", "tmp_v_quats", "v_means", "v_log_scales", "v_raw_quats",
                                              "v_logits", "v_dc", "v_rest")])
+
+
+def _segments(spec, capacity, dev):
+    """(segments, minimum entries, workspace pointer, bytes) of the view's compositing (rasterizer.cuda.depth_segments;
+    RGB only).  The workspace is scratch of ONE call: the caching allocator hands the block back to the next one."""
+    if spec.render_depth:
+        return 0, 0, None, 0
+    tb = spec.tile_bounds
+    segs, seg_min, ws = _C._forward_segments(capacity, tb[0] * tb[1], spec.height, spec.width, dev)
+    if ws is None:
+        return 0, 0, None, 0
+    return segs, seg_min, ws.data_ptr(), ws.numel()
 
 
 _ws_bytes_cache = {}
@@ -152,7 +165,7 @@ class _Render(Function):
                              p(cov3d), p(xys), p(depths), p(radii), p(conics), p(comp), p(tiles), p(colors), p(recs),
                              p(counts), p(order), p(cum), p(ids), p(bins), p(count_out), p(sort_ws), sort_b,
                              p(bin_ws), bin_b, p(img), p(dep), p(Ts), p(idx), p(alpha), p(acc),
-                             0 if acc is None else acc.numel() * 4)
+                             0 if acc is None else acc.numel() * 4, *_segments(spec, capacity, dev))
             _call("gsr_view_forward", C.byref(desc), _stream(dev))
         ctx.spec, ctx.stats, ctx.degree = spec, stats, degree
         ctx.sh_collector = sh_collector
@@ -202,7 +215,8 @@ class _Render(Function):
                              p(means), None, p(raw_quats), None, p(features_dc), p(features_rest), p(viewmat),
                              p(projmat), None, p(background), p(scales), p(quats), p(opac), p(dirs), p(cov3d), p(xys),
                              p(depths), p(radii), p(conics), p(comp), None, p(colors), None, None, None, None, p(ids),
-                             p(bins), None, None, 0, None, 0, None, None, p(Ts), p(idx), None, None, 0)
+                             p(bins), None, None, 0, None, 0, None, None, p(Ts), p(idx), None, None, 0,
+                             *_segments(spec, ctx.capacity, dev))
             grads = _ViewGrads(p(v_img), p(v_a), p(v_dep) if spec.render_depth else None, p(acc), int(zeroed),
                                p(stats.first) if use_stats else None, (1.0 / stats.max_dim) if use_stats else 0.0,
                                p(stats.xys_grad_norm) if use_stats else None, p(stats.vis_counts) if use_stats else None,

@@ -552,6 +552,48 @@ def _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacitie
         raise RuntimeError("background must have one value per channel")
 
 
+def depth_segments(list_entries: int, num_tiles: int):
+    """-> (segments, minimum entries) for ``gsr_rasterize_forward_seg`` / ``gsr_rasterize_backward_seg``: into how many
+    runs the lists of the tiles that are split over four waves are cut, each run walked by its own waves (DESIGN.md
+    4.16).  Only tile grids that cannot fill the chip gain: 16 runs (GSR_DEPTH_SEGMENTS; 1 = off) on grids of up to
+    GSR_DEPTH_SEGMENTS_GRID = 1 100 tiles (the grids on which forward and backward split every tile), for lists of more
+    than GSR_DEPTH_SEGMENTS_MIN = 512 entries.  Measured (tools/exp/seg_ab.py, profiles/r04_depth_segments.txt):
+    300 k Gaussians of the trainer's object scene at 480 x 270, compositing backward 436 -> 263 us with 8 runs
+    (pre-pass 75 + walk 188), forward 338 -> 295 us with 4; config 3 (whose first 2 000 iterations run on this grid)
+    818 / 825 -> 871 (8 runs) -> 885 iterations/s (16).  On larger grids the kernels are bound by their total work,
+    which the pre-passes raise: 960 x 540 unchanged, the long-tail 1080p scene 0.62 -> 0.67 ms (backward), the default
+    0.427 -> 0.448 ms (the empty workgroups of the segment grid) -- off there."""
+    segs, grid, least = _segment_knobs()
+    _, _, small_grid, _, small_grid_bwd = _deep_knobs()
+    # (only where EVERY tile above the small-grid floor is split, forward and backward alike: which tiles are cut, and
+    #  where, is then a function of the tile's list alone and every route to the kernels rounds the same way)
+    if segs < 2 or num_tiles <= 0 or num_tiles > min(grid, small_grid, small_grid_bwd):
+        return 1, 0
+    return segs, least
+
+
+def _forward_segments(list_entries: int, num_tiles: int, H: int, W: int, dev):
+    """-> (segments, minimum entries, workspace or None) of ``gsr_rasterize_forward_seg`` for this tile grid."""
+    segs, seg_min = depth_segments(list_entries, num_tiles)
+    if segs < 2:
+        return 0, 0, None
+    nbytes = int(_lib().gsr_rasterize_forward_seg_workspace_bytes(C.c_uint(H), C.c_uint(W), C.c_int(segs)))
+    return segs, seg_min, torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+
+
+_segment_cache = {}
+
+
+def _segment_knobs():
+    if not _segment_cache:
+        import os
+
+        _segment_cache["v"] = (int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")),
+                               int(os.environ.get("GSR_DEPTH_SEGMENTS_GRID", "1100")),
+                               int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")))
+    return _segment_cache["v"]
+
+
 def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = False) -> int:
     """List length above which a 16x16 tile is composited by four waves (one per 8x8
     sub-tile) instead of one (include/gsraster.h, ``deep_tile_threshold``): GSR_DEEP_FACTOR
@@ -599,7 +641,8 @@ class _RasterDesc(C.Structure):  # gsr_raster_desc (include/gsraster.h)
                                              "tile_bins", "count_out", "sort_ws")]
                 + [("sort_ws_bytes", C.c_size_t), ("bin_ws", C.c_void_p), ("bin_ws_bytes", C.c_size_t)]
                 + [(k, C.c_void_p) for k in ("out_img", "out_extra", "final_Ts", "final_idx", "out_alpha", "zero_ptr")]
-                + [("zero_bytes", C.c_size_t)])
+                + [("zero_bytes", C.c_size_t), ("segments", C.c_int), ("segment_min_entries", C.c_int),
+                   ("seg_ws", C.c_void_p), ("seg_ws_bytes", C.c_size_t)])
 
 
 _raster_plan_cache = {}
@@ -675,13 +718,16 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
             zero_bytes = zero.numel() * 4
             if zero_bytes == 0:
                 zero = None
+        segs, seg_min, seg_ws = _forward_segments(capacity, tb[0] * tb[1], H, W, dev) if composite and extra is None \
+            else (0, 0, None)
         desc = _RasterDesc(n, H, W, int(capacity), deep_tile_threshold(capacity, tb[0] * tb[1]), float(extra_background),
                            xys.data_ptr(), depths.data_ptr(), radii.data_ptr(), conics.data_ptr(),
                            p(colors) if composite else None, p(extra), opacities.data_ptr(),
                            p(background) if composite else None, p(order_ready), at("records"),
                            at("counts"), at("order"), at("cum"), ids.data_ptr(), bins.data_ptr(), count_out.data_ptr(),
                            at("sort_ws"), sort_b, at("bin_ws"), bin_b, p(img), p(out_extra), p(Ts),
-                           p(idx), p(alpha), p(zero), zero_bytes)
+                           p(idx), p(alpha), p(zero), zero_bytes, segs, seg_min, p(seg_ws),
+                           seg_ws.numel() if seg_ws is not None else 0)
         _call("gsr_rasterize_gaussians_forward", C.byref(desc), _stream(dev))
     if not composite:
         return ids, bins
@@ -701,12 +747,15 @@ def composite_prepared(tile_bounds, img_width: int, img_height: int, gaussian_id
     alpha = planes[2] if want_alpha else None
     zero_bytes = zero.numel() * 4 if zero is not None else 0
     with _on(dev):
-        _call("gsr_rasterize_forward_ex", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(16),
+        tiles = tile_bounds[0] * tile_bounds[1]
+        segs, seg_min, seg_ws = _forward_segments(gaussian_ids_sorted.numel(), tiles, int(img_height), int(img_width), dev)
+        _call("gsr_rasterize_forward_seg", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
               C.c_uint(int(img_width)), C.c_uint(int(img_height)), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys),
               _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(background), _ptr(out_img), _ptr(Ts), _ptr(idx),
-              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])),
+              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)),
               _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero_bytes else None, C.c_size_t(zero_bytes),
-              _stream(dev))
+              C.c_int(segs), C.c_int(seg_min), _ptr(seg_ws) if seg_ws is not None else None,
+              C.c_size_t(seg_ws.numel() if seg_ws is not None else 0), _stream(dev))
     return out_img, Ts, idx, alpha
 
 
@@ -740,16 +789,23 @@ def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_b
             if channels != 3:
                 raise RuntimeError("rasterize_forward expects 3 channels; use nd_rasterize_forward")
             deep = deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])
-            if ex:
+            segs, seg_min, seg_ws = _forward_segments(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], H, W,
+                                                      dev) if block[0] == 16 else (0, 0, None)
+            if ex or segs > 1:
                 if zero is not None:
                     _check(zero, "zero", _f32)
                     if zero.numel() == 0:
                         zero = None
                 alpha = torch.empty((H, W), dtype=_f32, device=dev) if want_alpha else None
-                _call("gsr_rasterize_forward_ex", *head, *tail, C.c_int(deep),
-                      _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero is not None else None,
-                      C.c_size_t(zero.numel() * 4 if zero is not None else 0), _stream(dev))
-                return out_img, final_Ts, final_idx, alpha
+                tail_ex = (C.c_int(deep), _ptr(alpha) if alpha is not None else None,
+                           _ptr(zero) if zero is not None else None,
+                           C.c_size_t(zero.numel() * 4 if zero is not None else 0))
+                if segs > 1:
+                    _call("gsr_rasterize_forward_seg", head[0], head[1], head[3], head[4], *tail, *tail_ex, C.c_int(segs),
+                          C.c_int(seg_min), _ptr(seg_ws), C.c_size_t(seg_ws.numel()), _stream(dev))
+                else:
+                    _call("gsr_rasterize_forward_ex", *head, *tail, *tail_ex, _stream(dev))
+                return (out_img, final_Ts, final_idx, alpha) if ex else (out_img, final_Ts, final_idx)
             _call("gsr_rasterize_forward", *head, *tail, C.c_int(deep), _stream(dev))
     return out_img, final_Ts, final_idx
 
@@ -937,7 +993,14 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
             _call("gsr_rasterize_backward_nd", *head, C.c_uint(channels), *tail, _stream(dev))
         else:
             tiles = ((img_width + block_width - 1) // block_width) * ((img_height + block_width - 1) // block_width)
-            if zeroed:
+            segs, seg_min = depth_segments(gaussian_ids_sorted.numel(), tiles) if block_width == 16 else (1, 0)
+            if segs > 1:
+                deep = deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)
+                ws = torch.empty(((segs - 1) * int(img_height) * int(img_width), 2), dtype=_f32, device=dev)
+                _call("gsr_rasterize_backward_seg", C.c_uint(img_height), C.c_uint(img_width), *tail, C.c_int(deep),
+                      C.c_int(1 if zeroed else 0), C.c_int(segs), C.c_int(seg_min), _ptr(ws),
+                      C.c_size_t(ws.numel() * 4), _stream(dev))
+            elif zeroed:
                 _call("gsr_rasterize_backward_ex", *head, *tail,
                       C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)), C.c_int(1),
                       _stream(dev))

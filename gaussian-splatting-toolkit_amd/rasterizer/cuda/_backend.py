@@ -43,6 +43,10 @@ SYMBOLS = (
     "gsr_rasterize_backward",
     "gsr_rasterize_forward_ex",
     "gsr_rasterize_backward_ex",
+    "gsr_rasterize_forward_seg",
+    "gsr_rasterize_forward_seg_workspace_bytes",
+    "gsr_rasterize_backward_seg",
+    "gsr_rasterize_backward_seg_workspace_bytes",
     "gsr_rasterize_forward_nd",
     "gsr_rasterize_backward_nd",
     "gsr_cov2d_bounds",
@@ -106,6 +110,8 @@ def _load():
     lib.gsr_refine_workspace_bytes.restype = C.c_size_t
     lib.gsr_tile_lists_subrange_workspace_bytes.restype = C.c_size_t
     lib.gsr_saturation_filter_workspace_bytes.restype = C.c_size_t
+    lib.gsr_rasterize_forward_seg_workspace_bytes.restype = C.c_size_t
+    lib.gsr_rasterize_backward_seg_workspace_bytes.restype = C.c_size_t
     lib.gsr_rasterize_backward_det_workspace_bytes.restype = C.c_size_t
     return lib
 

@@ -319,6 +319,44 @@ int gsr_rasterize_backward_ex(unsigned img_height, unsigned img_width,
                               float *v_opacity, int deep_tile_threshold,
                               int accumulators_zeroed, gsr_stream_t stream);
 
+/* gsr_rasterize_forward_ex (16x16 tiles, 3 channels) with DEPTH SEGMENTS: the list of every tile that is split over
+ * four waves (deep_tile_threshold) and holds more than max(deep_tile_threshold, segment_min_entries) entries is cut
+ * into `segments` (2..16) runs of whole 64-entry chunks.  A pre-pass computes every run's transmittance product per
+ * pixel; each run is then composited by its own waves from the true incoming T (the stop rule of forward.cu:278-395
+ * needs it) and a combine pass adds the runs' colours in list order.  For tile grids too small to fill the chip (the
+ * 480 x 270 phase of the reference's coarse-to-fine schedule, vanilla_gs.py:48-53, is 510 tiles).  Results equal
+ * gsr_rasterize_forward_ex's to rounding.  workspace: gsr_rasterize_forward_seg_workspace_bytes(...) bytes, 16-byte
+ * aligned.  segments < 2 or deep_tile_threshold <= 0: gsr_rasterize_forward_ex. */
+size_t gsr_rasterize_forward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments);
+int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                              const float *xys, const float *conics, const float *colors,
+                              const float *opacities, const float *background, float *out_img,
+                              float *final_Ts, int32_t *final_idx, int deep_tile_threshold,
+                              float *out_alpha, void *zero_ptr, size_t zero_bytes, int segments,
+                              int segment_min_entries, void *workspace, size_t workspace_bytes,
+                              gsr_stream_t stream);
+
+/* gsr_rasterize_backward_ex (16x16 tiles) with DEPTH SEGMENTS: the list of every tile that is split over four waves
+ * (deep_tile_threshold) and holds more than max(deep_tile_threshold, segment_min_entries) entries is cut into
+ * `segments` (2..16) runs, each walked by its own waves; a pre-pass computes what every run does to the backward's
+ * per-pixel state (backward.cu:133-303: T and the colour buffer -- an affine map per run), so the runs are
+ * independent.  For tile grids too small to fill the chip and for scenes whose deepest tiles set the kernel's
+ * duration.  Results equal gsr_rasterize_backward_ex's to rounding (T reaches a run as a product of run products).
+ * workspace: gsr_rasterize_backward_seg_workspace_bytes(img_height, img_width, segments) bytes, 8-byte aligned.
+ * segments < 2 or deep_tile_threshold <= 0: gsr_rasterize_backward_ex. */
+size_t gsr_rasterize_backward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments);
+int gsr_rasterize_backward_seg(unsigned img_height, unsigned img_width, int num_points,
+                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                               const float *xys, const float *conics, const float *colors,
+                               const float *opacities, const float *background,
+                               const float *final_Ts, const int32_t *final_idx,
+                               const float *v_output, const float *v_output_alpha,
+                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                               int deep_tile_threshold, int accumulators_zeroed, int segments,
+                               int segment_min_entries, void *workspace, size_t workspace_bytes,
+                               gsr_stream_t stream);
+
 /* generic channel count; replace nd_rasterize_forward_tensor /
  * nd_rasterize_backward_tensor (bindings.cu:330-469), kernels
  * forward.cu:159-276 / backward.cu:23-131.  Accumulation is fp32 here (the
@@ -557,6 +595,11 @@ typedef struct gsr_view_desc {
   float *out_alpha;
   void *zero_ptr;
   size_t zero_bytes;
+  /* depth segments of the compositing, forward and backward (gsr_rasterize_forward_seg / _backward_seg; RGB only):
+   * segments < 2 = off; seg_ws: gsr_rasterize_forward_seg_workspace_bytes(...) bytes (enough for the backward too) */
+  int segments, segment_min_entries;
+  void *seg_ws;
+  size_t seg_ws_bytes;
 } gsr_view_desc;
 
 /* cotangents in, parameter gradients out.  accumulators: (9 + render_depth) n floats laid out
@@ -617,6 +660,11 @@ typedef struct gsr_raster_desc {
   float *out_alpha;
   void *zero_ptr;
   size_t zero_bytes;
+  /* depth segments of the compositing (gsr_rasterize_forward_seg): segments < 2 = off; the extra channel composites
+   * without them */
+  int segments, segment_min_entries;
+  void *seg_ws;
+  size_t seg_ws_bytes;
 } gsr_raster_desc;
 int gsr_rasterize_gaussians_forward(const gsr_raster_desc *desc, gsr_stream_t stream);
 int gsr_view_backward(const gsr_view_desc *view, const gsr_view_grads *grads, gsr_stream_t stream);

@@ -285,7 +285,8 @@ def test_random_view_sequences_with_two_round_lists_forced():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GSR_TWO_ROUND="1")
+    env = dict(os.environ, GSR_TWO_ROUND="1", GSR_DEPTH_SEGMENTS="1")  # (two rounds resume ONE chain: bitwise only
+    #                                                                     against the walk without depth segments)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_sequence.py"), "80", "23"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
@@ -1120,7 +1121,10 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
     single walk and gradients equal up to the order of the float atomics -- on the first two-round view and on the
     ones that size their lists from it."""
     from rasterizer import rasterize as R
+    import rasterizer.cuda as C_
 
+    monkeypatch.setattr(C_, "depth_segments", lambda entries, num_tiles: (1, 0))  # (375 tiles: the single walk would
+    #                                                     be cut into runs, the two rounds resume one chain)
     W, H, n = 400, 240, 120_000
     cam = S.make_camera(W, H)
     sc = S.make_scene(n, cam, sh_degree=1, seed=3, scale_lo=0.02, scale_hi=0.1)

@@ -459,14 +459,16 @@ def test_depth_order_without_counts_bucket_sort(n, mode, monkeypatch):
 @pytest.mark.parametrize("n,W,H,ck,opac_hi", [(3000, 160, 96, {}, 1.0), (20_000, 317, 203, {"yaw": 0.3}, 1.0),
                                              (5000, 256, 256, {}, 0.02), (200_000, 640, 360, {}, 1.0),
                                              (30_000, 3840, 2160, {}, 1.0), (20_000, 2560, 1440, {"yaw": 0.2}, 1.0)])
-def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi):
+def test_exact_lists_drop_only_dead_pairs(n, W, H, ck, opac_hi, monkeypatch):
     """count_reach + bin_sorted(conics, opacities): per tile, the list is a
     subsequence of the reference's; every dropped (Gaussian, tile) pair has
     alpha < 1/255 at every pixel of the tile; the image composited from the short
     lists is bit-identical, gradients equal up to atomic summation order.  The 4K and
-    1440p cases run in 4 and 2 tile-row bands (grids above 16384 tiles)."""
+    1440p cases run in 4 and 2 tile-row bands (grids above 16384 tiles).  (Bitwise under the single walk: depth
+    segments, which cut a tile's list by its LENGTH, are switched off -- their own tests compare to rounding.)"""
     import rasterizer.cuda as C
 
+    monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))
     bw = 16
     cam, sc = make(n, W, H, cam_kw=ck, scale_lo=0.01, scale_hi=0.2 if W < 2000 else 0.08)
     rng = np.random.default_rng(n)
@@ -747,6 +749,8 @@ def test_deep_tiles_split_over_four_waves_give_identical_results(rgbd, monkeypat
     v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
     v_ext = torch.rand(H, W, device=DEV) * 2 - 1
 
+    monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))  # (their own tests follow)
+
     def run(threshold):
         monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
         if rgbd:
@@ -772,6 +776,99 @@ def test_deep_tiles_split_over_four_waves_give_identical_results(rgbd, monkeypat
         for x, y in zip(b0, ba):
             scale = x.abs().max().item()
             assert (x - y).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("opaque", [False, True])
+def test_depth_segments_of_the_forward_equal_the_single_walk(opaque, monkeypatch):
+    """gsr_rasterize_forward_seg: the lists of the split tiles cut into 2 .. 16 runs; a pre-pass gives every run the
+    transmittance in front of it, the runs composite in parallel with the unchanged stop rule, a combine pass adds
+    them up in list order.  Image and final T equal the single walk's to rounding; the last drawn index is the same
+    wherever the pixel's decisions are not within rounding of a threshold (all but a handful of pixels).  Long-tail
+    scene, and the same scene nearly opaque (every pixel finishes inside some run)."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 60_000, 320, 208, 16
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=5, scale_lo=0.01, scale_hi=0.08, longtail=True)
+    opac = sc["opacities"].copy()
+    if opaque:
+        opac = np.maximum(opac, 0.97).astype(np.float32)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    colors = np.random.default_rng(2).uniform(0, 1, (n, 3)).astype(np.float32)
+    order, cum = C.depth_order(cu(depths), cu(radii), cu(tiles))
+    I = int(cum[-1].item())
+    ids, bins = C.bin_sorted(n, I, order, cum, cu(xys), cu(radii), tb, bw)
+    lens = (bins[:, 1] - bins[:, 0]).cpu().numpy()
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+
+    def run(segs, least, threshold=96, ex=True):
+        monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
+        monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (segs, least))
+        if ex:
+            return C.rasterize_forward_ex(tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors),
+                                          cu(opac), bg, want_alpha=True)
+        return C.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors), cu(opac), bg)
+
+    img0, T0, idx0, a0 = run(1, 0)
+    if opaque:
+        assert (T0 < 1e-3).float().mean().item() > 0.5
+    for segs, least, thr in ((2, 64, 96), (5, 64, 96), (8, 512, 96), (16, 64, 1), (8, 64, int(np.percentile(lens, 70)))):
+        img, T, idx, a = run(segs, least, thr)
+        assert (img - img0).abs().max().item() <= 2e-6, (segs, least, thr)
+        assert (T - T0).abs().max().item() <= 1e-6 and torch.equal(a, 1 - T)
+        assert (idx != idx0).float().mean().item() <= 1e-3, (segs, least, thr)
+        img_b, T_b, idx_b = run(segs, least, thr, ex=False)  # (the plain entry takes the same route)
+        assert torch.equal(img_b, img) and torch.equal(T_b, T) and torch.equal(idx_b, idx)
+    with pytest.raises(RuntimeError):
+        run(17, 64)
+
+
+@pytest.mark.parametrize("opaque", [False, True])
+def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, monkeypatch):
+    """gsr_rasterize_backward_seg: the lists of the split tiles cut into 2 .. 16 runs, every run walked by its own
+    waves from the state a pre-pass computed (T and the colour buffer are mapped affinely by a run).  Gradients equal
+    the single walk's to rounding: a long-tail scene (lists of several thousand entries next to short ones; runs
+    behind every pixel's last index; tiles below the minimum stay whole), and the same scene nearly opaque -- pixels
+    saturate after a few splats, and alpha exceeds the backward's 0.99 clamp, where the backward's T is not the
+    forward's (backward.cu:133-303 restated in raster_bwd.hip)."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 60_000, 320, 208, 16
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=5, scale_lo=0.01, scale_hi=0.08, longtail=True)
+    opac = sc["opacities"].copy()
+    if opaque:
+        opac = np.maximum(opac, 0.97).astype(np.float32)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    colors = np.random.default_rng(2).uniform(0, 1, (n, 3)).astype(np.float32)
+    order, cum = C.depth_order(cu(depths), cu(radii), cu(tiles))
+    I = int(cum[-1].item())
+    ids, bins = C.bin_sorted(n, I, order, cum, cu(xys), cu(radii), tb, bw)
+    lens = (bins[:, 1] - bins[:, 0]).cpu().numpy()
+    assert lens.max() > 2000 and np.median(lens) < 1000
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
+    v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
+    f = C.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors), cu(opac), bg)
+    if opaque:
+        assert (f[1] < 1e-3).float().mean().item() > 0.5  # most pixels saturated
+
+    def run(segs, least, threshold=96):
+        monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
+        monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (segs, least))
+        return C.rasterize_backward(H, W, bw, ids, bins, cu(xys), cu(conics), cu(colors), cu(opac), bg, f[1], f[2],
+                                    v_img, v_alpha)
+
+    ref = run(1, 0)
+    assert all(torch.isfinite(t).all() for t in ref) and ref[0].abs().max().item() > 0
+    for segs, least, thr in ((2, 64, 96), (5, 64, 96), (8, 512, 96), (16, 64, 1), (8, 64, int(np.percentile(lens, 70)))):
+        got = run(segs, least, thr)
+        for x, y in zip(ref, got):
+            assert (x - y).abs().max().item() <= 2e-5 * x.abs().max().item(), (segs, least, thr)
+    with pytest.raises(RuntimeError):
+        run(17, 64)  # at most 16 runs
 
 
 @pytest.mark.parametrize("W,H,n", [(320, 208, 40_000), (3840, 2160, 30_000)])
@@ -900,13 +997,14 @@ def test_scan_mapping_forward_equals_the_serial_walk(n, W, H, ck, kw):
     (150_000, 640, 360, 0.01, 0.06, 0.05, True),    # a short prefix: many tiles need the second round
     (3_000, 160, 96, 0.01, 0.1, 0.5, False),
 ])
-def test_two_round_lists_equal_the_single_walk(n, W, H, lo, hi, frac, rgbd):
+def test_two_round_lists_equal_the_single_walk(n, W, H, lo, hi, frac, rgbd, monkeypatch):
     """Prefix lists + saturation filter + second-round lists + resumed compositing (include/gsraster.h "two-round
     lists") against ONE walk over the full lists: image, final T (and the depth channel) bit-identical, the last
     contributing Gaussian of every drawn pixel the same, gradients equal up to the order of the float atomics --
-    whatever the prefix length."""
+    whatever the prefix length.  (The single walk without depth segments: the two rounds resume ONE chain.)"""
     import rasterizer.cuda as C
 
+    monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))
     cam = S.make_camera(W, H)
     sc = S.make_scene(n, cam, sh_degree=0, seed=11, scale_lo=lo, scale_hi=hi)
     cov3d, xys, depths, radii, conics, comp, tiles = (cu(a) for a in project_cpu(cam, sc, 16))
