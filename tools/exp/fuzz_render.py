@@ -58,7 +58,9 @@ def main():
                         if a.numel() == 0:
                             continue
                         err, ref = float((a - b).abs().max()), float(a.abs().max())
-                        assert err <= 3e-4 * ref + 1e-12, f"grad of {nm} at capacity {cap}: {err:.3e} vs max {ref:.3e}"
+                        # (two runs of the SAME lists differ by the order of the float atomics: up to 6e-4 of the largest
+                        #  gradient where 150 k Gaussians pile up on 380 tiles -- seed 4012, case 47, round 4)
+                        assert err <= 1e-3 * ref + 1e-12, f"grad of {nm} at capacity {cap}: {err:.3e} vs max {ref:.3e}"
                 else:
                     assert bool(torch.isfinite(rgb2).all()), f"non-finite image with cut lists (capacity {cap})"
                     for nm, b in zip(raw.keys(), grads2):
