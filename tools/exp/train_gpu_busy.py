@@ -24,7 +24,7 @@ def summarize(d):
         for r in csv.DictReader(fh):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    fwd = [i for i, r in enumerate(rows) if "raster_fwd" in r[2]]
+    fwd = [i for i, r in enumerate(rows) if "raster_fwd_tile16" in r[2]]
     # the training run = the LAST 7000 forward launches before the evaluation renders; take the longest run of
     # launches whose iteration time is below 20 ms
     print("kernels", len(rows), "compositing forward launches", len(fwd))
@@ -52,7 +52,7 @@ def summarize(d):
         for s_, e_, k_ in rows[i0:i1]:
             k_ = k_.replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].replace("void ", "").strip()[-48:]
             per[k_] = per.get(k_, 0) + (e_ - s_)
-        top = sorted(per.items(), key=lambda kv: -kv[1])[:14]
+        top = sorted(per.items(), key=lambda kv: -kv[1])[:18]
         out[name + " us/iter by kernel"] = {k_: round(v_ / (b - a) / 1e3, 1) for k_, v_ in top}
         out[name] = {"ms_per_iter": round((t1 - t0) / (b - a) / 1e6, 4), "gpu_busy": round(busy / (t1 - t0), 3),
                      "kernels_per_iter": round((i1 - i0) / (b - a), 1)}
