@@ -520,12 +520,14 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
 // The pre-pass of the depth segments: (R, S) of segment seg_k = 1 + block / (4 base_grid) for every pixel of a deep
 // tile's sub-tile -> seg_state[(seg_k - 1) pixels + pixel].  Same staging, same sigma / alpha / validity expressions as
 // the walk above; no gradients.
+template <bool RGBD>
 __global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
     const float2 *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
     const float *__restrict__ final_Ts, const int *__restrict__ final_idx, const float *__restrict__ v_output,
+    const float *__restrict__ extra, const float *__restrict__ v_out_extra,
     const int deep_threshold, const unsigned base_grid, const int seg_count, const int seg_min,
     float2 *__restrict__ seg_state) {
   __shared__ SplatA sA[kChunk];
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
   const float fy0 = (float)qy, fy1 = (float)(qy + 8);
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
 
-  float rho[4], S[4], vr[4], vg[4], vb[4];
+  float rho[4], S[4], vr[4], vg[4], vb[4], ve[4];
   int binf[4];
   bool in_img[4];
 #pragma unroll
@@ -566,6 +568,11 @@ __global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
     vr[p] = drawn ? r : 0.f;
     vg[p] = drawn ? g : 0.f;
     vb[p] = drawn ? b : 0.f;
+    ve[p] = 0.f;
+    if constexpr (RGBD) {
+      const float e = v_out_extra[pid];
+      ve[p] = drawn ? e : 0.f;
+    }
     binf[p] = drawn ? fi : -1;
     rho[p] = 1.f;
     S[p] = 0.f;
@@ -578,7 +585,7 @@ __global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
   for (int hi = top; hi >= range.x; hi -= kChunk) {
     const int sidx_l = hi - lane;
     const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics, colors, opacities,
-                                  sA, sB, sC, nullptr, nullptr, nullptr, allowed);
+                                  sA, sB, sC, nullptr, RGBD ? extra : nullptr, nullptr, allowed);
     __syncthreads();
     for (int t = 0; t < count; ++t) {
       const SplatA A = sA[t];
@@ -600,7 +607,8 @@ __global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
         const bool valid = (C.sidx <= binf[p]) && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
         const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
         const float rn = rho[p] * ra;
-        const float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
+        float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
+        if constexpr (RGBD) d += C.extra * ve[p];
         const float fac = valid ? alpha * rn : 0.f;
         rho[p] = valid ? rn : rho[p];
         S[p] += fac * d;
@@ -906,21 +914,30 @@ GSR_EXPORT size_t gsr_rasterize_backward_seg_workspace_bytes(unsigned img_height
 
 GSR_EXPORT int gsr_rasterize_backward_seg(
     unsigned img_height, unsigned img_width, int num_points, const int32_t *gaussian_ids_sorted,
-    const int32_t *tile_bins, const float *xys, const float *conics, const float *colors, const float *opacities,
-    const float *background, const float *final_Ts, const int32_t *final_idx, const float *v_output,
-    const float *v_output_alpha, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
-    int deep_tile_threshold, int accumulators_zeroed, int segments, int segment_min_entries, void *workspace,
-    size_t workspace_bytes, gsr_stream_t stream) {
-  if (segments < 2 || deep_tile_threshold <= 0)
+    const int32_t *tile_bins, const float *xys, const float *conics, const float *colors, const float *extra,
+    const float *opacities, const float *background, float extra_background, const float *final_Ts,
+    const int32_t *final_idx, const float *v_output, const float *v_output_extra, const float *v_output_alpha,
+    float *v_xy, float *v_conic, float *v_colors, float *v_extra, float *v_opacity, int deep_tile_threshold,
+    int accumulators_zeroed, int segments, int segment_min_entries, void *workspace, size_t workspace_bytes,
+    gsr_stream_t stream) {
+  const bool rgbd = extra != nullptr;
+  if (segments < 2 || deep_tile_threshold <= 0) {
+    if (rgbd)
+      return gsr_rasterize_backward_rgbd(img_height, img_width, num_points, gaussian_ids_sorted, tile_bins, xys, conics,
+                                         colors, extra, opacities, background, extra_background, final_Ts, final_idx,
+                                         v_output, v_output_extra, v_output_alpha, v_xy, v_conic, v_colors, v_extra,
+                                         v_opacity, deep_tile_threshold, accumulators_zeroed, stream);
     return gsr_rasterize_backward_ex(img_height, img_width, 16, num_points, gaussian_ids_sorted, tile_bins, xys, conics,
                                      colors, opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy,
                                      v_conic, v_colors, v_opacity, deep_tile_threshold, accumulators_zeroed, stream);
+  }
   GSR_REQUIRE(img_height > 0 && img_width > 0, "rasterize_backward_seg: empty image");
   GSR_REQUIRE(num_points >= 0, "rasterize_backward_seg: num_points < 0");
   GSR_REQUIRE(segments <= 16, "rasterize_backward_seg: at most 16 segments");
   if (num_points == 0) return GSR_OK;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background && final_Ts &&
-                  final_idx && v_output && v_xy && v_conic && v_colors && v_opacity,
+                  final_idx && v_output && v_xy && v_conic && v_colors && v_opacity &&
+                  (!rgbd || (v_output_extra && v_extra)),
               "rasterize_backward_seg: null pointer");
   GSR_REQUIRE(workspace && workspace_bytes >= gsr_rasterize_backward_seg_workspace_bytes(img_height, img_width, segments) &&
                   (reinterpret_cast<uintptr_t>(workspace) & 7) == 0,
@@ -929,23 +946,33 @@ GSR_EXPORT int gsr_rasterize_backward_seg(
   if (!accumulators_zeroed) {
     int rc = zero_grads(num_points, 3, v_xy, v_conic, v_colors, v_opacity, s);
     if (rc != GSR_OK) return rc;
+    if (rgbd)
+      if (int zrc = gsr_zero_async(v_extra, sizeof(float) * (size_t)num_points, s)) return zrc;
   }
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
   const int seg_min = segment_min_entries > deep_tile_threshold ? segment_min_entries : deep_tile_threshold;
   float2 *state = static_cast<float2 *>(workspace);
-  hipLaunchKernelGGL(raster_bwd_segstate_kernel, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s, tiles_x,
-                     num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
-                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
-                     opacities, final_Ts, final_idx, v_output, deep_tile_threshold, base, segments, seg_min, state);
-  hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, false, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,
-                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
-                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
-                     opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,
-                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep_tile_threshold,
-                     base, (float *)nullptr, (unsigned char *)nullptr, (const int2 *)nullptr, 0, segments, seg_min,
-                     (const float2 *)state);
+#define GSR_LAUNCH_BWD_SEG(RGBD_)                                                                                      \
+  hipLaunchKernelGGL(raster_bwd_segstate_kernel<RGBD_>, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s,    \
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                         \
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,  \
+                     opacities, final_Ts, final_idx, v_output, extra, v_output_extra, deep_tile_threshold, base,       \
+                     segments, seg_min, state);                                                                        \
+  hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, RGBD_, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s, \
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                         \
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,  \
+                     opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,    \
+                     v_opacity, extra, extra_background, v_output_extra, v_extra, deep_tile_threshold, base,           \
+                     (float *)nullptr, (unsigned char *)nullptr, (const int2 *)nullptr, 0, segments, seg_min,          \
+                     (const float2 *)state)
+  if (rgbd) {
+    GSR_LAUNCH_BWD_SEG(true);
+  } else {
+    GSR_LAUNCH_BWD_SEG(false);
+  }
+#undef GSR_LAUNCH_BWD_SEG
   GSR_CHECK_LAUNCH("rasterize_backward_seg");
   return GSR_OK;
 }

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr, const unsigned zero_words,
     const int round, int *__restrict__ tile_flags, const int idx_base, const int seg_count = 1, const int seg_min = 0,
     const float *__restrict__ seg_tau = nullptr, float4 *__restrict__ seg_raw = nullptr,
-    int *__restrict__ seg_last = nullptr) {
+    int *__restrict__ seg_last = nullptr, float *__restrict__ seg_extra = nullptr) {
   // Two-round compositing (gsr_rasterize_forward_round): the lists of the nearest
   // Gaussians are a PREFIX of every tile's list.  round 1 composites such prefix lists and leaves the per-pixel
   // state of a wave that still has a live pixel RAW -- final_Ts = signed T (< 0: finished), out_img / out_extra = C
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
           const size_t at = (size_t)seg_k * pixels + (size_t)row * img_w + col;
           seg_raw[at] = make_float4(cr[p], cg[p], cb[p], T[p]);
           seg_last[at] = last[p];
+          if constexpr (RGBD) seg_extra[at] = ce[p];
         }
       }
       return;
@@ -361,7 +362,8 @@ __global__ __launch_bounds__(256) void raster_fwd_segcombine_kernel(
     const int tiles_x, const int img_w, const int img_h, const int2 *__restrict__ tile_bins,
     const float *__restrict__ background, const int deep_threshold, const int seg_count, const int seg_min,
     const float4 *__restrict__ seg_raw, const int *__restrict__ seg_last, float *__restrict__ out_img,
-    float *__restrict__ final_Ts, int *__restrict__ final_idx, float *__restrict__ out_alpha) {
+    float *__restrict__ final_Ts, int *__restrict__ final_idx, float *__restrict__ out_alpha,
+    const float *__restrict__ seg_extra, const float bg_extra, float *__restrict__ out_extra) {
   const size_t pixels = (size_t)img_w * img_h;
   const size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pid >= pixels) return;
@@ -371,13 +373,14 @@ __global__ __launch_bounds__(256) void raster_fwd_segcombine_kernel(
   if (!(deep_threshold > 0 && len > deep_threshold) || len <= seg_min) return;
   const int sl = seg_len_of(len, seg_count);
   const int nseg = min(seg_count, (len + sl - 1) / sl);
-  float cr = 0.f, cg = 0.f, cb = 0.f, T = 1.f;
+  float cr = 0.f, cg = 0.f, cb = 0.f, ce = 0.f, T = 1.f;
   int last = 0;
   for (int k = 0; k < nseg; ++k) {
     const float4 r = seg_raw[(size_t)k * pixels + pid];
     cr += r.x;
     cg += r.y;
     cb += r.z;
+    if (seg_extra) ce += seg_extra[(size_t)k * pixels + pid];
     T = r.w;
     last = max(last, seg_last[(size_t)k * pixels + pid]);
     if (T < 0.f) break;
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(256) void raster_fwd_segcombine_kernel(
   out_img[3 * pid] = cr + Tp * background[0];
   out_img[3 * pid + 1] = cg + Tp * background[1];
   out_img[3 * pid + 2] = cb + Tp * background[2];
+  if (seg_extra) out_extra[pid] = ce + Tp * bg_extra;
 }
 
 // ------------------------------------------------------------- scan mapping
@@ -695,27 +699,35 @@ GSR_EXPORT int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block
 GSR_EXPORT size_t gsr_rasterize_forward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments) {
   if (segments < 2) return 0;
   const size_t px = (size_t)img_height * img_width;
-  // run products (segments - 1 floats, padded to 16 bytes) | raw states (segments float4) | last drawn indices
-  return (((size_t)(segments - 1) * px * 4 + 15) & ~(size_t)15) + (size_t)segments * px * 16 + (size_t)segments * px * 4;
+  // run products (segments - 1 floats, padded to 16 bytes) | raw states (segments float4) | last drawn indices |
+  // the extra channel's sums
+  return (((size_t)(segments - 1) * px * 4 + 15) & ~(size_t)15) + (size_t)segments * px * (16 + 4 + 4);
 }
 
 GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
                                          const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
                                          const float *xys, const float *conics, const float *colors,
-                                         const float *opacities, const float *background, float *out_img,
-                                         float *final_Ts, int32_t *final_idx, int deep_tile_threshold,
-                                         float *out_alpha, void *zero_ptr, size_t zero_bytes, int segments,
-                                         int segment_min_entries, void *workspace, size_t workspace_bytes,
-                                         gsr_stream_t stream) {
-  if (segments < 2 || deep_tile_threshold <= 0)
+                                         const float *extra, const float *opacities, const float *background,
+                                         float extra_background, float *out_img, float *out_extra, float *final_Ts,
+                                         int32_t *final_idx, int deep_tile_threshold, float *out_alpha, void *zero_ptr,
+                                         size_t zero_bytes, int segments, int segment_min_entries, void *workspace,
+                                         size_t workspace_bytes, gsr_stream_t stream) {
+  if (segments < 2 || deep_tile_threshold <= 0) {
+    if (extra)
+      return gsr_rasterize_forward_rgbd(tiles_x, tiles_y, img_width, img_height, gaussian_ids_sorted, tile_bins, xys,
+                                        conics, colors, extra, opacities, background, extra_background, out_img,
+                                        out_extra, final_Ts, final_idx, deep_tile_threshold, out_alpha, zero_ptr,
+                                        zero_bytes, stream);
     return gsr_rasterize_forward_ex(tiles_x, tiles_y, 16, img_width, img_height, gaussian_ids_sorted, tile_bins, xys,
                                     conics, colors, opacities, background, out_img, final_Ts, final_idx,
                                     deep_tile_threshold, out_alpha, zero_ptr, zero_bytes, stream);
+  }
   int rc = check_common("rasterize_forward_seg", tiles_x, tiles_y, 16, img_width, img_height, 3);
   if (rc != GSR_OK) return rc;
   GSR_REQUIRE(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background && out_img &&
                   final_Ts && final_idx,
               "rasterize_forward_seg: null pointer");
+  GSR_REQUIRE((extra == nullptr) == (out_extra == nullptr), "rasterize_forward_seg: extra and out_extra go together");
   GSR_REQUIRE(segments <= 16, "rasterize_forward_seg: at most 16 segments");
   GSR_REQUIRE(zero_ptr == nullptr || ((zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0 &&
                                       zero_bytes < ((size_t)1 << 34)),
@@ -732,21 +744,26 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
   float *tau = reinterpret_cast<float *>(ws);
   float4 *raw = reinterpret_cast<float4 *>(ws + (((size_t)(segments - 1) * px * 4 + 15) & ~(size_t)15));
   int *lastp = reinterpret_cast<int *>(reinterpret_cast<char *>(raw) + (size_t)segments * px * 16);
+  float *extrap = extra ? reinterpret_cast<float *>(lastp + (size_t)segments * px) : nullptr;
   hipLaunchKernelGGL(raster_fwd_segtau_kernel, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s, tiles_x,
                      num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
                      opacities, deep_tile_threshold, base, segments, seg_min, tau);
-  hipLaunchKernelGGL((raster_fwd_tile16_kernel<false, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,
-                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
-                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
-                     opacities, background, out_img, final_Ts, final_idx, (const float *)nullptr, 0.f, (float *)nullptr,
-                     deep_tile_threshold, base, out_alpha, static_cast<unsigned *>(zero_ptr),
-                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, (const float *)tau, raw,
-                     lastp);
+#define GSR_LAUNCH_FWD_SEG(RGBD_)                                                                                       \
+  hipLaunchKernelGGL((raster_fwd_tile16_kernel<RGBD_, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,      \
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,   \
+                     opacities, background, out_img, final_Ts, final_idx, extra, extra_background, out_extra,           \
+                     deep_tile_threshold, base, out_alpha, static_cast<unsigned *>(zero_ptr),                            \
+                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, (const float *)tau, raw,      \
+                     lastp, extrap)
+  if (extra) GSR_LAUNCH_FWD_SEG(true);
+  else GSR_LAUNCH_FWD_SEG(false);
+#undef GSR_LAUNCH_FWD_SEG
   hipLaunchKernelGGL(raster_fwd_segcombine_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, tiles_x,
                      (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), background,
                      deep_tile_threshold, segments, seg_min, (const float4 *)raw, (const int *)lastp, out_img, final_Ts,
-                     final_idx, out_alpha);
+                     final_idx, out_alpha, (const float *)extrap, extra_background, out_extra);
   GSR_CHECK_LAUNCH("rasterize_forward_seg");
   return GSR_OK;
 }

@@ -46,19 +46,13 @@ GSR_EXPORT int gsr_view_forward(const gsr_view_desc *v, gsr_stream_t stream) {
   GSR_TRY(gsr_bin_sorted_dev(n, v->capacity, v->order, v->counts ? v->cum : nullptr, v->xys, v->radii,
                              v->reach_records, tiles_x, tiles_y, 16, 1, v->ids, v->tile_bins, v->count_out, nullptr,
                              v->bin_ws, v->bin_ws_bytes, stream));
-  if (v->render_depth) {
-    GSR_REQUIRE(v->out_depth != nullptr, "view_forward: render_depth without out_depth");
-    GSR_TRY(gsr_rasterize_forward_rgbd(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
-                                       v->tile_bins, v->xys, v->conics, v->colors, v->depths, v->opac, v->background,
-                                       0.f, v->out_img, v->out_depth, v->final_Ts, v->final_idx,
-                                       v->deep_tile_threshold, v->out_alpha, v->zero_ptr, v->zero_bytes, stream));
-  } else {
-    GSR_TRY(gsr_rasterize_forward_seg(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
-                                      v->tile_bins, v->xys, v->conics, v->colors, v->opac, v->background, v->out_img,
-                                      v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
-                                      v->zero_bytes, v->segments, v->segment_min_entries, v->seg_ws, v->seg_ws_bytes,
-                                      stream));
-  }
+  GSR_REQUIRE(!v->render_depth || v->out_depth != nullptr, "view_forward: render_depth without out_depth");
+  GSR_TRY(gsr_rasterize_forward_seg(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
+                                    v->tile_bins, v->xys, v->conics, v->colors, v->render_depth ? v->depths : nullptr,
+                                    v->opac, v->background, 0.f, v->out_img, v->render_depth ? v->out_depth : nullptr,
+                                    v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
+                                    v->zero_bytes, v->segments, v->segment_min_entries, v->seg_ws, v->seg_ws_bytes,
+                                    stream));
   return GSR_OK;
 }
 
@@ -93,19 +87,12 @@ GSR_EXPORT int gsr_rasterize_gaussians_forward(const gsr_raster_desc *v, gsr_str
                              tiles_x, tiles_y, 16, 1, v->ids, v->tile_bins, v->count_out, nullptr, v->bin_ws,
                              v->bin_ws_bytes, stream));
   if (v->out_img == nullptr) return GSR_OK;  // the lists only (built ahead of time, composited by a later call)
-  if (v->extra) {
-    GSR_REQUIRE(v->out_extra != nullptr, "rasterize_gaussians_forward: extra channel without out_extra");
-    GSR_TRY(gsr_rasterize_forward_rgbd(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
-                                       v->tile_bins, v->xys, v->conics, v->colors, v->extra, v->opac, v->background,
-                                       v->extra_background, v->out_img, v->out_extra, v->final_Ts, v->final_idx,
-                                       v->deep_tile_threshold, v->out_alpha, v->zero_ptr, v->zero_bytes, stream));
-  } else {
-    GSR_TRY(gsr_rasterize_forward_seg(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
-                                      v->tile_bins, v->xys, v->conics, v->colors, v->opac, v->background, v->out_img,
-                                      v->final_Ts, v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr,
-                                      v->zero_bytes, v->segments, v->segment_min_entries, v->seg_ws, v->seg_ws_bytes,
-                                      stream));
-  }
+  GSR_REQUIRE(v->extra == nullptr || v->out_extra != nullptr, "rasterize_gaussians_forward: extra channel without out_extra");
+  GSR_TRY(gsr_rasterize_forward_seg(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
+                                    v->tile_bins, v->xys, v->conics, v->colors, v->extra, v->opac, v->background,
+                                    v->extra_background, v->out_img, v->extra ? v->out_extra : nullptr, v->final_Ts,
+                                    v->final_idx, v->deep_tile_threshold, v->out_alpha, v->zero_ptr, v->zero_bytes,
+                                    v->segments, v->segment_min_entries, v->seg_ws, v->seg_ws_bytes, stream));
   return GSR_OK;
 }
 
@@ -117,20 +104,14 @@ GSR_EXPORT int gsr_view_backward(const gsr_view_desc *v, const gsr_view_grads *g
   float *acc = g->accumulators;
   GSR_REQUIRE(acc != nullptr && g->v_img != nullptr, "view_backward: null pointer");
   float *v_xy = acc, *v_conic = acc + 2 * N, *v_colors = acc + 5 * N, *v_opac = acc + 8 * N, *v_extra = acc + 9 * N;
-  if (v->render_depth) {
-    GSR_REQUIRE(g->v_depth != nullptr, "view_backward: render_depth without its cotangent");
-    GSR_TRY(gsr_rasterize_backward_rgbd((unsigned)v->img_height, (unsigned)v->img_width, n, v->ids, v->tile_bins,
-                                        v->xys, v->conics, v->colors, v->depths, v->opac, v->background, 0.f,
-                                        v->final_Ts, v->final_idx, g->v_img, g->v_depth, g->v_alpha, v_xy, v_conic,
-                                        v_colors, v_extra, v_opac, v->deep_tile_threshold, g->accumulators_zeroed,
-                                        stream));
-  } else {
-    GSR_TRY(gsr_rasterize_backward_seg((unsigned)v->img_height, (unsigned)v->img_width, n, v->ids, v->tile_bins,
-                                       v->xys, v->conics, v->colors, v->opac, v->background, v->final_Ts,
-                                       v->final_idx, g->v_img, g->v_alpha, v_xy, v_conic, v_colors, v_opac,
-                                       v->deep_tile_threshold, g->accumulators_zeroed, v->segments,
-                                       v->segment_min_entries, v->seg_ws, v->seg_ws_bytes, stream));
-  }
+  GSR_REQUIRE(!v->render_depth || g->v_depth != nullptr, "view_backward: render_depth without its cotangent");
+  GSR_TRY(gsr_rasterize_backward_seg((unsigned)v->img_height, (unsigned)v->img_width, n, v->ids, v->tile_bins, v->xys,
+                                     v->conics, v->colors, v->render_depth ? v->depths : nullptr, v->opac,
+                                     v->background, 0.f, v->final_Ts, v->final_idx, g->v_img,
+                                     v->render_depth ? g->v_depth : nullptr, g->v_alpha, v_xy, v_conic, v_colors,
+                                     v->render_depth ? v_extra : nullptr, v_opac, v->deep_tile_threshold,
+                                     g->accumulators_zeroed, v->segments, v->segment_min_entries, v->seg_ws,
+                                     v->seg_ws_bytes, stream));
   if (g->stats_first != nullptr)
     GSR_TRY(gsr_densify_stats_dev(n, v_xy, v->radii, g->stats_inv_size, g->stats_first, g->xys_grad_norm,
                                   g->vis_counts, g->max_2dsize, stream));

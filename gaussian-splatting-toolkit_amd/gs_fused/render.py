@@ -62,12 +62,15 @@ class _ViewGrads(C.Structure):  # gsr_view_grads
 
 
 def _segments(spec, capacity, dev):
-    """(segments, minimum entries, workspace pointer, bytes) of the view's compositing (rasterizer.cuda.depth_segments;
-    RGB only).  The workspace is scratch of ONE call: the caching allocator hands the block back to the next one."""
-    if spec.render_depth:
-        return 0, 0, None, 0
+    """(segments, minimum entries, workspace tensor or None) of the view's compositing
+    (rasterizer.cuda.depth_segments).  The workspace is scratch of ONE call; the caller keeps the tensor until the
+    call has been issued."""
     tb = spec.tile_bounds
-    segs, seg_min, ws = _C._forward_segments(capacity, tb[0] * tb[1], spec.height, spec.width, dev)
+    return _C._forward_segments(capacity, tb[0] * tb[1], spec.height, spec.width, dev)
+
+
+def _seg_fields(seg):
+    segs, seg_min, ws = seg
     if ws is None:
         return 0, 0, None, 0
     return segs, seg_min, ws.data_ptr(), ws.numel()
@@ -157,6 +160,7 @@ class _Render(Function):
             # alpha = 1 - T and the backward's cleared accumulators come out of the compositing launch
             acc = _C.backward_accumulators(n, 4 if spec.render_depth else 3, dev) if any(ctx.needs_input_grad[:6]) else None
             p = lambda t: None if t is None else t.data_ptr()
+            seg = _segments(spec, capacity, dev)
             desc = _ViewDesc(n, degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy, spec.cx,
                              spec.cy, spec.glob_scale, spec.clip_thresh, capacity,
                              _C.deep_tile_threshold(capacity, tb[0] * tb[1]),
@@ -165,8 +169,9 @@ class _Render(Function):
                              p(cov3d), p(xys), p(depths), p(radii), p(conics), p(comp), p(tiles), p(colors), p(recs),
                              p(counts), p(order), p(cum), p(ids), p(bins), p(count_out), p(sort_ws), sort_b,
                              p(bin_ws), bin_b, p(img), p(dep), p(Ts), p(idx), p(alpha), p(acc),
-                             0 if acc is None else acc.numel() * 4, *_segments(spec, capacity, dev))
+                             0 if acc is None else acc.numel() * 4, *_seg_fields(seg))
             _call("gsr_view_forward", C.byref(desc), _stream(dev))
+            del seg
         ctx.spec, ctx.stats, ctx.degree = spec, stats, degree
         ctx.sh_collector = sh_collector
         ctx.set_materialize_grads(False)
@@ -209,6 +214,7 @@ class _Render(Function):
                 v_dc = v_rest = None
             use_stats = stats is not None and stats.enabled
             p = lambda t: None if t is None else t.data_ptr()
+            seg = _segments(spec, ctx.capacity, dev)
             desc = _ViewDesc(n, ctx.degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy,
                              spec.cx, spec.cy, spec.glob_scale, spec.clip_thresh, ctx.capacity,
                              _C.deep_tile_threshold(ctx.capacity, tb[0] * tb[1], backward=True),
@@ -216,13 +222,14 @@ class _Render(Function):
                              p(projmat), None, p(background), p(scales), p(quats), p(opac), p(dirs), p(cov3d), p(xys),
                              p(depths), p(radii), p(conics), p(comp), None, p(colors), None, None, None, None, p(ids),
                              p(bins), None, None, 0, None, 0, None, None, p(Ts), p(idx), None, None, 0,
-                             *_segments(spec, ctx.capacity, dev))
+                             *_seg_fields(seg))
             grads = _ViewGrads(p(v_img), p(v_a), p(v_dep) if spec.render_depth else None, p(acc), int(zeroed),
                                p(stats.first) if use_stats else None, (1.0 / stats.max_dim) if use_stats else 0.0,
                                p(stats.xys_grad_norm) if use_stats else None, p(stats.vis_counts) if use_stats else None,
                                p(stats.max_2dsize) if use_stats else None, p(t_cov2d), p(t_cov3d), p(t_vs), p(t_vq),
                                p(v_means), p(g_s), p(g_q), p(g_o), p(v_dc), p(v_rest))
             _call("gsr_view_backward", C.byref(desc), C.byref(grads), _stream(dev))
+            del seg
             if use_stats:
                 stats.first.zero_()
             if collector is not None:

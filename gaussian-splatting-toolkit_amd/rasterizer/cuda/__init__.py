@@ -718,8 +718,7 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
             zero_bytes = zero.numel() * 4
             if zero_bytes == 0:
                 zero = None
-        segs, seg_min, seg_ws = _forward_segments(capacity, tb[0] * tb[1], H, W, dev) if composite and extra is None \
-            else (0, 0, None)
+        segs, seg_min, seg_ws = _forward_segments(capacity, tb[0] * tb[1], H, W, dev) if composite else (0, 0, None)
         desc = _RasterDesc(n, H, W, int(capacity), deep_tile_threshold(capacity, tb[0] * tb[1]), float(extra_background),
                            xys.data_ptr(), depths.data_ptr(), radii.data_ptr(), conics.data_ptr(),
                            p(colors) if composite else None, p(extra), opacities.data_ptr(),
@@ -751,8 +750,8 @@ def composite_prepared(tile_bounds, img_width: int, img_height: int, gaussian_id
         segs, seg_min, seg_ws = _forward_segments(gaussian_ids_sorted.numel(), tiles, int(img_height), int(img_width), dev)
         _call("gsr_rasterize_forward_seg", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
               C.c_uint(int(img_width)), C.c_uint(int(img_height)), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys),
-              _ptr(conics), _ptr(colors), _ptr(opacities), _ptr(background), _ptr(out_img), _ptr(Ts), _ptr(idx),
-              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)),
+              _ptr(conics), _ptr(colors), None, _ptr(opacities), _ptr(background), C.c_float(0.0), _ptr(out_img), None,
+              _ptr(Ts), _ptr(idx), C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)),
               _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero_bytes else None, C.c_size_t(zero_bytes),
               C.c_int(segs), C.c_int(seg_min), _ptr(seg_ws) if seg_ws is not None else None,
               C.c_size_t(seg_ws.numel() if seg_ws is not None else 0), _stream(dev))
@@ -801,8 +800,9 @@ def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_b
                            _ptr(zero) if zero is not None else None,
                            C.c_size_t(zero.numel() * 4 if zero is not None else 0))
                 if segs > 1:
-                    _call("gsr_rasterize_forward_seg", head[0], head[1], head[3], head[4], *tail, *tail_ex, C.c_int(segs),
-                          C.c_int(seg_min), _ptr(seg_ws), C.c_size_t(seg_ws.numel()), _stream(dev))
+                    _call("gsr_rasterize_forward_seg", head[0], head[1], head[3], head[4], *tail[:5], None, *tail[5:7],
+                          C.c_float(0.0), tail[7], None, *tail[8:], *tail_ex, C.c_int(segs), C.c_int(seg_min),
+                          _ptr(seg_ws), C.c_size_t(seg_ws.numel()), _stream(dev))
                 else:
                     _call("gsr_rasterize_forward_ex", *head, *tail, *tail_ex, _stream(dev))
                 return (out_img, final_Ts, final_idx, alpha) if ex else (out_img, final_Ts, final_idx)
@@ -863,13 +863,16 @@ def rasterize_forward_rgbd(tile_bounds, img_size, gaussian_ids_sorted, tile_bins
         alpha = torch.empty((H, W), dtype=_f32, device=dev) if want_alpha else None
         if zero is not None:
             _check(zero, "zero", _f32)
-        _call("gsr_rasterize_forward_rgbd", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(W),
+        segs, seg_min, seg_ws = _forward_segments(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], H, W, dev)
+        _call("gsr_rasterize_forward_seg", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]), C.c_uint(W),
               C.c_uint(H), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
               _ptr(extra), _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(img), _ptr(ext),
               _ptr(Ts), _ptr(idx),
               C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])),
               _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero is not None else None,
-              C.c_size_t(zero.numel() * 4 if zero is not None else 0), _stream(dev))
+              C.c_size_t(zero.numel() * 4 if zero is not None else 0), C.c_int(segs), C.c_int(seg_min),
+              _ptr(seg_ws) if seg_ws is not None else None, C.c_size_t(seg_ws.numel() if seg_ws is not None else 0),
+              _stream(dev))
     if want_alpha:
         return img, ext, Ts, idx, alpha
     return img, ext, Ts, idx
@@ -896,15 +899,18 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
         v_xy, v_conic = flat[: 2 * n].view(n, 2), flat[2 * n: 5 * n].view(n, 3)
         v_colors, v_opacity = flat[5 * n: 8 * n].view(n, 3), flat[8 * n: 9 * n].view(n, 1)
         v_extra = flat[9 * n:]
-        _call("gsr_rasterize_backward_rgbd", C.c_uint(img_height), C.c_uint(img_width), C.c_int(n),
+        tiles = ((img_width + 15) // 16) * ((img_height + 15) // 16)
+        segs, seg_min = depth_segments(gaussian_ids_sorted.numel(), tiles)
+        ws = torch.empty(((segs - 1) * int(img_height) * int(img_width), 2), dtype=_f32, device=dev) if segs > 1 else None
+        _call("gsr_rasterize_backward_seg", C.c_uint(img_height), C.c_uint(img_width), C.c_int(n),
               _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors), _ptr(extra),
               _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(final_Ts), _ptr(final_idx),
               _ptr(v_output), _ptr(v_output_extra),
               _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic),
               _ptr(v_colors), _ptr(v_extra), _ptr(v_opacity),
-              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(),
-                                          ((img_width + 15) // 16) * ((img_height + 15) // 16), backward=True)),
-              C.c_int(1 if accumulators is not None else 0), _stream(dev))
+              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)),
+              C.c_int(1 if accumulators is not None else 0), C.c_int(segs if ws is not None else 0), C.c_int(seg_min),
+              _ptr(ws) if ws is not None else None, C.c_size_t(ws.numel() * 4 if ws is not None else 0), _stream(dev))
     return v_xy, v_conic, v_colors, v_extra, v_opacity
 
 
@@ -997,7 +1003,8 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
             if segs > 1:
                 deep = deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)
                 ws = torch.empty(((segs - 1) * int(img_height) * int(img_width), 2), dtype=_f32, device=dev)
-                _call("gsr_rasterize_backward_seg", C.c_uint(img_height), C.c_uint(img_width), *tail, C.c_int(deep),
+                _call("gsr_rasterize_backward_seg", C.c_uint(img_height), C.c_uint(img_width), *tail[:6], None,
+                      *tail[6:8], C.c_float(0.0), *tail[8:11], None, *tail[11:15], None, tail[15], C.c_int(deep),
                       C.c_int(1 if zeroed else 0), C.c_int(segs), C.c_int(seg_min), _ptr(ws),
                       C.c_size_t(ws.numel() * 4), _stream(dev))
             elif zeroed:

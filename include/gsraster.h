@@ -319,7 +319,7 @@ int gsr_rasterize_backward_ex(unsigned img_height, unsigned img_width,
                               float *v_opacity, int deep_tile_threshold,
                               int accumulators_zeroed, gsr_stream_t stream);
 
-/* gsr_rasterize_forward_ex (16x16 tiles, 3 channels) with DEPTH SEGMENTS: the list of every tile that is split over
+/* gsr_rasterize_forward_ex / _rgbd (16x16 tiles, 3 channels [+ one]) with DEPTH SEGMENTS: the list of every tile that is split over
  * four waves (deep_tile_threshold) and holds more than max(deep_tile_threshold, segment_min_entries) entries is cut
  * into `segments` (2..16) runs of whole 64-entry chunks.  A pre-pass computes every run's transmittance product per
  * pixel; each run is then composited by its own waves from the true incoming T (the stop rule of forward.cu:278-395
@@ -328,16 +328,18 @@ int gsr_rasterize_backward_ex(unsigned img_height, unsigned img_width,
  * gsr_rasterize_forward_ex's to rounding.  workspace: gsr_rasterize_forward_seg_workspace_bytes(...) bytes, 16-byte
  * aligned.  segments < 2 or deep_tile_threshold <= 0: gsr_rasterize_forward_ex. */
 size_t gsr_rasterize_forward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments);
+/* extra / out_extra: NULL, or the fourth channel of gsr_rasterize_forward_rgbd ([n] / [P], over extra_background) */
 int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
                               const float *xys, const float *conics, const float *colors,
-                              const float *opacities, const float *background, float *out_img,
+                              const float *extra, const float *opacities, const float *background,
+                              float extra_background, float *out_img, float *out_extra,
                               float *final_Ts, int32_t *final_idx, int deep_tile_threshold,
                               float *out_alpha, void *zero_ptr, size_t zero_bytes, int segments,
                               int segment_min_entries, void *workspace, size_t workspace_bytes,
                               gsr_stream_t stream);
 
-/* gsr_rasterize_backward_ex (16x16 tiles) with DEPTH SEGMENTS: the list of every tile that is split over four waves
+/* gsr_rasterize_backward_ex / _rgbd (16x16 tiles) with DEPTH SEGMENTS: the list of every tile that is split over four waves
  * (deep_tile_threshold) and holds more than max(deep_tile_threshold, segment_min_entries) entries is cut into
  * `segments` (2..16) runs, each walked by its own waves; a pre-pass computes what every run does to the backward's
  * per-pixel state (backward.cu:133-303: T and the colour buffer -- an affine map per run), so the runs are
@@ -346,13 +348,15 @@ int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsi
  * workspace: gsr_rasterize_backward_seg_workspace_bytes(img_height, img_width, segments) bytes, 8-byte aligned.
  * segments < 2 or deep_tile_threshold <= 0: gsr_rasterize_backward_ex. */
 size_t gsr_rasterize_backward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments);
+/* extra / v_output_extra / v_extra: NULL, or the fourth channel as in gsr_rasterize_backward_rgbd */
 int gsr_rasterize_backward_seg(unsigned img_height, unsigned img_width, int num_points,
                                const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
                                const float *xys, const float *conics, const float *colors,
-                               const float *opacities, const float *background,
-                               const float *final_Ts, const int32_t *final_idx,
-                               const float *v_output, const float *v_output_alpha,
-                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                               const float *extra, const float *opacities, const float *background,
+                               float extra_background, const float *final_Ts, const int32_t *final_idx,
+                               const float *v_output, const float *v_output_extra,
+                               const float *v_output_alpha, float *v_xy, float *v_conic,
+                               float *v_colors, float *v_extra, float *v_opacity,
                                int deep_tile_threshold, int accumulators_zeroed, int segments,
                                int segment_min_entries, void *workspace, size_t workspace_bytes,
                                gsr_stream_t stream);
@@ -595,7 +599,7 @@ typedef struct gsr_view_desc {
   float *out_alpha;
   void *zero_ptr;
   size_t zero_bytes;
-  /* depth segments of the compositing, forward and backward (gsr_rasterize_forward_seg / _backward_seg; RGB only):
+  /* depth segments of the compositing, forward and backward (gsr_rasterize_forward_seg / _backward_seg):
    * segments < 2 = off; seg_ws: gsr_rasterize_forward_seg_workspace_bytes(...) bytes (enough for the backward too) */
   int segments, segment_min_entries;
   void *seg_ws;
@@ -660,8 +664,7 @@ typedef struct gsr_raster_desc {
   float *out_alpha;
   void *zero_ptr;
   size_t zero_bytes;
-  /* depth segments of the compositing (gsr_rasterize_forward_seg): segments < 2 = off; the extra channel composites
-   * without them */
+  /* depth segments of the compositing (gsr_rasterize_forward_seg): segments < 2 = off */
   int segments, segment_min_entries;
   void *seg_ws;
   size_t seg_ws_bytes;

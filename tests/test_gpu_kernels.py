@@ -778,8 +778,8 @@ def test_deep_tiles_split_over_four_waves_give_identical_results(rgbd, monkeypat
             assert (x - y).abs().max().item() <= 2e-5 * scale
 
 
-@pytest.mark.parametrize("opaque", [False, True])
-def test_depth_segments_of_the_forward_equal_the_single_walk(opaque, monkeypatch):
+@pytest.mark.parametrize("opaque,rgbd", [(False, False), (True, False), (True, True)])
+def test_depth_segments_of_the_forward_equal_the_single_walk(opaque, rgbd, monkeypatch):
     """gsr_rasterize_forward_seg: the lists of the split tiles cut into 2 .. 16 runs; a pre-pass gives every run the
     transmittance in front of it, the runs composite in parallel with the unchanged stop rule, a combine pass adds
     them up in list order.  Image and final T equal the single walk's to rounding; the last drawn index is the same
@@ -805,6 +805,11 @@ def test_depth_segments_of_the_forward_equal_the_single_walk(opaque, monkeypatch
     def run(segs, least, threshold=96, ex=True):
         monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
         monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (segs, least))
+        if rgbd:  # the fourth channel (the depths) rides in the colour image's fourth plane for the comparison
+            img, ext, T, idx, a = C.rasterize_forward_rgbd(tb, (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors),
+                                                           cu(depths), cu(opac), bg, 0.25, want_alpha=True)
+            out = (torch.cat([img, ext[..., None] / float(depths.max())], -1), T, idx, a)
+            return out if ex else out[:3]
         if ex:
             return C.rasterize_forward_ex(tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors),
                                           cu(opac), bg, want_alpha=True)
@@ -824,8 +829,8 @@ def test_depth_segments_of_the_forward_equal_the_single_walk(opaque, monkeypatch
         run(17, 64)
 
 
-@pytest.mark.parametrize("opaque", [False, True])
-def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, monkeypatch):
+@pytest.mark.parametrize("opaque,rgbd", [(False, False), (True, False), (True, True)])
+def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, rgbd, monkeypatch):
     """gsr_rasterize_backward_seg: the lists of the split tiles cut into 2 .. 16 runs, every run walked by its own
     waves from the state a pre-pass computed (T and the colour buffer are mapped affinely by a run).  Gradients equal
     the single walk's to rounding: a long-tail scene (lists of several thousand entries next to short ones; runs
@@ -851,6 +856,8 @@ def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, monkeypatc
     bg = cu(np.array(S.BACKGROUND, np.float32))
     v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
     v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
+    v_ext = torch.rand(H, W, device=DEV) * 2 - 1
+    monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))
     f = C.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors), cu(opac), bg)
     if opaque:
         assert (f[1] < 1e-3).float().mean().item() > 0.5  # most pixels saturated
@@ -858,6 +865,9 @@ def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, monkeypatc
     def run(segs, least, threshold=96):
         monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
         monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (segs, least))
+        if rgbd:
+            return C.rasterize_backward_rgbd(H, W, ids, bins, cu(xys), cu(conics), cu(colors), cu(depths), cu(opac), bg,
+                                             0.25, f[1], f[2], v_img, v_ext, v_alpha)
         return C.rasterize_backward(H, W, bw, ids, bins, cu(xys), cu(conics), cu(colors), cu(opac), bg, f[1], f[2],
                                     v_img, v_alpha)
 
