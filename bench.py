@@ -320,7 +320,7 @@ def train_only(args):
             "loss_first_last": [losses[0], losses[-1]],
             "phase_ms_median": res["phase_ms_median"],
             "phase_ms_median_by_resolution": res["phase_ms_median_by_resolution"],
-            "schedule": res["schedule"],
+            "schedule": res["schedule"], "depth_segments": res.get("depth_segments"),
             "list_overflow_views": res["list_overflow_views"],
             "render": res["render"],
             "scene": (f"hidden truth: {cfg.num_gaussians} flat textured Gaussians on {cfg.scene_objects[0]} spheres in a ball of "

@@ -383,6 +383,18 @@ class TrainConfig:
     fused_target: bool = True
 
 
+def _depth_segments_record(device):
+    """What the compositing kernels do on tile grids too small to fill the chip (rasterizer.cuda.depth_segments)."""
+    if device.type != "cuda":
+        return None
+    import rasterizer.cuda as _C
+
+    segs, grid, least = _C._segment_knobs()
+    return {"runs": segs, "tile_grids_up_to": grid, "lists_longer_than": least,
+            "what": "on such grids the list of every split tile is cut into runs composited by their own waves "
+                    "(gsr_rasterize_forward_seg / _backward_seg): results equal the single walk's to rounding"}
+
+
 def _sh_views_backward_autograd():
     """CPU stand-in of gs_fused.sh_backward_views: the same sum over views through the autograd of whatever
     `harness.pipeline.spherical_harmonics` is (SH is linear in the coefficients)."""
@@ -795,6 +807,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             "render": ("hip graph per view" if cfg.use_graph else "one fused op") if use_fused else "separate ops",
             "list_overflow_views": overflow_views + (_list_rebuilds() - rebuilds0), "phase_ms_median": phases,
             "phase_ms_median_by_resolution": phases_by_res,
+            "depth_segments": _depth_segments_record(device),
             "schedule": {"num_downscales": cfg.num_downscales, "resolution_schedule": cfg.resolution_schedule,
                          "background_color": cfg.background_color, "caller_syncs": cfg.caller_syncs},
             "update": "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
