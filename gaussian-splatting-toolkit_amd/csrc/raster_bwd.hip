@@ -359,14 +359,14 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
       binf[p] = drawn ? in_idx[p] : -1;
     }
   }
-  if constexpr (SEG) {  // the state behind this segment: the maps of the segments after it, farthest first
-    const size_t pixels = (size_t)img_w * img_h;
-    for (int j = seg_k + seg_behind; j > seg_k; --j) {
+  if constexpr (SEG) {  // the state behind this run: ONE composed map per pixel (raster_bwd_segprefix_kernel)
+    if (seg_behind > 0) {
+      const size_t pixels = (size_t)img_w * img_h;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
         if (in_img[p]) {
-          const float2 st = seg_state[(size_t)(j - 1) * pixels + (size_t)row * img_w + col];
+          const float2 st = seg_state[(size_t)seg_k * pixels + (size_t)row * img_w + col];
           K[p] -= T[p] * st.y;
           T[p] *= st.x;
         }
@@ -621,6 +621,32 @@ __global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
   for (int p = 0; p < 4; ++p) {
     const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
     if (in_img[p]) seg_state[(size_t)(seg_k - 1) * pixels + (size_t)row * img_w + col] = make_float2(rho[p], S[p]);
+  }
+}
+
+// Between the pre-pass and the runs: per pixel of a split tile, the runs' maps (R_j, S_j), j = 1 .. n - 1 (stored at
+// j - 1) become, in place, the composed maps run k starts from, k = 0 .. n - 2 (stored at k): everything behind run k
+// applied in walk order, farthest run first -- (A, B) with T = T_final A, K = K_0 - T_final B; composing run j onto
+// (A, B) gives (A R_j, B + A S_j).  A wave of run k then loads one map per pixel instead of n - 1 - k.
+__global__ __launch_bounds__(256) void raster_bwd_segprefix_kernel(
+    const int tiles_x, const int img_w, const int img_h, const int2 *__restrict__ tile_bins, const int deep_threshold,
+    const int seg_count, const int seg_min, float2 *__restrict__ seg_state) {
+  const size_t pixels = (size_t)img_w * img_h;
+  const size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= pixels) return;
+  const int row = (int)(pid / img_w), col = (int)(pid - (size_t)row * img_w);
+  const int2 range = tile_bins[(row >> 4) * tiles_x + (col >> 4)];
+  const int len = range.y - range.x;
+  if (!(deep_threshold > 0 && len > deep_threshold) || len <= seg_min) return;
+  const int sl = seg_len_of(len, seg_count);
+  const int nseg = min(seg_count, (len + sl - 1) / sl);
+  float A = 1.f, B = 0.f;
+  for (int k = nseg - 2; k >= 0; --k) {  // run k + 1's map sits at k
+    float2 *q = seg_state + (size_t)k * pixels + pid;
+    const float2 rs = *q;
+    B += A * rs.y;
+    A *= rs.x;
+    *q = make_float2(A, B);
   }
 }
 
@@ -960,6 +986,9 @@ GSR_EXPORT int gsr_rasterize_backward_seg(
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,  \
                      opacities, final_Ts, final_idx, v_output, extra, v_output_extra, deep_tile_threshold, base,       \
                      segments, seg_min, state);                                                                        \
+  hipLaunchKernelGGL(raster_bwd_segprefix_kernel, dim3((unsigned)(((size_t)img_height * img_width + 255) / 256)),     \
+                     dim3(256), 0, s, tiles_x, (int)img_width, (int)img_height,                                        \
+                     reinterpret_cast<const int2 *>(tile_bins), deep_tile_threshold, segments, seg_min, state);        \
   hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, RGBD_, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s, \
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                         \
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,  \

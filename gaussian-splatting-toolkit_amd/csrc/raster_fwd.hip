@@ -146,11 +146,10 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       last[p] = final_idx[pid];
     }
     if constexpr (SEG) {
-      if (split && inside) {  // the transmittance the runs in front of this one leave (0: finished there)
+      if (split && inside && seg_k > 0) {  // the transmittance the runs in front of this one leave (0: finished
+        // there): ONE load -- raster_fwd_segprefix_kernel has turned the runs' products into prefix products
         const size_t pixels = (size_t)img_w * img_h, pid = (size_t)row * img_w + col;
-        float t = 1.f;
-        for (int j = 0; j < seg_k; ++j) t *= seg_tau[(size_t)j * pixels + pid];
-        T[p] = t;
+        T[p] = seg_tau[(size_t)(seg_k - 1) * pixels + pid];
       }
     }
   }
@@ -352,6 +351,30 @@ __global__ __launch_bounds__(64) void raster_fwd_segtau_kernel(
     const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
     if (col < img_w && row < img_h && ((allowed >> p) & 1))
       seg_tau[(size_t)seg_k * pixels + (size_t)row * img_w + col] = T[p] > 0.f ? T[p] : 0.f;
+  }
+}
+
+// Between the pre-pass and the runs: per pixel of a split tile, the runs' products tau_0 .. tau_{n-2} become the prefix
+// products P_1 .. P_{n-1} in place (P_k = tau_0 ... tau_{k-1}, multiplied in list order: what run k starts from).  A
+// wave of run k then needs one load per pixel instead of k dependent ones -- 15 L2 round trips per pixel for the
+// last of 16 runs, more than its whole walk takes.
+__global__ __launch_bounds__(256) void raster_fwd_segprefix_kernel(
+    const int tiles_x, const int img_w, const int img_h, const int2 *__restrict__ tile_bins, const int deep_threshold,
+    const int seg_count, const int seg_min, float *__restrict__ seg_tau) {
+  const size_t pixels = (size_t)img_w * img_h;
+  const size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= pixels) return;
+  const int row = (int)(pid / img_w), col = (int)(pid - (size_t)row * img_w);
+  const int2 range = tile_bins[(row >> 4) * tiles_x + (col >> 4)];
+  const int len = range.y - range.x;
+  if (!(deep_threshold > 0 && len > deep_threshold) || len <= seg_min) return;
+  const int sl = seg_len_of(len, seg_count);
+  const int nseg = min(seg_count, (len + sl - 1) / sl);
+  float t = 1.f;
+  for (int k = 0; k + 1 < nseg; ++k) {
+    float *q = seg_tau + (size_t)k * pixels + pid;
+    t *= *q;
+    *q = t;
   }
 }
 
@@ -749,6 +772,9 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
                      num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
                      opacities, deep_tile_threshold, base, segments, seg_min, tau);
+  hipLaunchKernelGGL(raster_fwd_segprefix_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, tiles_x,
+                     (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), deep_tile_threshold,
+                     segments, seg_min, tau);
 #define GSR_LAUNCH_FWD_SEG(RGBD_)                                                                                       \
   hipLaunchKernelGGL((raster_fwd_tile16_kernel<RGBD_, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,      \
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \

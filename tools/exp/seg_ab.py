@@ -1,7 +1,7 @@
 """Depth segments in the compositing backward (gsr_rasterize_backward_seg) against the single walk:
 gradients (max error relative to max |ref| per tensor) and the time of the rasterizer's backward.
    python tools/exp/seg_ab.py [W H N] [reps]      BLOB=1: the trainer's object scene (deep centre tiles)"""
-import os, sys
+import gc, os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gaussian-splatting-toolkit_amd")]
 import numpy as np
@@ -44,6 +44,7 @@ def run(segs):
     ins = [t.clone().requires_grad_(True) for t in (xys, conics, colors, opac)]
     img, alpha = rasterize_gaussians(ins[0], depths, radii, ins[1], tiles, ins[2], ins[3], H, W, 16, bg, return_alpha=True)
     torch.cuda.synchronize()
+    gc.collect()  # (a full collection inside a 30-call loop is a 2 ms-per-call artefact)
     f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.no_grad():
         f0.record()
@@ -56,6 +57,7 @@ def run(segs):
     loss = (img * v_img).sum() + (alpha * v_alpha).sum()
     grads = torch.autograd.grad(loss, ins, retain_graph=True)
     torch.cuda.synchronize()
+    gc.collect()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -68,7 +70,7 @@ def run(segs):
 ref, t1, img1 = run(1)
 print(f"{W}x{H} ({ntiles} tiles), {n} Gaussians, visible {int((radii > 0).sum())}, intersections {int(tiles.sum())}")
 print(f"segments 1: forward (lists + compositing) {t_fwd:8.1f} us  backward {t1:8.1f} us")
-for segs in (2, 4, 8):
+for segs in [int(x) for x in os.environ.get("SEGS", "2,4,8").split(",")]:
     got, t, img = run(segs)
     errs = [float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(got, ref)]
     l2 = [float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(got, ref)]
