@@ -563,7 +563,7 @@ def depth_segments(list_entries: int, num_tiles: int):
     818 / 825 -> 871 (8 runs) -> 885 iterations/s (16).  On larger grids the kernels are bound by their total work,
     which the pre-passes raise: 960 x 540 unchanged, the long-tail 1080p scene 0.62 -> 0.67 ms (backward), the default
     0.427 -> 0.448 ms (the empty workgroups of the segment grid) -- off there."""
-    segs, grid, least = _segment_knobs()
+    segs, grid, least, _ = _segment_knobs()
     _, _, small_grid, _, small_grid_bwd = _deep_knobs()
     # (only where EVERY tile above the small-grid floor is split, forward and backward alike: which tiles are cut, and
     #  where, is then a function of the tile's list alone and every route to the kernels rounds the same way)
@@ -575,6 +575,12 @@ def depth_segments(list_entries: int, num_tiles: int):
 def _forward_segments(list_entries: int, num_tiles: int, H: int, W: int, dev):
     """-> (segments, minimum entries, workspace or None) of ``gsr_rasterize_forward_seg`` for this tile grid."""
     segs, seg_min = depth_segments(list_entries, num_tiles)
+    if segs > 1:
+        # GSR_DEPTH_SEGMENTS_FWD: fewer (or no) runs for the forward alone.  Its pre-pass walks every run from T = 1 to
+        # the run's own saturation: on an OPAQUE scene that is most of the list, where the single walk stops early
+        # (300 k opaque Gaussians at 480 x 270: forward 338 us single, 295 with 4 runs, 432 with 16); a training view
+        # of a young, transparent model gains up to the 16 (profiles/r04_depth_segments.txt)
+        segs = min(segs, _segment_knobs()[3]) if _segment_knobs()[3] > 0 else segs
     if segs < 2:
         return 0, 0, None
     nbytes = int(_lib().gsr_rasterize_forward_seg_workspace_bytes(C.c_uint(H), C.c_uint(W), C.c_int(segs)))
@@ -590,7 +596,8 @@ def _segment_knobs():
 
         _segment_cache["v"] = (int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_GRID", "1100")),
-                               int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")))
+                               int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")),
+                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "0")))
     return _segment_cache["v"]
 
 
