@@ -84,3 +84,38 @@ def test_two_round_plan_asks_for_the_culled_count_once_and_then_plans(monkeypatc
 
 def test_cached_two_segment_lists_are_a_miss_for_a_single_segment_caller():
     assert R._is_two(("two", object(), 123)) and not R._is_two(None) and not R._is_two((1, 2, 3))
+
+
+def test_depth_segments_only_where_every_tile_is_split_forward_and_backward(monkeypatch):
+    """rasterizer.cuda.depth_segments: runs on tile grids of up to 1 100 tiles -- the grids on which
+    forward AND backward split every tile above the small-grid floor, so that which tiles are cut is a function of the
+    tile's list alone and every route to the kernels rounds the same way -- and nowhere else, whatever the knobs say."""
+    import rasterizer.cuda as C
+
+    def knobs(**env):
+        for k in ("GSR_DEPTH_SEGMENTS", "GSR_DEPTH_SEGMENTS_GRID", "GSR_DEPTH_SEGMENTS_MIN", "GSR_DEPTH_SEGMENTS_FWD",
+                  "GSR_SMALL_GRID", "GSR_SMALL_GRID_BWD", "GSR_SMALL_GRID_MIN", "GSR_DEEP_FACTOR", "GSR_DEEP_MIN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        C._segment_cache.clear()
+        C._deep_cache.clear()
+
+    try:
+        knobs()
+        assert C.depth_segments(1_000_000, 30 * 17) == (16, 512)            # 480 x 270
+        assert C.depth_segments(1_000_000, 1100) == (16, 512)
+        assert C.depth_segments(1_000_000, 60 * 34) == (1, 0)               # 960 x 540: the backward is not split-all
+        assert C.depth_segments(1_000_000, 120 * 68) == (1, 0)              # 1080p
+        for tiles in (510, 1100):  # on every grid with segments both thresholds are the constant floor
+            assert C.deep_tile_threshold(10, tiles) == C.deep_tile_threshold(10**9, tiles, backward=True) == 96
+        knobs(GSR_DEPTH_SEGMENTS=1)
+        assert C.depth_segments(1_000_000, 510) == (1, 0)
+        knobs(GSR_DEPTH_SEGMENTS_GRID=5000)                                  # asked for more than the split-all grids:
+        assert C.depth_segments(1_000_000, 2040) == (1, 0)                   # ... capped by GSR_SMALL_GRID_BWD
+        knobs(GSR_DEPTH_SEGMENTS_GRID=5000, GSR_SMALL_GRID_BWD=2560)
+        assert C.depth_segments(1_000_000, 2040) == (16, 512) and C.depth_segments(1_000_000, 2561) == (1, 0)
+        knobs(GSR_DEPTH_SEGMENTS=5, GSR_DEPTH_SEGMENTS_MIN=64)
+        assert C.depth_segments(1, 256) == (5, 64)
+    finally:
+        knobs()
