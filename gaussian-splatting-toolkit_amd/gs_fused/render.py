@@ -69,6 +69,15 @@ def _segments(spec, capacity, dev):
     return _C._forward_segments(capacity, tb[0] * tb[1], spec.height, spec.width, dev)
 
 
+def _segments_backward(spec, capacity, dev):
+    """The backward's runs (not capped by GSR_DEPTH_SEGMENTS_FWD) and its workspace of (runs - 1) maps per pixel."""
+    tb = spec.tile_bounds
+    segs, seg_min = _C.depth_segments(capacity, tb[0] * tb[1])
+    if segs < 2:
+        return 0, 0, None
+    return segs, seg_min, torch.empty(((segs - 1) * spec.height * spec.width * 8,), dtype=torch.uint8, device=dev)
+
+
 def _seg_fields(seg):
     segs, seg_min, ws = seg
     if ws is None:
@@ -214,7 +223,7 @@ class _Render(Function):
                 v_dc = v_rest = None
             use_stats = stats is not None and stats.enabled
             p = lambda t: None if t is None else t.data_ptr()
-            seg = _segments(spec, ctx.capacity, dev)
+            seg = _segments_backward(spec, ctx.capacity, dev)
             desc = _ViewDesc(n, ctx.degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy,
                              spec.cx, spec.cy, spec.glob_scale, spec.clip_thresh, ctx.capacity,
                              _C.deep_tile_threshold(ctx.capacity, tb[0] * tb[1], backward=True),

@@ -389,8 +389,9 @@ def _depth_segments_record(device):
         return None
     import rasterizer.cuda as _C
 
-    segs, grid, least, _ = _C._segment_knobs()
-    return {"runs": segs, "tile_grids_up_to": grid, "lists_longer_than": least,
+    segs, grid, least, fwd = _C._segment_knobs()
+    return {"runs": segs, "runs_forward": min(segs, fwd) if fwd > 0 else segs, "tile_grids_up_to": grid,
+            "lists_longer_than": least,
             "what": "on such grids the list of every split tile is cut into runs composited by their own waves "
                     "(gsr_rasterize_forward_seg / _backward_seg): results equal the single walk's to rounding"}
 

@@ -576,10 +576,11 @@ def _forward_segments(list_entries: int, num_tiles: int, H: int, W: int, dev):
     """-> (segments, minimum entries, workspace or None) of ``gsr_rasterize_forward_seg`` for this tile grid."""
     segs, seg_min = depth_segments(list_entries, num_tiles)
     if segs > 1:
-        # GSR_DEPTH_SEGMENTS_FWD: fewer (or no) runs for the forward alone.  Its pre-pass walks every run from T = 1 to
-        # the run's own saturation: on an OPAQUE scene that is most of the list, where the single walk stops early
-        # (300 k opaque Gaussians at 480 x 270: forward 338 us single, 295 with 4 runs, 432 with 16); a training view
-        # of a young, transparent model gains up to the 16 (profiles/r04_depth_segments.txt)
+        # GSR_DEPTH_SEGMENTS_FWD (8; 0 = as the backward): fewer runs for the forward.  Its pre-pass walks every run
+        # from T = 1 to the run's own saturation: on an OPAQUE scene that is most of the list, where the single walk
+        # stops early (300 k opaque Gaussians at 480 x 270: forward 338 us single, 295 with 4 runs, 340 with 8, 432
+        # with 16); a training view of a young, transparent model gains up to the 16, but only ~1 % of config 3's rate
+        # over 8 (profiles/r04_depth_segments.txt): 8 never loses
         segs = min(segs, _segment_knobs()[3]) if _segment_knobs()[3] > 0 else segs
     if segs < 2:
         return 0, 0, None
@@ -597,7 +598,7 @@ def _segment_knobs():
         _segment_cache["v"] = (int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_GRID", "1100")),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")),
-                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "0")))
+                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "8")))
     return _segment_cache["v"]
 
 

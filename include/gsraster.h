@@ -600,7 +600,8 @@ typedef struct gsr_view_desc {
   void *zero_ptr;
   size_t zero_bytes;
   /* depth segments of the compositing, forward and backward (gsr_rasterize_forward_seg / _backward_seg):
-   * segments < 2 = off; seg_ws: gsr_rasterize_forward_seg_workspace_bytes(...) bytes (enough for the backward too) */
+   * segments < 2 = off; seg_ws: gsr_rasterize_forward_seg_workspace_bytes(...) bytes for gsr_view_forward,
+   * gsr_rasterize_backward_seg_workspace_bytes(...) for gsr_view_backward (each call with its own `segments`) */
   int segments, segment_min_entries;
   void *seg_ws;
   size_t seg_ws_bytes;

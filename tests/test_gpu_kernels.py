@@ -802,6 +802,8 @@ def test_depth_segments_of_the_forward_equal_the_single_walk(opaque, rgbd, monke
     lens = (bins[:, 1] - bins[:, 0]).cpu().numpy()
     bg = cu(np.array(S.BACKGROUND, np.float32))
 
+    monkeypatch.setattr(C, "_segment_knobs", lambda: (16, 1100, 512, 0))  # (no separate cap on the forward's runs)
+
     def run(segs, least, threshold=96, ex=True):
         monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
         monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (segs, least))
