@@ -275,6 +275,100 @@ GSR_EXPORT int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width, flo
   return GSR_OK;
 }
 
+// ---- L1-only photometric head: what DepthGSModel's `main_loss` really is --------
+// depth_gs.py:445-448 reads
+//     loss_dict["main_loss"] = (1 - self.config.ssim_lambda) * Ll1
+//     +self.config.ssim_lambda * simloss
+// -- the second line is a stand-alone expression statement, so the SSIM term is computed
+// and thrown away: the co-gs photometric loss is  weight * mean |gt - pred|  with
+// weight = 1 - ssim_lambda.  One streaming kernel each way, no maps, no blur.
+namespace {
+
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const long long n4, const long long n, const int clamp_pred,
+                                                     const float *__restrict__ pred, const float *__restrict__ gt,
+                                                     double *__restrict__ sums) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float4 *p4 = reinterpret_cast<const float4 *>(pred);
+  const float4 *g4 = reinterpret_cast<const float4 *>(gt);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 x = p4[i];
+    const float4 y = g4[i];
+    if (clamp_pred) {
+      x.x = fminf(x.x, 1.f);
+      x.y = fminf(x.y, 1.f);
+      x.z = fminf(x.z, 1.f);
+      x.w = fminf(x.w, 1.f);
+    }
+    acc += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+  }
+  if (blockIdx.x == 0) {  // the (at most three) elements behind the last float4
+    const long long i = 4 * n4 + threadIdx.x;
+    if (i < n) {
+      const float x = clamp_pred ? fminf(pred[i], 1.f) : pred[i];
+      acc += fabsf(x - gt[i]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(&sums[blockIdx.x % GSR_LOSS_SUM_SLOTS], (double)red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void l1_finalize_kernel(const long long n, const float weight,
+                                                         const double *__restrict__ sums,
+                                                         float *__restrict__ loss_out) {
+  double a = 0.0;
+  for (int k = threadIdx.x; k < GSR_LOSS_SUM_SLOTS; k += 64) a += sums[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (threadIdx.x == 0) *loss_out = (float)((double)weight * (a / (double)n));
+}
+
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const long long n, const float weight, const int clamp_pred,
+                                                     const float *__restrict__ upstream,
+                                                     const float *__restrict__ pred, const float *__restrict__ gt,
+                                                     float *__restrict__ v_pred) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float xr = pred[i];
+  const float x = clamp_pred ? fminf(xr, 1.f) : xr;
+  const float d = x - gt[i];
+  const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  const float k = upstream[0] * weight / (float)n;
+  v_pred[i] = (clamp_pred && xr > 1.f) ? 0.f : k * sgn;
+}
+
+}  // namespace
+
+GSR_EXPORT int gsr_l1_forward(long long num_values, float weight, int clamp_pred, const float *pred,
+                              const float *gt, double *sums, float *loss_out, gsr_stream_t stream) {
+  GSR_REQUIRE(num_values > 0, "l1_forward: empty image");
+  GSR_REQUIRE(pred && gt && sums && loss_out, "l1_forward: null pointer");
+  GSR_REQUIRE(((uintptr_t)pred & 15) == 0 && ((uintptr_t)gt & 15) == 0, "l1_forward: images must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (int zrc = gsr_zero_async(sums, GSR_LOSS_SUM_SLOTS * sizeof(double), s)) return zrc;
+  const long long n4 = num_values / 4;
+  const unsigned blocks = (unsigned)std::max<long long>(1, std::min<long long>((n4 + 1023) / 1024, 4096));
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(blocks), dim3(256), 0, s, n4, num_values, clamp_pred, pred, gt, sums);
+  hipLaunchKernelGGL(l1_finalize_kernel, dim3(1), dim3(64), 0, s, num_values, weight, (const double *)sums,
+                     loss_out);
+  GSR_CHECK_LAUNCH("l1_forward");
+  return GSR_OK;
+}
+
+GSR_EXPORT int gsr_l1_backward(long long num_values, float weight, int clamp_pred, const float *upstream,
+                               const float *pred, const float *gt, float *v_pred, gsr_stream_t stream) {
+  GSR_REQUIRE(num_values > 0, "l1_backward: empty image");
+  GSR_REQUIRE(upstream && pred && gt && v_pred, "l1_backward: null pointer");
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3((unsigned)((num_values + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     num_values, weight, clamp_pred, upstream, pred, gt, v_pred);
+  GSR_CHECK_LAUNCH("l1_backward");
+  return GSR_OK;
+}
+
 // ---- depth head of the co-gs model (DepthGSModel, gs_toolkit/models/depth_gs.py) --
 //   pred  = where(alpha > 0, depth / alpha, depth.detach().max())      (:356-363)
 //   loss  = | gt * (gt > 0) - pred * (gt > 0) |.mean()                   (:531-538)

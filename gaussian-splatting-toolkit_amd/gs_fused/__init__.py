@@ -2,7 +2,7 @@
 photometric loss head (f2), the one-launch Adam step (f1) and SH colours from
 split coefficients and the per-Gaussian activations (f4).  Same native library and C ABI (`include/gsraster.h`)
 as `rasterizer`; no CPU fallback."""
-from .loss import L1SSIMLoss, depth_l1_loss, l1_ssim_loss  # noqa: F401
+from .loss import L1SSIMLoss, depth_l1_loss, l1_loss, l1_ssim_loss  # noqa: F401
 from .adam import FusedAdam  # noqa: F401
 from .sh import sh_backward_views, spherical_harmonics_split  # noqa: F401
 from .activations import activate_gaussians, densify_stats_  # noqa: F401

@@ -86,6 +86,44 @@ class L1SSIMLoss(torch.nn.Module):
         return l1_ssim_loss(pred, gt, self.ssim_lambda, clamp_pred=self.clamp_pred)
 
 
+class _L1(Function):
+    @staticmethod
+    def forward(ctx, pred: Tensor, gt: Tensor, weight: float, clamp_pred: bool):
+        if pred.shape != gt.shape or pred.numel() == 0:
+            raise ValueError(f"expected two images of one (non-empty) shape, got {tuple(pred.shape)} and {tuple(gt.shape)}")
+        pred = _check(pred.contiguous(), "pred", _f32)
+        gt = _check(gt.contiguous(), "gt", _f32)
+        dev = pred.device
+        with torch.cuda.device(dev):
+            work = torch.empty((64,), dtype=torch.float64, device=dev)
+            loss = torch.empty((), dtype=_f32, device=dev)
+            _call("gsr_l1_forward", C.c_longlong(pred.numel()), C.c_float(weight), C.c_int(1 if clamp_pred else 0),
+                  _ptr(pred), _ptr(gt), _ptr(work), _ptr(loss), _stream(dev))
+        ctx.save_for_backward(pred, gt)
+        ctx.weight, ctx.clamp_pred = float(weight), bool(clamp_pred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, v_loss):
+        pred, gt = ctx.saved_tensors
+        dev = pred.device
+        up = v_loss.to(_f32).reshape(1).contiguous()
+        with torch.cuda.device(dev):
+            v_pred = torch.empty_like(pred)
+            _call("gsr_l1_backward", C.c_longlong(pred.numel()), C.c_float(ctx.weight),
+                  C.c_int(1 if ctx.clamp_pred else 0), _ptr(up), _ptr(pred), _ptr(gt), _ptr(v_pred), _stream(dev))
+        return v_pred, None, None, None
+
+
+def l1_loss(pred: Tensor, gt: Tensor, weight: float = 1.0, clamp_pred: bool = False) -> Tensor:
+    """``weight * |gt - pred|.mean()`` in one streaming kernel each way -- the photometric loss of the co-gs
+    model AS ITS SOURCE COMPUTES IT: `DepthGSModel.get_loss_dict` (depth_gs.py:445-448) writes
+    ``loss_dict["main_loss"] = (1 - ssim_lambda) * Ll1`` and puts ``+ssim_lambda * simloss`` on a line of its own,
+    an expression statement whose value is dropped, so ``weight = 1 - ssim_lambda`` and no SSIM term.
+    `clamp_pred`: the loss of ``torch.clamp(pred, max=1.0)`` (depth_gs.py:343) without that op."""
+    return _L1.apply(pred, gt, weight, clamp_pred)
+
+
 class _DepthL1(Function):
     @staticmethod
     def forward(ctx, depth: Tensor, alpha: Tensor, gt: Tensor):

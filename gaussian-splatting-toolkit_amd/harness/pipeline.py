@@ -64,6 +64,8 @@ def render_view(
     sh_exchange=None,  # (parallel.GradientExchange, names, leaves) with names / leaves = ("features_dc",
                        # "features_rest") / those parameters, or ("sh_coeffs",) / ([N,K,3],): data parallel, the SH
                        # gradient is formed from the ranks' gathered colour cotangents (GradientExchange, `sh_views`)
+    normalise_depth: bool = True,  # False: "depth" stays None and the caller takes the accumulated depth ("depth_acc")
+                                   # and the alpha to gs_fused.depth_l1_loss, which normalises inside its kernels
     caller_syncs=False,  # True: block the host where the UNCHANGED models do -- `if (self.radii).sum() == 0`
                          # (vanilla_gs.py:784) and `assert (num_tiles_hit > 0).any()` (:811); "camera": also the
                          # intrinsics read back from the device ahead of the projection (:736-740, :772-773).
@@ -84,7 +86,7 @@ def render_view(
     if caller_syncs and (radii).sum() == 0:  # vanilla_gs.py:784-794: nothing on screen, the background
         rgb = background.repeat(H, W, 1)
         return {"rgb": rgb, "alpha": background.new_zeros(H, W, 1), "depth": background.new_ones(H, W, 1) * 10,
-                "xys": xys, "radii": radii, "depths": depths, "conics": conics, "num_tiles_hit": num_tiles_hit,
+                "depth_acc": None, "xys": xys, "radii": radii, "depths": depths, "conics": conics, "num_tiles_hit": num_tiles_hit,
                 "rgbs": None}
     if retain_xys_grad and xys.requires_grad:
         xys.retain_grad()  # densification reads xys.grad (vanilla_gs.py:352-353,797-798)
@@ -122,7 +124,7 @@ def render_view(
     else:
         raise ValueError("Unknown rasterize_mode: %s" % rasterize_mode)
 
-    depth_im = None
+    depth_im = depth_acc = None
     if render_depth and fused_depth:
         from gs_fused import rasterize_gaussians_rgbd
 
@@ -142,6 +144,7 @@ def render_view(
                 xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opac, H, W,
                 BLOCK_WIDTH, background=torch.zeros(3, device=means3d.device),
             )[..., 0:1]
-        depth_im = torch.where(alpha > 0, depth_im / alpha, depth_im.detach().max())
-    return {"rgb": rgb, "alpha": alpha, "depth": depth_im, "xys": xys, "radii": radii,
+        depth_acc = depth_im
+        depth_im = torch.where(alpha > 0, depth_im / alpha, depth_im.detach().max()) if normalise_depth else None
+    return {"rgb": rgb, "alpha": alpha, "depth": depth_im, "depth_acc": depth_acc, "xys": xys, "radii": radii,
             "depths": depths, "conics": conics, "num_tiles_hit": num_tiles_hit, "rgbs": rgbs}

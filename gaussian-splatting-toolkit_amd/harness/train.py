@@ -98,6 +98,14 @@ def downscale_image(image: torch.Tensor, d: int) -> torch.Tensor:
                          antialias=False)[0].permute(1, 2, 0)
 
 
+def downscale_depth(depth: torch.Tensor, d: int) -> torch.Tensor:
+    """`DepthGSModel._downscale_if_required` for a 2-D image (depth_gs.py:161-176): resized as [1,H,W]."""
+    if d <= 1:
+        return depth
+    return F.interpolate(depth[None, None], size=[depth.shape[0] // d, depth.shape[1] // d], mode="bilinear",
+                         align_corners=False, antialias=False)[0, 0]
+
+
 def composite_with_background(image: torch.Tensor, background: torch.Tensor) -> torch.Tensor:
     """What the models do with a ground-truth image that carries an alpha channel (vanilla_gs.py:870-881): straight
     colour over the step's background, `a * rgb + (1 - a) * background`; an RGB image is returned as it is."""
@@ -256,7 +264,8 @@ class GaussianParams(torch.nn.Module):
                 self.gauss[k] = torch.nn.Parameter(new[k])
 
     def render(self, cam: CameraTensors, background, sh_degree_to_use: int, render_depth=False,
-               retain_xys_grad=False, clamp_rgb=True, sh_exchange=None, caller_syncs=False):
+               retain_xys_grad=False, clamp_rgb=True, sh_exchange=None, caller_syncs=False, fused_depth=False,
+               normalise_depth=True):
         g = self.gauss
         if self.split_sh and g["features_dc"].is_cuda and g["features_rest"].shape[1] in (3, 8, 15):
             coeffs = (g["features_dc"], g["features_rest"])  # gs_fused.spherical_harmonics_split
@@ -273,7 +282,8 @@ class GaussianParams(torch.nn.Module):
             opac, dirs = torch.sigmoid(g["opacities"]), None
         return render_view(g["means"], scales, quats, opac, coeffs, cam, background, sh_degree_to_use,
                            render_depth=render_depth, retain_xys_grad=retain_xys_grad, viewdirs=dirs,
-                           clamp_rgb=clamp_rgb, caller_syncs=caller_syncs,
+                           clamp_rgb=clamp_rgb, caller_syncs=caller_syncs, fused_depth=fused_depth,
+                           normalise_depth=normalise_depth,
                            sh_exchange=None if sh_exchange is None else (
                                sh_exchange, ("features_dc", "features_rest"), (g["features_dc"], g["features_rest"])))
 
@@ -300,6 +310,28 @@ def ssim(img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
     c1, c2 = 0.01 ** 2, 0.03 ** 2
     m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s11 + s22 + c2))
     return m.mean()
+
+
+def cogs_main_loss(pred: torch.Tensor, target: torch.Tensor, ssim_lambda: float) -> torch.Tensor:
+    """`DepthGSModel.get_loss_dict`'s photometric terms op by op (depth_gs.py:441-462), quirk included: the SSIM is
+    computed and then DROPPED -- `+self.config.ssim_lambda * simloss` stands on a line of its own (:447-448) -- so
+    `main_loss` = (1 - ssim_lambda) * L1; `scale_reg` is tensor(0.) with the default config and the trainer adds
+    the dict's values up (engine/trainer.py:497)."""
+    Ll1 = torch.abs(target - pred).mean()
+    simloss = 1 - ssim(target, pred)
+    main_loss = (1 - ssim_lambda) * Ll1
+    +ssim_lambda * simloss  # noqa: B018  (an expression statement, as in the source)
+    scale_reg = torch.tensor(0.0).to(pred.device)
+    return main_loss + scale_reg
+
+
+def cogs_depth_l1(pred_depth: torch.Tensor, gt_depth: torch.Tensor) -> torch.Tensor:
+    """`depth_l1` of depth_gs.py:531-538: |gt * (gt > 0) - pred * (gt > 0)|.mean() over ALL pixels, pred [H,W,1]
+    squeezed; added to the loss with weight 1 (`depth_lambda` is declared twice in the config, :85 and :115, and
+    read nowhere)."""
+    depth_nonzero = gt_depth > 0
+    pred = pred_depth.squeeze(-1)
+    return torch.abs(gt_depth * depth_nonzero - pred * depth_nonzero).mean()
 
 
 def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -381,6 +413,27 @@ class TrainConfig:
     # the product) are cached per view and resolution and the step runs one `addcmul` with its background.
     # False: the reference's per-step sequence.
     fused_target: bool = True
+    # "gaussian-splatting": GaussianSplattingModel (vanilla_gs.py).  "co-gs": DepthGSModel (depth_gs.py) -- BASELINE
+    # config 5: the depth image is rasterised on the TRAINING path (`output_depth_during_training = True`, :99,
+    # :345-363), the photometric loss is (1 - ssim_lambda) * L1 ONLY (:445-448: the `+ ssim_lambda * simloss` line is
+    # an expression statement -- the SSIM is computed and dropped; followed as written), and from
+    # `step > depth_loss_start_iteration` (:119-120, :472-476) the L1 between the rendered depth and the ground
+    # truth's on the pixels with gt > 0 is ADDED UNWEIGHTED (:532-538; the trainer sums the dict,
+    # engine/trainer.py:497 -- `depth_lambda` is never read).  Refinement, optimisers and schedules are the base
+    # model's.  Set num_downscales = 0 and background_color = "random" for the reference's co-gs defaults (:51, :49).
+    model: str = "gaussian-splatting"
+    depth_loss_start_iteration: int = 6000
+    use_depth_loss: bool = True
+    # co-gs: RGB and depth from ONE compositing pass each way (gs_fused.rasterize_gaussians_rgbd) and the depth
+    # normalisation + masked L1 in gs_fused.depth_l1_loss; False: the models' two `rasterize_gaussians` calls and
+    # their torch ops (depth_gs.py:330-363, 531-538)
+    fused_depth: bool = True
+
+
+def quantise_depth_mm(depth: torch.Tensor) -> torch.Tensor:
+    """A ground-truth depth image as the toolkit's dataset delivers it: a 16-bit PNG in millimetres read as
+    `astype("float32") / 1000.0` (data/datasets/base_dataset.py:123-125); 0 = no measurement."""
+    return torch.round(depth.clamp(0.0, 65.535) * 1000.0) / 1000.0
 
 
 def _depth_segments_record(device):
@@ -434,6 +487,11 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     # (the reference seeds every rank differently, scripts/train.py:54: the backgrounds differ per rank, as there)
     bg_gen = torch.Generator(device=device).manual_seed(cfg.seed + 977 * (rank + 1)) if random_bg else None
 
+    if cfg.model not in ("gaussian-splatting", "co-gs"):
+        raise ValueError(f"unknown model {cfg.model!r}")
+    cogs = cfg.model == "co-gs"
+    if cogs and (cfg.fused_render or cfg.use_graph):
+        raise ValueError("co-gs runs through the separate ops (fused_depth = one RGB + depth compositing pass)")
     mk = lambda: blob_scene(cfg.num_gaussians, seed=cfg.seed, sh_degree=cfg.sh_degree, kind=cfg.scene,
                             scale_lo=cfg.scene_scale[0], scale_hi=cfg.scene_scale[1], tex_cell=cfg.tex_cell,
                             objects=cfg.scene_objects, extent=cfg.scene_extent)
@@ -453,6 +511,16 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         else:
             gt_rgba = None
             gt = [truth.render(c, bg, cfg.sh_degree)["rgb"] for c in cams]
+        gt_depth = None
+        if cogs:
+            # the sensor's depth image: z-depth of the hidden scene where it covers the pixel, 0 (= no measurement,
+            # masked out by `gt_depth > 0`) elsewhere, in millimetre steps like the dataset's 16-bit PNGs
+            gt_depth = []
+            for c in cams:
+                o = truth.render(c, torch.zeros(3, device=device), cfg.sh_degree, render_depth=True,
+                                 fused_depth=device.type == "cuda")
+                gt_depth.append(quantise_depth_mm(torch.where(o["alpha"] > 0.5, o["depth"], torch.zeros_like(o["depth"]))
+                                                  [..., 0]).contiguous())
 
     raw = mk()
     rng = np.random.default_rng(cfg.seed + 1)
@@ -507,6 +575,20 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         loss_fn = lambda pred, target: ((1 - cfg.ssim_lambda) * (pred - target).abs().mean()
                                         + cfg.ssim_lambda * (1 - ssim(pred, target)))
 
+    depth_loss_fn = None
+    if cogs:
+        w_l1 = 1.0 - cfg.ssim_lambda
+        if cfg.fused_loss and device.type == "cuda":
+            from gs_fused import depth_l1_loss, l1_loss
+
+            loss_fn = lambda pred, target: l1_loss(pred, target, w_l1, clamp_pred=fused_clamp)
+        else:
+            loss_fn = lambda pred, target: cogs_main_loss(pred, target, cfg.ssim_lambda)
+        if cfg.fused_depth and cfg.fused_loss and device.type == "cuda":
+            depth_loss_fn = lambda out, gtd: depth_l1_loss(out["depth_acc"], out["alpha"], gtd)
+        else:
+            depth_loss_fn = lambda out, gtd: cogs_depth_l1(out["depth"], gtd)
+
     fused_stats = cfg.fused_activations and device.type == "cuda" and os.environ.get("GSR_AB_STATS", "1") != "0"
     if fused_stats:
         from gs_fused import densify_stats_
@@ -524,10 +606,21 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     history = []  # (step, N) after every refinement that changed the model
     max_dim = max(cfg.width, cfg.height)
 
+    depth_err = []  # co-gs: mean |rendered depth - gt depth| over the measured pixels, at every evaluate()
+
     def evaluate():
         with torch.no_grad():
             idx = np.linspace(0, cfg.num_views - 1, cfg.eval_views).astype(int)
-            return float(np.mean([psnr(model.render(cams[i], bg, cfg.sh_degree)["rgb"], gt[i]) for i in idx]))
+            if not cogs:
+                return float(np.mean([psnr(model.render(cams[i], bg, cfg.sh_degree)["rgb"], gt[i]) for i in idx]))
+            ps, de = [], []
+            for i in idx:
+                o = model.render(cams[i], bg, cfg.sh_degree, render_depth=True, fused_depth=device.type == "cuda")
+                ps.append(psnr(o["rgb"], gt[i]))
+                m = gt_depth[i] > 0
+                de.append(float((o["depth"][..., 0] - gt_depth[i]).abs()[m].mean()) if bool(m.any()) else 0.0)
+            depth_err.append(float(np.mean(de)))
+            return float(np.mean(ps))
 
     start_step = 0
     if cfg.resume_from:
@@ -561,6 +654,8 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
 
     gc.collect()
     gc.freeze()
+    if device.type == "cuda":
+        torch.cuda.reset_peak_memory_stats(device)
     t0 = time.perf_counter()
     use_fused = (cfg.fused_render or cfg.use_graph) and device.type == "cuda" and cfg.split_sh and cfg.fused_loss \
         and cfg.sh_degree in (0, 1, 2, 3)
@@ -599,187 +694,196 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     rebuilds0 = _list_rebuilds()
     target_cache = {}  # (view, downscale factor) -> (resized alpha * rgb [h,w,3], resized 1 - alpha [h,w,1])
     bg_static = bg.clone() if (random_bg and cfg.use_graph) else None  # a replayed graph reads its background here
-    for step in range(start_step, cfg.iters):
-        ph = None
-        v = view_for_rank(step, rank, world, cfg.num_views)
-        deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
-        exchange.active_rows["features_rest"] = (deg + 1) ** 2 - 1
-        # this step's resolution (vanilla_gs.py:646-657, 719-720), background (:688-690) and ground truth
-        # (:859-868 downscaled every step, :870-881 composited over the step's background)
-        d = downscale_factor(step, cfg.num_downscales, cfg.resolution_schedule)
-        cam = cams_by_d[d][v]
-        max_dim = max(cam.width, cam.height)  # `max(self.last_size)` of after_train / refinement_after
-        if random_bg:
-            bg_step = torch.rand(3, device=device, generator=bg_gen)
-            if cfg.fused_target:
-                planes = target_cache.get((v, d))
-                if planes is None:
-                    small = downscale_image(gt_rgba[v], d)
-                    a_ = small[..., 3:4]
-                    planes = target_cache[(v, d)] = ((a_ * small[..., :3]).contiguous(), (1 - a_).contiguous())
-                target = torch.addcmul(planes[0], planes[1], bg_step)
-            else:
-                target = composite_with_background(downscale_image(gt_rgba[v], d), bg_step)
-            if bg_static is not None:
-                bg_static.copy_(bg_step)
-                bg_step = bg_static
-        else:
-            bg_step, target = bg, downscale_image(gt[v], d)
-        if use_fused:
-            spec = ViewSpec(cam.height, cam.width, cam.fx, cam.fy, cam.cx, cam.cy, deg)
-            fstats.enabled = not (cfg.densify and step >= rcfg.stop_split_at)
-            fstats.max_dim = max_dim
-            g_ = model.gauss
-            if cfg.use_graph:
-                # `generation` counts the refinements that swapped parameter tensors: N can come out
-                # unchanged (k culled, k duplicated) while every tensor the graph points at is gone
-                key = (spec, model.num_points, caps.capacity, fstats.enabled, generation)
-                if vkey != key:  # new SH degree, N changed by refinement, or larger lists: capture again
-                    vgraph = ViewGraph({k: g_[k] for k in PARAM_NAMES}, spec, caps.capacity, graph_loss, bg_step,
-                                       [(cam.height, cam.width, 3)], stats=fstats)
-                    vgraph.capture(cam.viewmat, cam.projmat, cam.campos, (target,))
-                    vkey = key
+    try:  # (an exception in the loop must not leave the collector frozen for the rest of the process)
+        for step in range(start_step, cfg.iters):
+            ph = None
+            v = view_for_rank(step, rank, world, cfg.num_views)
+            deg = min(step // cfg.sh_degree_interval, cfg.sh_degree)
+            exchange.active_rows["features_rest"] = (deg + 1) ** 2 - 1
+            # this step's resolution (vanilla_gs.py:646-657, 719-720), background (:688-690) and ground truth
+            # (:859-868 downscaled every step, :870-881 composited over the step's background)
+            d = downscale_factor(step, cfg.num_downscales, cfg.resolution_schedule)
+            cam = cams_by_d[d][v]
+            max_dim = max(cam.width, cam.height)  # `max(self.last_size)` of after_train / refinement_after
+            if random_bg:
+                bg_step = torch.rand(3, device=device, generator=bg_gen)
+                if cfg.fused_target:
+                    planes = target_cache.get((v, d))
+                    if planes is None:
+                        small = downscale_image(gt_rgba[v], d)
+                        a_ = small[..., 3:4]
+                        planes = target_cache[(v, d)] = ((a_ * small[..., :3]).contiguous(), (1 - a_).contiguous())
+                    target = torch.addcmul(planes[0], planes[1], bg_step)
                 else:
-                    # the count of the previous replay is in pinned memory by now
-                    if not vgraph.fits():
+                    target = composite_with_background(downscale_image(gt_rgba[v], d), bg_step)
+                if bg_static is not None:
+                    bg_static.copy_(bg_step)
+                    bg_step = bg_static
+            else:
+                bg_step, target = bg, downscale_image(gt[v], d)
+            if use_fused:
+                spec = ViewSpec(cam.height, cam.width, cam.fx, cam.fy, cam.cx, cam.cy, deg)
+                fstats.enabled = not (cfg.densify and step >= rcfg.stop_split_at)
+                fstats.max_dim = max_dim
+                g_ = model.gauss
+                if cfg.use_graph:
+                    # `generation` counts the refinements that swapped parameter tensors: N can come out
+                    # unchanged (k culled, k duplicated) while every tensor the graph points at is gone
+                    key = (spec, model.num_points, caps.capacity, fstats.enabled, generation)
+                    if vkey != key:  # new SH degree, N changed by refinement, or larger lists: capture again
+                        vgraph = ViewGraph({k: g_[k] for k in PARAM_NAMES}, spec, caps.capacity, graph_loss, bg_step,
+                                           [(cam.height, cam.width, 3)], stats=fstats)
+                        vgraph.capture(cam.viewmat, cam.projmat, cam.campos, (target,))
+                        vkey = key
+                    else:
+                        # the count of the previous replay is in pinned memory by now
+                        if not vgraph.fits():
+                            overflow_views += 1
+                            caps.capacity = ((int(1.5 * int(vgraph.count_host[0])) + (1 << 20)) >> 20) << 20
+                    loss, out = vgraph.replay(cam.viewmat, cam.projmat, cam.campos, (target,))
+                    if dp:
+                        exchange.start_all()
+                else:
+                    zero_grads()
+                    slot = caps.slot(device)
+                    used = caps.capacity
+                    collector = exchange.begin_sh_views(("features_dc", "features_rest"),
+                                                        (g_["features_dc"], g_["features_rest"]), g_["means"], cam.campos,
+                                                        cfg.sh_degree, deg) if sh_views else None
+                    out = render_gaussians(g_["means"], g_["scales"], g_["quats"], g_["opacities"], g_["features_dc"],
+                                           g_["features_rest"], cam.viewmat, cam.projmat, cam.campos, bg_step, spec, used,
+                                           count_out=slot, stats=fstats, sh_collector=collector)
+                    loss = loss_fn(out["rgb"], target)
+                    loss.backward()
+                    caps.submitted(slot, used, device)
+                    if caps.overflowed():
                         overflow_views += 1
-                        caps.capacity = ((int(1.5 * int(vgraph.count_host[0])) + (1 << 20)) >> 20) << 20
-                loss, out = vgraph.replay(cam.viewmat, cam.projmat, cam.campos, (target,))
-                if dp:
-                    exchange.start_all()
             else:
                 zero_grads()
-                slot = caps.slot(device)
-                used = caps.capacity
-                collector = exchange.begin_sh_views(("features_dc", "features_rest"),
-                                                    (g_["features_dc"], g_["features_rest"]), g_["means"], cam.campos,
-                                                    cfg.sh_degree, deg) if sh_views else None
-                out = render_gaussians(g_["means"], g_["scales"], g_["quats"], g_["opacities"], g_["features_dc"],
-                                       g_["features_rest"], cam.viewmat, cam.projmat, cam.campos, bg_step, spec, used,
-                                       count_out=slot, stats=fstats, sh_collector=collector)
-                loss = loss_fn(out["rgb"], target)
+                ph = _phase_marks(5) if (cfg.phase_every and step % cfg.phase_every == 0 and device.type == "cuda") else None
+                if ph:
+                    ph[0].record()
+                depth_on = cogs and cfg.use_depth_loss and step > cfg.depth_loss_start_iteration
+                out = model.render(cam, bg_step, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp,
+                                   sh_exchange=exchange if sh_views else None, caller_syncs=cfg.caller_syncs,
+                                   render_depth=cogs, fused_depth=cogs and cfg.fused_depth and device.type == "cuda",
+                                   normalise_depth=not (cogs and cfg.fused_depth and cfg.fused_loss
+                                                        and device.type == "cuda"))
+                rgb = out["rgb"]
+                if ph:
+                    ph[1].record()
+                loss = loss_fn(rgb, target)
+                if depth_on:
+                    # `gt_depth = self.get_gt_img(batch["depth"])` (downscaled like the image under a resolution schedule)
+                    loss = loss + depth_loss_fn(out, downscale_depth(gt_depth[v], d))
+                if ph:
+                    ph[2].record()
                 loss.backward()
-                caps.submitted(slot, used, device)
-                if caps.overflowed():
-                    overflow_views += 1
-        else:
-            zero_grads()
-            ph = _phase_marks(5) if (cfg.phase_every and step % cfg.phase_every == 0 and device.type == "cuda") else None
-            if ph:
-                ph[0].record()
-            out = model.render(cam, bg_step, deg, retain_xys_grad=True, clamp_rgb=not fused_clamp,
-                               sh_exchange=exchange if sh_views else None, caller_syncs=cfg.caller_syncs)
-            rgb = out["rgb"]
-            if ph:
-                ph[1].record()
-            loss = loss_fn(rgb, target)
-            if ph:
-                ph[2].record()
-            loss.backward()
-            if ph:
-                ph[3].record()
-        # densification statistics (vanilla_gs.py:344-372; not updated past stop_split_at, :347)
-        if use_fused or (cfg.densify and step >= rcfg.stop_split_at):
-            pass
-        elif fused_stats:
-            densify_stats_(out["xys"].grad, out["radii"], max_dim, xys_grad_norm, vis_counts, max_2dsize,
-                           first=stats_first)
-        else:
-            with torch.no_grad():
-                visible = out["radii"] > 0
-                g = out["xys"].grad
-                gnorm = torch.zeros_like(xys_grad_norm) if g is None else g.norm(dim=-1)
-                size = out["radii"].float() / max_dim
-                if stats_first:
-                    xys_grad_norm, vis_counts = gnorm.clone(), torch.ones_like(vis_counts)
-                    max_2dsize = torch.where(visible, size, torch.zeros_like(size))
-                else:
-                    xys_grad_norm += torch.where(visible, gnorm, torch.zeros_like(xys_grad_norm))
-                    vis_counts += visible.to(torch.int32)
-                    max_2dsize = torch.where(visible, torch.maximum(max_2dsize, size), max_2dsize)
-        if first_pending and world > 1 and rank > 0 and cfg.densify and step < rcfg.stop_split_at:
-            # which Gaussians this rank's FIRST view after a refinement really saw (parallel.single_process_vis_counts)
-            first_vis = (out["radii"] > 0).to(torch.int32)
-        first_pending = False
-        stats_first = False
-        if dp and sharded is None:
-            b = exchange.finish()
-            if not exchanged_bytes or exchanged_bytes[-1][1] != b:
-                exchanged_bytes.append((step, b))
-        if cfg.means_lr_schedule:
-            # the scheduler steps after the optimizer (trainer.py:479-525): iteration `step` runs at lr(step)
-            if sharded is not None:
-                sharded.set_lr("means", means_lr(step, LRS["means"]))
+                if ph:
+                    ph[3].record()
+            # densification statistics (vanilla_gs.py:344-372; not updated past stop_split_at, :347)
+            if use_fused or (cfg.densify and step >= rcfg.stop_split_at):
+                pass
+            elif fused_stats:
+                densify_stats_(out["xys"].grad, out["radii"], max_dim, xys_grad_norm, vis_counts, max_2dsize,
+                               first=stats_first)
             else:
-                grp = optims["all"].param_groups[0] if "all" in optims else optims["means"].param_groups[0]
-                grp["lr"] = means_lr(step, LRS["means"])
-        for o in optims.values():
-            o.step()
-        if sharded is not None:
-            b = sharded.step()
-            if not exchanged_bytes or exchanged_bytes[-1][1] != b:
-                exchanged_bytes.append((step, b))
-        if ph:
-            ph[4].record()
-            phase_marks.append((d, ph))
-        # refinement_after: every refine_every iterations, after the optimizer step
-        # (TrainingCallback(update_every_num_iters=refine_every), vanilla_gs.py:610-616)
-        if cfg.densify and step % rcfg.refine_every == 0 and step > rcfg.warmup_length:
-            branch, reset = _refinement_branch(rcfg, step, cfg.num_views)
-            if branch != "none" or reset:
-                if use_fused:
-                    xys_grad_norm, vis_counts, max_2dsize = fstats.as_tuple()
-                if dp and branch == "densify":
-                    allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize, first_visible=first_vis,
-                                            force=cfg.force_exchange)
-                old = {k: model.gauss[k] for k in PARAM_NAMES}
-                moments = {}
-                for o in optims.values():
-                    moments.update(_adam_moments(o, old))
+                with torch.no_grad():
+                    visible = out["radii"] > 0
+                    g = out["xys"].grad
+                    gnorm = torch.zeros_like(xys_grad_norm) if g is None else g.norm(dim=-1)
+                    size = out["radii"].float() / max_dim
+                    if stats_first:
+                        xys_grad_norm, vis_counts = gnorm.clone(), torch.ones_like(vis_counts)
+                        max_2dsize = torch.where(visible, size, torch.zeros_like(size))
+                    else:
+                        xys_grad_norm += torch.where(visible, gnorm, torch.zeros_like(xys_grad_norm))
+                        vis_counts += visible.to(torch.int32)
+                        max_2dsize = torch.where(visible, torch.maximum(max_2dsize, size), max_2dsize)
+            if first_pending and world > 1 and rank > 0 and cfg.densify and step < rcfg.stop_split_at:
+                # which Gaussians this rank's FIRST view after a refinement really saw (parallel.single_process_vis_counts)
+                first_vis = (out["radii"] > 0).to(torch.int32)
+            first_pending = False
+            stats_first = False
+            if dp and sharded is None:
+                b = exchange.finish()
+                if not exchanged_bytes or exchanged_bytes[-1][1] != b:
+                    exchanged_bytes.append((step, b))
+            if cfg.means_lr_schedule:
+                # the scheduler steps after the optimizer (trainer.py:479-525): iteration `step` runs at lr(step)
                 if sharded is not None:
-                    moments = sharded.full_moments()  # refinement moves whole rows of both moments
-                new, new_moments, info = _refine(old, moments, (xys_grad_norm, vis_counts, max_2dsize), rcfg, step,
-                                                 cfg.num_views, max_dim, seed=cfg.refine_seed + step)
-                if any(new[k] is not old[k] for k in PARAM_NAMES):
-                    generation += 1
-                    model.replace(new)
-                    cur = {k: model.gauss[k] for k in PARAM_NAMES}
+                    sharded.set_lr("means", means_lr(step, LRS["means"]))
+                else:
+                    grp = optims["all"].param_groups[0] if "all" in optims else optims["means"].param_groups[0]
+                    grp["lr"] = means_lr(step, LRS["means"])
+            for o in optims.values():
+                o.step()
+            if sharded is not None:
+                b = sharded.step()
+                if not exchanged_bytes or exchanged_bytes[-1][1] != b:
+                    exchanged_bytes.append((step, b))
+            if ph:
+                ph[4].record()
+                phase_marks.append((d, ph, bool(cogs and cfg.use_depth_loss and step > cfg.depth_loss_start_iteration)))
+            # refinement_after: every refine_every iterations, after the optimizer step
+            # (TrainingCallback(update_every_num_iters=refine_every), vanilla_gs.py:610-616)
+            if cfg.densify and step % rcfg.refine_every == 0 and step > rcfg.warmup_length:
+                branch, reset = _refinement_branch(rcfg, step, cfg.num_views)
+                if branch != "none" or reset:
+                    if use_fused:
+                        xys_grad_norm, vis_counts, max_2dsize = fstats.as_tuple()
+                    if dp and branch == "densify":
+                        allreduce_densify_stats(xys_grad_norm, vis_counts, max_2dsize, first_visible=first_vis,
+                                                force=cfg.force_exchange)
+                    old = {k: model.gauss[k] for k in PARAM_NAMES}
+                    moments = {}
                     for o in optims.values():
-                        _swap_parameters(o, old, cur, new_moments)
-                    if info["n_out"] != info["n_in"]:
-                        n = info["n_out"]
-                        xys_grad_norm = torch.empty(n, device=device)
-                        vis_counts = torch.empty(n, device=device, dtype=torch.int32)
-                        max_2dsize = torch.empty(n, device=device)
-                        if use_fused:
-                            fstats = DensifyStats(n, device, max_dim)
-                    history.append((step, model.num_points))
-                    exchange.rebind({k: model.gauss[k] for k in PARAM_NAMES})
-                if sharded is not None:
-                    # new tensors, or the same ones with an opacity reset (which zeroed moments in the
-                    # gathered copies): cut this rank's rows again
-                    sharded.bind({k: model.gauss[k] for k in PARAM_NAMES}, new_moments)
-            # the statistics restart after every refinement_after past the warm-up (:491-493)
-            stats_first = True
-            first_pending, first_vis = True, None
-            if use_fused:
-                fstats.restart()
-        if cfg.save_every and cfg.checkpoint_dir and step > 0 and step % cfg.save_every == 0 and \
-                (rank == 0 or sharded is not None):
-            from .checkpoint import save_checkpoint
+                        moments.update(_adam_moments(o, old))
+                    if sharded is not None:
+                        moments = sharded.full_moments()  # refinement moves whole rows of both moments
+                    new, new_moments, info = _refine(old, moments, (xys_grad_norm, vis_counts, max_2dsize), rcfg, step,
+                                                     cfg.num_views, max_dim, seed=cfg.refine_seed + step)
+                    if any(new[k] is not old[k] for k in PARAM_NAMES):
+                        generation += 1
+                        model.replace(new)
+                        cur = {k: model.gauss[k] for k in PARAM_NAMES}
+                        for o in optims.values():
+                            _swap_parameters(o, old, cur, new_moments)
+                        if info["n_out"] != info["n_in"]:
+                            n = info["n_out"]
+                            xys_grad_norm = torch.empty(n, device=device)
+                            vis_counts = torch.empty(n, device=device, dtype=torch.int32)
+                            max_2dsize = torch.empty(n, device=device)
+                            if use_fused:
+                                fstats = DensifyStats(n, device, max_dim)
+                        history.append((step, model.num_points))
+                        exchange.rebind({k: model.gauss[k] for k in PARAM_NAMES})
+                    if sharded is not None:
+                        # new tensors, or the same ones with an opacity reset (which zeroed moments in the
+                        # gathered copies): cut this rank's rows again
+                        sharded.bind({k: model.gauss[k] for k in PARAM_NAMES}, new_moments)
+                # the statistics restart after every refinement_after past the warm-up (:491-493)
+                stats_first = True
+                first_pending, first_vis = True, None
+                if use_fused:
+                    fstats.restart()
+            if cfg.save_every and cfg.checkpoint_dir and step > 0 and step % cfg.save_every == 0 and \
+                    (rank == 0 or sharded is not None):
+                from .checkpoint import save_checkpoint
 
-            # (sharded moments are gathered by a collective: every rank calls, rank 0 writes)
-            save_checkpoint(cfg.checkpoint_dir, step, model, optims, sharded=sharded, write=rank == 0)
-        if cfg.log_every and step % cfg.log_every == 0:
-            losses.append(float(loss.detach()))
-    if dp:
-        dist.barrier()
-    if device.type == "cuda":
-        torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    gc.unfreeze()
+                # (sharded moments are gathered by a collective: every rank calls, rank 0 writes)
+                save_checkpoint(cfg.checkpoint_dir, step, model, optims, sharded=sharded, write=rank == 0)
+            if cfg.log_every and step % cfg.log_every == 0:
+                losses.append(float(loss.detach()))
+        if dp:
+            dist.barrier()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.unfreeze()
     psnr1 = evaluate()
-    phases = phases_by_res = None
+    phases = phases_by_res = phases_by_depth = None
     if phase_marks:
         names = ("render", "loss", "backward", "stats_exchange_optimizer")
 
@@ -789,10 +893,13 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             out["samples"] = len(marks)
             return out
 
-        phases = med([m for _, m in phase_marks])
+        phases = med([m for _, m, _ in phase_marks])
         if len(factors) > 1:  # the coarse-to-fine schedule: one set of medians per resolution
-            phases_by_res = {f"{cfg.width // d_}x{cfg.height // d_}": med([m for dd, m in phase_marks if dd == d_])
-                             for d_ in sorted({dd for dd, _ in phase_marks}, reverse=True)}
+            phases_by_res = {f"{cfg.width // d_}x{cfg.height // d_}": med([m for dd, m, _ in phase_marks if dd == d_])
+                             for d_ in sorted({dd for dd, _, _ in phase_marks}, reverse=True)}
+        if cogs:  # before / after the depth loss joins (the depth pass then has a backward as well)
+            phases_by_depth = {("depth_loss_on" if on else "depth_loss_off"): med([m for _, m, o in phase_marks if o == on])
+                               for on in sorted({o for _, _, o in phase_marks})}
     if cfg.export_ply and rank == 0:
         from gs_io.ply import write_gaussian_ply
 
@@ -807,13 +914,17 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             "allreduce_bytes": exchanged_bytes,
             "render": ("hip graph per view" if cfg.use_graph else "one fused op") if use_fused else "separate ops",
             "list_overflow_views": overflow_views + (_list_rebuilds() - rebuilds0), "phase_ms_median": phases,
-            "phase_ms_median_by_resolution": phases_by_res,
+            "phase_ms_median_by_resolution": phases_by_res, "phase_ms_median_by_depth_loss": phases_by_depth,
             "depth_segments": _depth_segments_record(device),
             "schedule": {"num_downscales": cfg.num_downscales, "resolution_schedule": cfg.resolution_schedule,
                          "background_color": cfg.background_color, "caller_syncs": cfg.caller_syncs},
             "update": "reduce-scatter + sharded Adam + all-gather" if sharded is not None else
             ("all-reduce (geometry) + all-gathered colour cotangents (SH) + Adam" if sh_views else "all-reduce + Adam"),
-            "init": cfg.init,
+            "init": cfg.init, "model": cfg.model,
+            "depth": ({"loss_from_step": cfg.depth_loss_start_iteration + 1 if cfg.use_depth_loss else None,
+                       "one_compositing_pass": bool(cfg.fused_depth and device.type == "cuda"),
+                       "mean_abs_error_start_end": [depth_err[0], depth_err[-1]]} if cogs else None),
+            "peak_memory_bytes": (int(torch.cuda.max_memory_allocated(device)) if device.type == "cuda" else None),
             "densify_grad_thresh": (rcfg.densify_grad_thresh if cfg.densify else None)}
 
 

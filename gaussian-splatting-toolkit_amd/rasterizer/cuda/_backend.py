@@ -52,6 +52,8 @@ SYMBOLS = (
     "gsr_cov2d_bounds",
     "gsr_l1_ssim_forward",
     "gsr_l1_ssim_backward",
+    "gsr_l1_forward",
+    "gsr_l1_backward",
     "gsr_depth_l1_forward",
     "gsr_depth_l1_backward",
     "gsr_sh_forward_split",
@@ -80,6 +82,8 @@ SYMBOLS = (
     "gsr_rasterize_backward_det_workspace_bytes",
     "gsr_rasterize_backward_det",
     "gsr_debug_count_staged",
+    "gsr_calibrate_valu",
+    "gsr_calibrate_copy",
 )
 
 
@@ -102,6 +106,7 @@ def _load():
         raise ImportError(f"rasterizer: {LIB_PATH} lacks symbols {missing}")
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_version.restype = C.c_int
+    lib.gsr_calibrate_valu.restype = C.c_longlong
     lib.gsr_cumsum_workspace_bytes.restype = C.c_size_t
     lib.gsr_sort_workspace_bytes.restype = C.c_size_t
     lib.gsr_reach_record_bytes.restype = C.c_size_t

@@ -421,6 +421,21 @@ int gsr_l1_ssim_backward(unsigned img_height, unsigned img_width,
                          const float *gt, const float *maps, float *v_pred,
                          gsr_stream_t stream);
 
+/* f2, the photometric head of the co-gs model as its source computes it
+ * (gs_toolkit/models/depth_gs.py:445-448: the `+ ssim_lambda * simloss` line is a
+ * stand-alone expression statement, so `main_loss` = (1 - ssim_lambda) * L1 only):
+ *   *loss_out = weight * mean |min(pred, 1) - gt|   (clamp_pred != 0; pred as is otherwise)
+ * pred, gt: num_values fp32 each (an [H,W,3] image: 3 H W), 16-byte aligned.  sums:
+ * workspace of GSR_LOSS_SUM_SLOTS doubles, zeroed by the call.  backward:
+ * v_pred = upstream[0] * weight * sign(pred - gt) / num_values, 0 where pred > 1
+ * under clamp_pred (upstream on the device). */
+int gsr_l1_forward(long long num_values, float weight, int clamp_pred,
+                   const float *pred, const float *gt, double *sums,
+                   float *loss_out, gsr_stream_t stream);
+int gsr_l1_backward(long long num_values, float weight, int clamp_pred,
+                    const float *upstream, const float *pred, const float *gt,
+                    float *v_pred, gsr_stream_t stream);
+
 /* f2, depth head of the co-gs model (gs_toolkit/models/depth_gs.py:356-363, 531-538):
  *   pred = alpha > 0 ? depth / alpha : *depth_max      (depth_max: device float, the
  *                                                       detached maximum of `depth`)
@@ -840,6 +855,20 @@ int gsr_rasterize_backward_det(
  * this is what a launch really reads of the lists (bench.py prices the roofline on
  * it).  Device-wide setting (synchronises the device); not for production loops. */
 int gsr_debug_count_staged(unsigned long long *counters);
+
+/* ---- box calibration (bench.py `calibration`; not part of the path) ----------
+ * Two fixed workloads, timed by the caller with events on `stream` next to the
+ * bench's own steps, so that a move of the headline between two GPU leases can be
+ * attributed to the box (clock state, memory) or to the code.
+ * gsr_calibrate_valu: `workgroups` x 256 lanes each run `iters` rounds of 8
+ *   independent non-packed fp32 fma chains; returns the number of VALU
+ *   lane-operations launched (8 * iters * 256 * workgroups; -1 on error);
+ *   scratch: at least `workgroups` floats (never written).
+ * gsr_calibrate_copy: float4 grid-stride copy of `bytes` (multiple of 16). */
+long long gsr_calibrate_valu(int iters, int workgroups, float *scratch,
+                             gsr_stream_t stream);
+int gsr_calibrate_copy(const void *src, void *dst, size_t bytes,
+                       gsr_stream_t stream);
 
 #ifdef __cplusplus
 }

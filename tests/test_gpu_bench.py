@@ -35,6 +35,13 @@ def test_single_gpu_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # what lets a reader tell box from code: a calibration of the box next to the timed region,
+    # the normalised value, the fixed-duration warm-up, the per-step spread -- inside `config`, which the driver keeps
+    cal, tim = d["config"]["calibration"], d["config"]["timing"]
+    assert 5 < cal["valu_Tops"] < 45 and 500 < cal["copy_GBps"] < 8000, cal
+    assert abs(d["value_normalised"] - d["value"] * cal["reference_valu_Tops"] / cal["valu_Tops"]) < 0.01 * d["value"]
+    assert tim["fixed_warmup_s"] >= 0.3 and tim["fixed_warmup_steps"] > 0 and tim["ms_per_step_median"] > 0
+    assert d["end_to_end_built_GBps"] < 8000
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -93,5 +100,19 @@ def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks():
         assert t["schedule"]["num_downscales"] == 2 and t["schedule"]["background_color"] == "random"
         assert len(t["phase_ms_median_by_resolution"]) == 3, t["phase_ms_median_by_resolution"]
         assert t["iters_per_s_with_caller_syncs"] > 0 and t["list_overflow_views"] == 0
+        # BASELINE config 5's loop (co-gs) rides in the same record ...
+        c = t["cogs_3m_4k"]
+        assert "error" not in c and c["iters"] == 120 and c["iters_per_s"] > 0, c
+        assert c["depth"]["loss_from_step"] == 41 and c["depth"]["one_compositing_pass"] is True
+        assert set(c["phase_ms_median_by_depth_loss"]) == {"depth_loss_off", "depth_loss_on"}
+        assert c["peak_memory_GB"] > 0 and c["list_overflow_views"] == 0
         if extra:
             assert t["replicas_identical"] is True and t["allreduce_bytes_step_bytes"], t
+        else:
+            # ... and at N = 1 the raster bench on the model the config-3 leg has just trained
+            r = t["trained_raster"]
+            assert "error" not in r and r["ms"] > 0 and r["gaussians"] == t["gaussians"]["end"], r
+            assert r["raster_fwd_ms"] > 0 and r["raster_bwd_ms"] > 0 and r["tile_list_length"]["max"] > 0
+            dg = json.loads(lines[0])["config"]["train_digest"]
+            assert dg["config3_iters_per_s"] == t["iters_per_s"] and dg["cogs_3m_4k"]["iters_per_s"] == c["iters_per_s"]
+            assert dg["trained_raster"]["ms"] == r["ms"]
