@@ -841,25 +841,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.cuda.synchronize()
-    t_w = time.perf_counter()
     for _ in range(max(args.warmup, 1)):  # (at least one: the workload's statistics below come from a rendered view)
         out = step()
-    torch.cuda.synchronize()
     # A fixed DURATION of the workload ahead of the timed steps, whatever --warmup says: the driver runs
     # `--steps 20 --warmup 5` (25 ms of GPU time in all), and a box whose clocks have not settled reads several
-    # per cent low.  The number of extra steps is derived from the warm-up's own rate and agreed
-    # across ranks (every step carries collectives under data parallelism).
-    est_ms = 1e3 * (time.perf_counter() - t_w) / max(args.warmup, 1)
+    # per cent low.  The number of extra steps is derived from the rate of ten more steps (the
+    # first ones carry one-off costs) and agreed across ranks (every step carries collectives under data parallelism).
+    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    for _ in range(10):
+        out = step()
+    torch.cuda.synchronize()
+    est_ms = 1e3 * (time.perf_counter() - t_w) / 10
     if dp:
         tt_ = torch.tensor([est_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
         est_ms = float(tt_.item())
-    fixed_warmup_steps = int(min(2000, max(0, np.ceil(1e3 * FIXED_WARMUP_SECONDS / max(est_ms, 1e-3)))))
     t_w = time.perf_counter()
-    for _ in range(fixed_warmup_steps):
-        out = step()
-    torch.cuda.synchronize()
+    if dp:  # a count every rank agrees on (with margin: the estimate runs slower than the settled rate)
+        fixed_warmup_steps = int(min(4000, max(0, np.ceil(1.5e3 * FIXED_WARMUP_SECONDS / max(est_ms, 1e-3)))))
+        for _ in range(fixed_warmup_steps):
+            out = step()
+        torch.cuda.synchronize()
+    else:  # by the clock
+        fixed_warmup_steps = 0
+        while time.perf_counter() - t_w < FIXED_WARMUP_SECONDS and fixed_warmup_steps < 20000:
+            for _ in range(20):
+                out = step()
+            torch.cuda.synchronize()
+            fixed_warmup_steps += 20
     fixed_warmup_s = time.perf_counter() - t_w
     num_intersects = int(out["num_tiles_hit"].sum().item())  # the reference's lists (3-sigma boxes)
     from rasterizer import rasterize as _R

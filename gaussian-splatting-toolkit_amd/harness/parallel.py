@@ -209,6 +209,7 @@ class GradientExchange:
         self.use_hooks = True
         self._sh = None           # this step's deferred SH gradient (deferred_sh_colors), or None
         self._sh_work = None
+        self._held = []           # collectives that came up before this step's SH gather was issued (`_hold`)
         self.sh_views_backward = None  # (degree, deg_use, means, campos [W,3], v_colors [W,N,3], scale) -> grads; default: native
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self._ws = dist.get_world_size(group) if self.enabled else 1
@@ -274,9 +275,34 @@ class GradientExchange:
                     "deg_use": int(degrees_to_use)}
         return self
 
+    # The collectives of a step pair across ranks by ISSUE ORDER.  With a deferred SH gradient announced
+    # (`begin_sh_views`) the all-gather of the colour cotangents is the FIRST collective of the step on every rank, by
+    # construction rather than by the luck of autograd's ordering: an all-reduce that comes up while the gather has not
+    # been issued yet is HELD (`_hold`) and issued right behind it -- from `offer()` (the normal case: the colour
+    # cotangent leaves the compositing backward before any parameter gradient exists, nothing is ever held) or, on a
+    # rank whose colours received no cotangent at all, from the top of `finish()`, where that rank joins the gather
+    # with zeros.  (the zeros used to be offered at the very END of finish(), behind the late all-reduces --
+    # an all-gather paired with an all-reduce on the other rank.)
+    def _gather_outstanding(self) -> bool:
+        return self._sh is not None and self._sh_work is None
+
+    def _hold(self, thunk) -> bool:
+        if self._gather_outstanding():
+            self._held.append(thunk)
+            return True
+        return False
+
+    def _release_held(self) -> None:
+        held, self._held = self._held, []
+        for thunk in held:
+            thunk()
+
     def offer(self, v_colors: torch.Tensor) -> None:
-        """(from the backward of `deferred_sh_colors`) start the all-gather of [v_colors | campos]."""
+        """(from the backward of `deferred_sh_colors`) start the all-gather of [v_colors | campos], then whatever
+        all-reduces were held back for it."""
         sh = self._sh
+        if self._sh_work is not None:
+            raise RuntimeError("GradientExchange.offer: this step's colour cotangents were already gathered")
         msg = torch.cat((v_colors.reshape(-1), sh["campos"].to(v_colors.device)))
         out = torch.empty((self._ws, msg.numel()), dtype=msg.dtype, device=msg.device)
         if self._caps.get("gather_into_tensor", False):
@@ -286,21 +312,14 @@ class GradientExchange:
         sh["out"] = out
         self._sh_work = work
         self._bytes += out.numel() * out.element_size()
+        self._release_held()
 
     def _finish_sh(self) -> None:
         sh = self._sh
         self._sh = None
         if sh is None:
             return
-        if self._sh_work is None:
-            # the colours never received a cotangent on this rank (their output was unused in its loss): the other
-            # ranks are already inside the all-gather -- join it with zeros, so that the collectives stay matched
-            # (raising here would leave them hanging), and contribute no gradient
-            n = sh["means"].shape[0]
-            self._sh = sh
-            self.offer(torch.zeros((n, 3), dtype=sh["means"].dtype, device=sh["means"].device))
-            self._sh = None
-        self._sh_work.wait()
+        self._sh_work.wait()  # (issued by offer(), or with zeros at the top of finish())
         self._sh_work = None
         out, n = sh["out"], sh["means"].shape[0]
         v_all, campos_all = out[:, :3 * n], out[:, 3 * n:]
@@ -315,6 +334,9 @@ class GradientExchange:
             self.named[k].grad = g.view_as(self.named[k])
 
     def _start_flat(self) -> None:
+        if self._hold(self._start_flat):
+            self._flat_started = True  # (decided; issued right behind the gather)
+            return
         names = self._small_names()
         parts = []
         for k in names:
@@ -336,6 +358,8 @@ class GradientExchange:
             self._flat_arrived[name] = True
             if not self._flat_started and all(self._flat_arrived.get(k) for k in self._small_names()):
                 self._start_flat()
+            return
+        if self._hold(lambda: self._start(name, p)):
             return
         g = p.grad
         rows = self.active_rows.get(name)
@@ -375,6 +399,12 @@ class GradientExchange:
         tensors' collectives."""
         if not self.enabled:
             return 0
+        if self._gather_outstanding():
+            # the colours never received a cotangent on this rank (their output was unused in its loss): join the
+            # gather with zeros -- still this step's first collective here, the held all-reduces follow it -- and
+            # contribute no gradient
+            n_ = self._sh["means"].shape[0]
+            self.offer(torch.zeros((n_, 3), dtype=self._sh["means"].dtype, device=self._sh["means"].device))
         seen = {id(g) for _, _, g, rows, _ in self.pending if rows != "flat"}
         for name, p in self.named.items():
             if self._is_small(name) or name in self._deferred():

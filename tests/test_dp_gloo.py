@@ -384,6 +384,67 @@ def test_a_rank_without_colour_cotangent_joins_the_gather_with_zeros():
     assert results[0][1] == results[1][1] == [2.0, 0.0]
 
 
+def _ordering_worker(rank, world, port, q, colours_first):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-splatting-toolkit_amd"))
+    from harness.parallel import GradientExchange
+
+    n = 10
+    named = {"means": torch.randn(n, 3).requires_grad_(True), "big": torch.zeros(n, 15, 3, requires_grad=True),
+             "sh_coeffs": torch.zeros(n, 4, 3, requires_grad=True)}
+    ex = GradientExchange(named, average=False).attach()
+    issued = []
+    real_gather, real_reduce = dist.all_gather_into_tensor, dist.all_reduce
+    dist.all_gather_into_tensor = lambda *a, **k: (issued.append("gather"), real_gather(*a, **k))[1]
+    dist.all_reduce = lambda t, *a, **k: (issued.append("reduce%d" % t.numel()), real_reduce(t, *a, **k))[1]
+    got = {}
+    ex.sh_views_backward = lambda degree, deg_use, means, campos_all, v_all, scale, split: (
+        got.setdefault("v", v_all.clone()), torch.zeros(n, 4, 3))[1]
+    mk = lambda: ex.deferred_sh_colors(lambda: torch.ones(n, 3), ("sh_coeffs",), (named["sh_coeffs"],), named["means"],
+                                       torch.zeros(3), 1, 1)
+    # autograd runs the node created LAST first: `colours_first` decides whether rank 0's colour cotangent is offered
+    # before or after the other parameters' hooks fire
+    if colours_first:
+        rest = named["big"].sum() * (rank + 1) + (named["means"] * 2).sum()
+        colors = mk()
+    else:
+        colors = mk()
+        rest = named["big"].sum() * (rank + 1) + (named["means"] * 2).sum()
+    loss = rest + (colors.sum() * 5 if rank == 0 else 0.0)  # rank 1's loss does not touch the colours
+    loss.backward()
+    ex.finish()
+    dist.all_gather_into_tensor, dist.all_reduce = real_gather, real_reduce
+    q.put((rank, issued, got["v"].reshape(world, n, 3)[:, 0, 0].tolist(), float(named["big"].grad[0, 0, 0]),
+           float(named["means"].grad[0, 0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("colours_first", [True, False])
+def test_the_colour_gather_is_the_first_collective_of_the_step_on_every_rank(colours_first):
+    """Round-4 advice: a rank whose colours got no cotangent issued its (zero) all-gather at the END of finish(), behind
+    all-reduces its hooks had started during the backward, while the other rank had issued the gather first:
+    collectives pair by issue order, so an all-gather met an all-reduce.  Now every all-reduce that comes up before the
+    step's gather is held and issued behind it -- whichever way autograd orders the nodes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ordering_worker, args=(r, 2, port, q, colours_first)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, order0, v0, big0, m0), (_, order1, v1, big1, m1) = results
+    assert order0 == order1 and order0[0] == "gather" and len(order0) == 3, (order0, order1)
+    assert v0 == v1 == [5.0, 0.0]          # rank 0's cotangent, zeros from rank 1
+    assert big0 == big1 == 3.0 and m0 == m1 == 4.0  # (1 + 2) and (2 + 2): summed over the ranks
+
+
 def _caps_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

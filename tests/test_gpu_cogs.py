@@ -114,7 +114,9 @@ def test_one_cogs_training_step_against_the_oracle_chain(fused):
         mine = npy(p[k].grad).reshape(g_ref.shape)
         floor = 1e-3 * max(1e-9, float(np.abs(g_ref).max()))
         e = np.abs(mine - g_ref) / np.maximum(np.abs(g_ref), floor)
-        assert e.max() < 1e-3, f"{k}: max rel err {e.max():.3e}"
+        # (unfused: the cotangents that enter the rasterizer's backward come out of the CALLER's fp32 torch chain --
+        # where / div / abs / mean and their autograd -- while the checker forms them in float64: 2e-3 there)
+        assert e.max() < (1e-3 if fused else 2e-3), f"{k}: max rel err {e.max():.3e}"
     # the depth loss really reaches the geometry: without it the gradient of the means is a different one
     no_dep = _oracle_view(raw, cam_np, bg, deg_use, H, W, v_img, zeros, None)
     assert np.abs(ref["grads"]["means"] - no_dep["grads"]["means"]).max() > 1e-2 * np.abs(ref["grads"]["means"]).max()

@@ -52,6 +52,34 @@ def classify(ins):
     return c
 
 
+def issue_cycles(ins):
+    """Issue cost of one wave64 VALU instruction on a gfx950 SIMD, in cycles, as MEASURED by tools/exp/valubench2.hip
+    (8 resident waves per SIMD, independent instructions; profiles/r05_valubench2.txt):
+      8.2  transcendentals (v_exp / v_rcp / v_rsq / ...) and v_permlane{16,32}_swap
+      4.2  v_min / v_max, every v_cmp, v_cndmask, anything with a DPP modifier, v_cvt, v_readfirstlane / v_readlane,
+           the VOP3-only integer ops (v_lshl_add, v_bfe, v_med3, v_mad ...), v_pk_* (two lane-ops per lane), and ANY
+           plain instruction with an SGPR source operand (v_mul_f32 v, s, v: 4.14 against 2.45 with two VGPRs)
+      2.7  v_fma_f32 (VOP3)
+      2.4  v_add / v_sub / v_mul (e32 and e64) / v_fmac / v_fmamk / v_fmaak / v_mov / v_and / v_or / v_xor / shifts /
+           v_add_u32
+    0 for everything that is not a VALU instruction."""
+    op = ins.split()[0]
+    if not op.startswith("v_"):
+        return 0.0
+    if op.startswith(TRANS) or op.startswith("v_permlane"):
+        return 8.2
+    ops = ins[len(op):]
+    sgpr_src = bool(re.search(r",\s*-?\|?s(\d+|\[)", ops)) or (", vcc" in ops and not op.startswith("v_cndmask"))
+    if ("dpp" in ins or "quad_perm" in ins or "row_" in ins or op.startswith(
+            ("v_min_", "v_max_", "v_cmp", "v_cndmask", "v_cvt_", "v_readfirstlane", "v_readlane", "v_lshl_add", "v_bfe",
+             "v_med3", "v_mad_", "v_pk_", "v_bfi", "v_add3", "v_lshl_or", "v_and_or", "v_or3", "v_mbcnt", "v_mul_lo",
+             "v_mul_hi", "v_ldexp", "v_frexp", "v_trunc", "v_floor", "v_rndne", "v_fract"))) or sgpr_src:
+        return 4.2
+    if op.startswith("v_fma_f32"):
+        return 2.7
+    return 2.4
+
+
 def kernel_text(asm, needle):
     lines = asm.splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and needle in l and ": " in l and "@" in l)
@@ -119,25 +147,29 @@ def main():
         blocks = tally(body)
         out.write("=" * 110 + "\n%s: innermost LDS-reading loop %s, %d basic blocks, kernel VGPRs %s\n" % (
             title, label, len(blocks), vg.group(1) if vg else "?"))
-        out.write("%-14s %5s %5s %5s %5s %5s %5s %5s %5s %5s %5s\n" % (
-            "block", "VALU", "trans", "dpp", "cndm", "SALU", "brnch", "wait", "LDS", "VMEM", "atom"))
+        out.write("%-14s %5s %5s %5s %5s %5s %5s %5s %5s %5s %5s %7s\n" % (
+            "block", "VALU", "trans", "dpp", "cndm", "SALU", "brnch", "wait", "LDS", "VMEM", "atom", "cycles"))
         tot = None
         for name, ins in blocks:
             c = {}
             for i in ins:
                 for k, v in classify(i).items():
                     c[k] = c.get(k, 0) + v
+            c["cycles"] = sum(issue_cycles(i) for i in ins)
             tot = c if tot is None else {k: tot[k] + c.get(k, 0) for k in tot}
-            out.write("%-14s %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d\n" % (
+            out.write("%-14s %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %7.1f\n" % (
                 name, c.get("valu", 0), c.get("trans", 0), c.get("dpp", 0), c.get("cndmask", 0), c.get("salu", 0),
-                c.get("branch", 0), c.get("waitcnt", 0), c.get("lds", 0), c.get("vmem", 0), c.get("atomic", 0)))
-        out.write("%-14s %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d   (every block once)\n\n" % (
+                c.get("branch", 0), c.get("waitcnt", 0), c.get("lds", 0), c.get("vmem", 0), c.get("atomic", 0),
+                c["cycles"]))
+        out.write("%-14s %5d %5d %5d %5d %5d %5d %5d %5d %5d %5d %7.1f   (every block once; cycles = measured VALU "
+                  "issue cost per wave-instruction, tools/exp/valubench2.hip)\n\n" % (
             "sum", tot["valu"], tot["trans"], tot["dpp"], tot["cndmask"], tot["salu"], tot["branch"], tot["waitcnt"],
-            tot["lds"], tot["vmem"], tot["atomic"]))
+            tot["lds"], tot["vmem"], tot["atomic"], tot["cycles"]))
         for name, ins in blocks:
             out.write("-- %s\n" % name)
             for i in ins:
-                out.write("    " + i + "\n")
+                cyc = issue_cycles(i)
+                out.write("    %-72s%s\n" % (i, ("  ; %.1f" % cyc) if cyc else ""))
         out.write("\n")
 
 
