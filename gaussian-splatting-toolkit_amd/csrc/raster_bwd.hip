@@ -40,6 +40,7 @@
 namespace {
 // measurement hook, see raster_fwd.hip
 __device__ unsigned long long *g_bwd_staged = nullptr;
+__device__ gsr::WaveTrace g_bwd_trace = {nullptr, 0u};
 }  // namespace
 
 namespace {
@@ -280,9 +281,12 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     seg_k = (int)(blk / (4u * base_grid));
     blk -= (unsigned)seg_k * (4u * base_grid);
   }
+  const WaveTrace trace = g_bwd_trace;
+  const unsigned long long trace_t0 = trace_begin(trace);
   const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile, allowed = job.allowed;  // allowed: the sub-tiles this wave owns (raster_common.h)
   if (tile < 0) return;
+  const int trace_len = range.y - range.x;
   int seg_behind = 0;  // segments behind this one whose maps are applied first
   if constexpr (SEG) {
     const int len = range.y - range.x;
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     __syncthreads();
   }
   }
+  trace_end(trace, trace_t0, tile, allowed, trace_len);
 }
 
 // The pre-pass of the depth segments: (R, S) of segment seg_k = 1 + block / (4 base_grid) for every pixel of a deep
@@ -1112,6 +1117,16 @@ GSR_EXPORT int gsr_rasterize_backward_det(
 }
 
 int gsr_set_fwd_staged_counter(unsigned long long *counter);  // raster_fwd.hip
+
+int gsr_set_fwd_wave_trace(unsigned long long *buf, unsigned capacity);  // raster_fwd.hip
+
+GSR_EXPORT int gsr_debug_wave_trace(unsigned long long *records, unsigned capacity_waves) {
+  int rc = gsr_set_fwd_wave_trace(records, capacity_waves);
+  if (rc != GSR_OK) return rc;
+  gsr::WaveTrace t = {records ? records + 4ull * capacity_waves : nullptr, capacity_waves};
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), &t, sizeof(t)));
+  return GSR_OK;
+}
 
 GSR_EXPORT int gsr_debug_count_staged(unsigned long long *counters) {
   int rc = gsr_set_fwd_staged_counter(counters);

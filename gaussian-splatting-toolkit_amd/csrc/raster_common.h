@@ -91,14 +91,24 @@ __device__ __forceinline__ int splat_reach_mask(float x, float y, float a, float
 // its sub-tile, so results are bit-identical to the one-wave-per-tile walk.
 // Block b of the extra range [base_grid, 4 base_grid) sits on XCD b % 8 like the regular
 // block of the same tile (the four waves share the splat records in one L2).
+// ORDER (round 5): the hardware starts workgroups in block order, and a deep tile is the longest job of the launch.
+// With the extra blocks BEHIND the regular ones (rounds 2-4) three quarters of every deep tile's work were the last
+// waves to start -- the opposite of longest-job-first.  The extra range now comes first: blocks [0, 3 base_grid) are
+// the extra sub-tile waves (the ones of shallow tiles exit at once), blocks [3 base_grid, 4 base_grid) the regular
+// ones.  The XCD of a block is unchanged (base_grid is a multiple of 8).  GSR_DEEP_EXTRAS_FIRST=0 builds the old order.
+#ifndef GSR_DEEP_EXTRAS_FIRST
+#define GSR_DEEP_EXTRAS_FIRST 1
+#endif
 struct TileJob {
   int tile;     // < 0: nothing to do
   int allowed;  // sub-tile mask this wave owns (15 = the whole tile)
 };
-__device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned base_grid, const int tiles_x,
+__device__ __forceinline__ TileJob tile_job(const unsigned b_launch, const unsigned base_grid, const int tiles_x,
                                             const int tiles_y, const int2 *__restrict__ tile_bins,
                                             const int deep_threshold, int2 &range) {
   TileJob j{-1, 15};
+  unsigned b = b_launch;
+  if (GSR_DEEP_EXTRAS_FIRST && deep_threshold > 0) b = b_launch < 3u * base_grid ? b_launch + base_grid : b_launch - 3u * base_grid;
   if (b < base_grid) {
     j.tile = gsr_xcd_remap(b, tiles_x, tiles_y);
     if (j.tile < 0) return j;
@@ -119,6 +129,29 @@ __device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned bas
 // Depth segments (raster_fwd.hip / raster_bwd.hip): a split tile's list of `len` entries is cut into at most K runs of
 // whole 64-entry chunks; run k is [k seg_len, (k + 1) seg_len) of the list.
 __device__ __forceinline__ int seg_len_of(const int len, const int K) { return ((len + K * 64 - 1) / (K * 64)) * 64; }
+
+// ---- measurement hook (gsr_debug_wave_trace): one 32-byte record per wave that ran a tile to its end ------------
+// {constant 100-MHz clock at entry, at exit, tile | allowed << 32, list length | hw id << 32}: who ran when and for
+// how long -- the tail / imbalance of a launch (tools/exp/wave_trace.py).  hw id = HW_REG_HW_ID (SIMD [5:4], CU [11:8],
+// SH [12], SE [15:13]) | XCC_ID << 20.
+struct WaveTrace {
+  unsigned long long *buf;
+  unsigned capacity;
+};
+__device__ __forceinline__ unsigned long long trace_begin(const WaveTrace &tr) {
+  return tr.buf ? wall_clock64() : 0ull;
+}
+__device__ __forceinline__ void trace_end(const WaveTrace &tr, const unsigned long long t0, const int tile,
+                                          const int allowed, const int len) {
+  if (tr.buf && blockIdx.x < tr.capacity && threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    unsigned long long *r = tr.buf + 4ull * blockIdx.x;
+    r[0] = t0;
+    r[1] = wall_clock64();
+    r[2] = (unsigned long long)(unsigned)tile | ((unsigned long long)(unsigned)allowed << 32);
+    r[3] = (unsigned long long)(unsigned)len | ((unsigned long long)((hw & 0xffffu) | (xcc << 20)) << 32);
+  }
+}
 
 // Stage up to 64 splats (one per `live` lane, sorted index `sidx`) into LDS,
 // dropping the ones that cannot reach the tile; returns how many were kept.

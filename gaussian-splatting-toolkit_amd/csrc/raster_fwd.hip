@@ -31,6 +31,7 @@ using namespace gsr;
 // stage to *g_fwd_staged (gsr_debug_count_staged, used by bench.py to price the roofline on
 // the entries actually touched -- tiles stop early once every pixel is saturated)
 __device__ unsigned long long *g_fwd_staged = nullptr;
+__device__ gsr::WaveTrace g_fwd_trace = {nullptr, 0u};
 
 // ------------------------------------------------------------------ tile16
 // The kernel is VALU-issue bound (rocprof: VALU busy ~86 %, LDS and memory
@@ -96,10 +97,13 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     seg_k = (int)(blk / (4u * base_grid));
     blk -= (unsigned)seg_k * (4u * base_grid);
   }
+  const WaveTrace trace = g_fwd_trace;
+  const unsigned long long trace_t0 = trace_begin(trace);
   const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile;
   int allowed = job.allowed;
   if (tile < 0) return;
+  const int trace_len = range.y - range.x;
   bool split = false;
   if constexpr (SEG) {
     const int len = range.y - range.x;
@@ -262,6 +266,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       if constexpr (RGBD) out_extra[pid] = ce[p] + Tp * bg_extra;
     }
   }
+  trace_end(trace, trace_t0, tile, allowed, trace_len);
 }
 
 // Pre-pass of the depth segments: the transmittance product of run seg_k = block / (4 base_grid) (every run but a
@@ -880,6 +885,13 @@ GSR_EXPORT int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, 
                        final_idx, (const float *)nullptr, 0.f, (float *)nullptr, deep, base, out_alpha,
                        static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), round, tile_flags, idx_base);
   GSR_CHECK_LAUNCH("rasterize_forward_round");
+  return GSR_OK;
+}
+
+// internal: see gsr_debug_wave_trace (raster_bwd.hip)
+int gsr_set_fwd_wave_trace(unsigned long long *buf, unsigned capacity) {
+  gsr::WaveTrace t = {buf, capacity};
+  GSR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_trace), &t, sizeof(t)));
   return GSR_OK;
 }
 

@@ -43,7 +43,7 @@ class _Activate(Function):
                   _ptr(quats), _ptr(opac), _ptr(dirs) if want_dirs else None, _stream(dev))
         ctx.save_for_backward(raw_quats, scales, quats, opac)
         ctx.set_materialize_grads(False)
-        from rasterizer.rasterize import announce_opacity
+        from rasterizer.ahead import announce_opacity
 
         announce_opacity(opac)  # the projection that follows may start this view's tile lists with it
         if want_dirs:

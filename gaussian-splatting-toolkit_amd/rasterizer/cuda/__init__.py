@@ -64,13 +64,17 @@ def _on(dev):
 def _carve(sizes, dev):
     """One float32 allocation cut into 1-D pieces of `sizes` elements, each starting on a 256-byte boundary (what a
     separate `torch.empty` would give: the kernels read rows as float2 / float4) -- one allocator round trip
-    instead of len(sizes)."""
+    instead of len(sizes).  The pieces are tensors of their OWN over the shared storage (`set_`), not views of one
+    base: each has its own version counter, so a caller's in-place op on one output (`depths.clamp_()`, a masked
+    `radii`) neither invalidates the others that an autograd node saved nor trips "a view created inside a custom
+    Function was modified in place" (ADVICE r4).  What remains of the sharing: the block lives as long as any piece
+    does, and `torch.save` of one piece writes the whole storage -- `.clone()` an output that is kept for long."""
     offs, total = [], 0
     for sz in sizes:
         offs.append(total)
         total += (int(sz) + 63) & ~63
-    flat = torch.empty((max(total, 1),), dtype=_f32, device=dev)
-    return [flat[o:o + int(sz)] for o, sz in zip(offs, sizes)]
+    store = torch.empty((max(total, 1),), dtype=_f32, device=dev).untyped_storage()
+    return [torch.empty((0,), dtype=_f32, device=dev).set_(store, o, (int(sz),), (1,)) for o, sz in zip(offs, sizes)]
 
 
 def _stream(device) -> C.c_void_p:
@@ -595,10 +599,12 @@ def _segment_knobs():
     if not _segment_cache:
         import os
 
-        _segment_cache["v"] = (int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")),
+        # (the C entries take at most 16 runs -- GSR_REQUIRE(segments <= 16) -- and the backward calls them from inside
+        #  autograd: a larger value in the environment is clamped here instead of raising there)
+        _segment_cache["v"] = (min(16, max(1, int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")))),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_GRID", "1100")),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")),
-                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "8")))
+                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "8")))))
     return _segment_cache["v"]
 
 
@@ -635,7 +641,7 @@ def _deep_knobs():
     if not _deep_cache:
         import os
 
-        _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "1024")),
+        _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "256")),
                             int(os.environ.get("GSR_SMALL_GRID", "2560")), int(os.environ.get("GSR_SMALL_GRID_MIN", "96")),
                             int(os.environ.get("GSR_SMALL_GRID_BWD", "1100")))
     return _deep_cache["v"]

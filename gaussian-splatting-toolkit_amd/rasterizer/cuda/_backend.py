@@ -11,7 +11,8 @@ import os
 import subprocess
 
 PATH = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PATH, "libgsraster.so")
+# (GSR_LIBRARY: another build of the same library, for A/B measurements of compile-time variants -- tools/r05/)
+LIB_PATH = os.environ.get("GSR_LIBRARY") or os.path.join(PATH, "libgsraster.so")
 CSRC = os.path.normpath(os.path.join(PATH, "..", "..", "csrc"))
 
 # every symbol include/gsraster.h declares
@@ -82,6 +83,7 @@ SYMBOLS = (
     "gsr_rasterize_backward_det_workspace_bytes",
     "gsr_rasterize_backward_det",
     "gsr_debug_count_staged",
+    "gsr_debug_wave_trace",
     "gsr_calibrate_valu",
     "gsr_calibrate_copy",
 )

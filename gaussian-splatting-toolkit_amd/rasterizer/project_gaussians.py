@@ -14,7 +14,7 @@ import rasterizer.cuda as _C
 
 
 def _ahead(*args):
-    from rasterizer.rasterize import speculate_lists  # (imported late: rasterize imports this package's siblings)
+    from rasterizer.ahead import speculate_lists  # (imported late: the package is still being imported)
 
     speculate_lists(*args)
 

@@ -856,6 +856,16 @@ int gsr_rasterize_backward_det(
  * it).  Device-wide setting (synchronises the device); not for production loops. */
 int gsr_debug_count_staged(unsigned long long *counters);
 
+/* ---- measurement hook: who ran when ---------------------------------------------
+ * records: device buffer of 2 * capacity_waves * 4 uint64 (or NULL = off, the
+ * default).  While set, every wave of the 16x16 compositing kernels that runs its
+ * tile to the end writes {100-MHz clock at entry, at exit, tile | sub-tile mask <<
+ * 32, list length | hardware id << 32} to record blockIdx.x -- forward launches to
+ * the first capacity_waves records, backward launches to the second half.  The
+ * tail and the imbalance of a launch (tools/exp/wave_trace.py).  Device-wide
+ * setting (synchronises the device); not for production loops. */
+int gsr_debug_wave_trace(unsigned long long *records, unsigned capacity_waves);
+
 /* ---- box calibration (bench.py `calibration`; not part of the path) ----------
  * Two fixed workloads, timed by the caller with events on `stream` next to the
  * bench's own steps, so that a move of the headline between two GPU leases can be

@@ -675,6 +675,13 @@ def test_compositing_kernels_on_random_shapes():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert out.stdout.count(" ok") >= 40
+    # once more with the depth-segment kernels forced onto short lists (the fuzz's grids are all below the 1 100
+    # tiles on which every tile above 96 entries is split): 5 runs for every list of more than one chunk
+    env = dict(os.environ, GSR_DEPTH_SEGMENTS="5", GSR_DEPTH_SEGMENTS_MIN="64", GSR_DEPTH_SEGMENTS_FWD="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_raster.py"), "40", "57"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count(" ok") >= 25
 
 
 def test_projection_and_sh_on_random_cameras_and_scales():
@@ -881,6 +888,83 @@ def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, rgbd, monk
             assert (x - y).abs().max().item() <= 2e-5 * x.abs().max().item(), (segs, least, thr)
     with pytest.raises(RuntimeError):
         run(17, 64)  # at most 16 runs
+
+
+@pytest.mark.parametrize("segs,least", [(1, 0), (5, 64), (16, 64)])
+@pytest.mark.parametrize("opaque", [False, True])
+@pytest.mark.parametrize("rgbd", [False, True])
+def test_depth_segment_kernels_against_the_oracle(segs, least, opaque, rgbd, monkeypatch):
+    """The depth-segment kernels (gsr_rasterize_forward_seg / _backward_seg, plain and RGBD) against the ORACLE, not
+    against this package's single walk: the deep-tile threshold forced low (every tile with more than 96 entries is
+    split over four waves, the precondition of the runs), 1 / 5 / 16 runs, a translucent long-tail scene and the same
+    scene nearly opaque.  Forward: 1e-4 abs on decision-stable pixels, the last drawn index equal there (a run
+    boundary may move it at a handful of pixels whose stop decision is within rounding: <= 1e-3 of them);
+    backward: 1e-3 relative (floor 1e-3 of the largest), from the ORACLE's forward state."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 30_000, 320, 208, 16
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=15, scale_lo=0.01, scale_hi=0.08, longtail=True)
+    opac = sc["opacities"].copy()
+    if opaque:
+        opac = np.maximum(opac, 0.97).astype(np.float32)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    I, cum = O.compute_cumulative_intersects(tiles)
+    _, _, ks, vs, bins = O.bin_and_sort_gaussians(n, I, xys, depths, radii, cum, tb, bw)
+    assert (bins[:, 1] - bins[:, 0]).max() > 1500  # lists long enough for 16 runs of whole chunks
+    rng = np.random.default_rng(3)
+    colors = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    bg = rng.uniform(0, 1, 3).astype(np.float32)
+    ebg = 0.25
+    ref = O.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), vs, bins, xys, conics, colors, opac, bg, ambig_eps=1e-5)
+    dcol = np.repeat(depths[:, None], 3, 1).astype(np.float32)
+    refd = O.rasterize_forward(tb, (bw, bw, 1), (W, H, 1), vs, bins, xys, conics, dcol, opac,
+                               np.full(3, ebg, np.float32)) if rgbd else None
+
+    monkeypatch.setattr(C, "_segment_knobs", lambda: (16, 1100, 512, 0))
+    monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: 96)
+    monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (segs, least))
+    g = dict(ids=cu(vs), bins=cu(bins), xys=cu(xys), conics=cu(conics), colors=cu(colors), opac=cu(opac), bg=cu(bg))
+    if rgbd:
+        img, ext, Ts, idx, alpha = C.rasterize_forward_rgbd(tb, (W, H, 1), g["ids"], g["bins"], g["xys"], g["conics"],
+                                                            g["colors"], cu(depths), g["opac"], g["bg"], ebg,
+                                                            want_alpha=True)
+    else:
+        img, Ts, idx, alpha = C.rasterize_forward_ex(tb, (bw, bw, 1), (W, H, 1), g["ids"], g["bins"], g["xys"],
+                                                     g["conics"], g["colors"], g["opac"], g["bg"], want_alpha=True)
+    ok = ~ref[3]
+    check_image(npy(img), npy(Ts), ref, ref[3])
+    assert (npy(idx)[ok] != ref[2][ok]).mean() <= 1e-3
+    assert np.abs(npy(alpha) - (1 - ref[1]))[ok].max() < 1e-4
+    if rgbd:
+        assert np.abs(npy(ext) - refd[0][..., 0])[ok].max() < 1e-4 * max(1.0, float(depths.max()))
+    if opaque:
+        assert (ref[1] < 1e-3).mean() > 0.5  # most pixels saturate: the runs behind them are never composited
+
+    # backward from the oracle's forward state
+    v_img = rng.uniform(-1, 1, (H, W, 3)).astype(np.float32)
+    v_alpha = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    v_ext = rng.uniform(-1, 1, (H, W)).astype(np.float32)
+    rb = list(O.rasterize_backward(H, W, bw, vs, bins, xys, conics, colors, opac, bg, ref[1], ref[2], v_img, v_alpha))
+    if rgbd:
+        ve3 = np.zeros((H, W, 3), np.float32)
+        ve3[..., 0] = v_ext
+        rd = O.rasterize_backward(H, W, bw, vs, bins, xys, conics, dcol, opac, np.full(3, ebg, np.float32), refd[1],
+                                  refd[2], ve3, np.zeros((H, W), np.float32))
+        rb[0], rb[1], rb[3] = rb[0] + rd[0], rb[1] + rd[1], rb[3] + rd[3]
+        rb.append(rd[2][:, 0])
+        got = C.rasterize_backward_rgbd(H, W, g["ids"], g["bins"], g["xys"], g["conics"], g["colors"], cu(depths),
+                                        g["opac"], g["bg"], ebg, cu(ref[1]), cu(ref[2]), cu(v_img), cu(v_ext),
+                                        cu(v_alpha))
+        names = ["v_xy", "v_conic", "v_colors", "v_extra", "v_opacity"]
+        rb = [rb[0], rb[1], rb[2], rb[4], rb[3]]
+    else:
+        got = C.rasterize_backward(H, W, bw, g["ids"], g["bins"], g["xys"], g["conics"], g["colors"], g["opac"],
+                                   g["bg"], cu(ref[1]), cu(ref[2]), cu(v_img), cu(v_alpha))
+        names = ["v_xy", "v_conic", "v_colors", "v_opacity"]
+    for a, r, nm in zip(got, rb, names):
+        grad_close(npy(a).reshape(np.asarray(r).shape), np.asarray(r), name=f"{nm} segs={segs}")
 
 
 @pytest.mark.parametrize("W,H,n", [(320, 208, 40_000), (3840, 2160, 30_000)])
