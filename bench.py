@@ -104,11 +104,21 @@ class KernelTimers:
                 for k, v in self.pairs.items()}
 
 
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz, non-packed fp32: 39.3 T lane-ops/s
+# What one gfx950 SIMD issues depends on the instruction (tools/exp/valubench2.hip, profiles/r05_valubench2.txt; the
+# guide's "SIMD-32, two cycles per wave64 instruction" holds for the plain class only):
+#   ~2.4 cycles  v_add / v_sub / v_mul / v_fmac / v_fmamk / v_mov / v_and ...            -> 78.6 T lane-ops/s chip-wide
+#   ~2.7         v_fma_f32 (VOP3)
+#   ~4.2         v_min / v_max, v_cmp, v_cndmask, DPP, v_cvt, anything with an SGPR source, v_pk_* (2 lane-ops per lane)
+#   ~8.2         v_exp / v_rcp / v_rsq, v_permlane{16,32}_swap
+# and ONE wave alone issues at most one VALU instruction per ~5 cycles.  The peak below is the plain class's.
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+# mean issue cost of one VALU instruction of the compositing loops as compiled (tools/isa_tally.py with the table above:
+# profiles/r05_isa_tally_cycles.txt, 338.2 cycles / 99 and 2591.9 / 793 instructions per loop body)
+VALU_CYCLES_PER_INSTRUCTION = {"raster_fwd": 3.42, "raster_bwd": 3.27}
 # `value_normalised` = value x (CALIBRATION_REFERENCE / this run's VALU calibration): what the same code would read on a
 # box in the reference clock state.  The reference is the calibration of the lease this round's kernels were tuned on
 # (profiles/r05_calibration.txt); the step is VALU-issue bound for ~2/3 of its time (compositing), HBM-bound for the rest
-CALIBRATION_REFERENCE_VALU_TOPS = 31.0
+CALIBRATION_REFERENCE_VALU_TOPS = 67.0
 FIXED_WARMUP_SECONDS = 0.35  # of the workload itself, ahead of the timed steps, whatever --warmup says
 
 
@@ -1086,6 +1096,12 @@ def main():
                 simd_cycles = qa / 8.0 * 1024.0
                 roofline["valu_busy"] = round(qi * 4.0 / simd_cycles, 3)
                 roofline["limiter"] = "VALU issue (SQ_INSTS_VALU x 4 cycles / SIMD-cycles resident, this run)"
+                cpi = VALU_CYCLES_PER_INSTRUCTION.get(dominant)
+                if cpi:
+                    # ... with every instruction priced at its MEASURED issue cost instead of a flat 4 cycles
+                    roofline["valu_pipe_busy"] = round(qi * cpi / simd_cycles, 3)
+                    roofline["valu_pipe_busy_what"] = (f"SQ_INSTS_VALU x {cpi} cycles (the loop's mean issue cost per "
+                                                       "instruction by the measured per-class table) / SIMD-cycles resident")
             qi_launch, _ = pmc_stage(q, dominant, "SQ_INSTS_VALU", 1)
             if qi_launch is not None and kern_ms[dominant] > 0:
                 # the roofline the compositing kernels ARE at: wave64 VALU instructions of one launch x 64 lanes over
@@ -1093,7 +1109,9 @@ def main():
                 lane_ops = qi_launch * 64.0 / (kern_ms[dominant] * 1e-3)
                 roofline["valu"] = {"lane_ops_per_s": round(lane_ops / 1e12, 2), "unit": "T lane-ops/s",
                                     "peak": round(VALU_PEAK_LANE_OPS / 1e12, 1),
-                                    "peak_what": "256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz, non-packed fp32",
+                                    "peak_what": "256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz: the plain class (add / mul / fmac, "
+                                                 "~2.4 cycles per wave64 instruction measured); v_fma 2.7, cmp / cndmask / min / "
+                                                 "DPP 4.2, exp / rcp / permlane_swap 8.2 -- see valu_pipe_busy",
                                     "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 3),
                                     "valu_instructions_per_launch": int(qi_launch)}
         # every kernel's own fraction, and the end-to-end figure from SURVEY 8(d)

@@ -106,6 +106,12 @@ __device__ __forceinline__ bool gsr_cov2d_bounds(float c0, float c1, float c2,
   return true;
 }
 
+// deep_tile_threshold carries one flag bit besides the threshold (include/gsraster.h, GSR_DEEP_ORDERED): the buffer
+// behind tile_bins holds the launch's JOB ORDER (raster_common.h), built by the entry point itself.
+#define GSR_DEEP_FLAGS GSR_DEEP_ORDERED
+__host__ __device__ __forceinline__ int gsr_deep_threshold(int v) { return v > 0 ? (v & ~GSR_DEEP_FLAGS) : 0; }
+__host__ __device__ __forceinline__ bool gsr_deep_ordered(int v) { return v > 0 && (v & GSR_DEEP_ORDERED) != 0; }
+
 // XCD-aware workgroup -> tile remap.  Workgroup b is dispatched to XCD b % 8
 // (observed, used for speed only).  The tile grid is cut into blocks of 8 x 4 tiles
 // that are dealt to the XCDs round-robin: the tiles of a block -- which share most

@@ -36,6 +36,9 @@
 #ifndef GSR_BWD_GROUP
 #define GSR_BWD_GROUP 4
 #endif
+#ifndef GSR_BWD_FOLD_VALID
+#define GSR_BWD_FOLD_VALID 1
+#endif
 
 namespace {
 // measurement hook, see raster_fwd.hip
@@ -432,9 +435,19 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             // it finished in front of this splat
             if (!((C.mask >> p) & 1) || C.sidx > topp[p]) continue;
             const float sigma = sig[p];
-            const float vis = __expf(-sigma);
-            const float alpha = fminf(GSR_ALPHA_MAX_BWD, B.opac * vis);
-            const bool valid = (C.sidx <= binf[p]) && !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+            const float vis0 = __expf(-sigma);
+            const float alpha0 = fminf(GSR_ALPHA_MAX_BWD, B.opac * vis0);
+            const bool valid = (C.sidx <= binf[p]) && !(sigma < 0.f || alpha0 < GSR_ALPHA_MIN);
+#if GSR_BWD_FOLD_VALID
+            // An invalid (pixel, splat) pair runs the same arithmetic on alpha = vis = 0: ra = 1 / (1 - 0) = 1, T * 1 = T
+            // and alpha * T = 0 EXACTLY, so T, K and every sum come out as with the three selects this replaces (two
+            // v_cndmask, 4.2 issue cycles each on gfx950, instead of three: DESIGN.md section 4.17).  v_alpha stays finite
+            // (T, K and the cotangents are: NaN cotangents of undrawn pixels were zeroed at the load), so 0 * v_alpha = 0.
+            const float alpha = valid ? alpha0 : 0.f;
+            const float vis = valid ? vis0 : 0.f;
+#else
+            const float alpha = alpha0, vis = vis0;
+#endif
             const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
             const float Tn = T[p] * ra;
             // sum_c (rgb_c*T - buffer_c*ra) v_out_c + T_final*ra*(v_out_alpha - bg.v_out)
@@ -444,9 +457,15 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
             float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
             if constexpr (RGBD) d += C.extra * ve[p];  // (a literal "+ 0.f" in the 3-channel case is a real v_add: -0 semantics)
             const float v_alpha = Tn * d + ra * K[p];
+#if GSR_BWD_FOLD_VALID
+            const float w = vis * v_alpha;
+            const float fac = alpha * Tn;
+            T[p] = Tn;
+#else
             const float w = valid ? vis * v_alpha : 0.f;
             const float fac = valid ? alpha * Tn : 0.f;
             T[p] = valid ? Tn : T[p];
+#endif
             K[p] -= fac * d;
             sr += fac * vr[p];
             sg += fac * vg[p];
@@ -886,7 +905,7 @@ GSR_EXPORT int gsr_rasterize_backward_ex(
     return (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : GSR_BWD_GROUP;
   }();
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
-  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const int deep = gsr_prepare_jobs(deep_tile_threshold, tiles_x, tiles_y, tile_bins, s);
 #define GSR_LAUNCH_T16(G)                                                                          \
   hipLaunchKernelGGL((raster_bwd_tile16_kernel<G, false>), dim3(deep ? 4 * base : base),            \
                      dim3(64), 0, s, tiles_x,                                                        \
@@ -926,7 +945,7 @@ GSR_EXPORT int gsr_rasterize_backward_rgbd(
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
-  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const int deep = gsr_prepare_jobs(deep_tile_threshold, tiles_x, tiles_y, tile_bins, s);
   hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, true>), dim3(deep ? 4 * base : base), dim3(64),
                      0, s, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics,
@@ -983,13 +1002,15 @@ GSR_EXPORT int gsr_rasterize_backward_seg(
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  const int deep_arg = gsr_prepare_jobs(deep_tile_threshold, tiles_x, tiles_y, tile_bins, s);  // (threshold | order flag)
+  deep_tile_threshold = gsr_deep_threshold(deep_tile_threshold);
   const int seg_min = segment_min_entries > deep_tile_threshold ? segment_min_entries : deep_tile_threshold;
   float2 *state = static_cast<float2 *>(workspace);
 #define GSR_LAUNCH_BWD_SEG(RGBD_)                                                                                      \
   hipLaunchKernelGGL(raster_bwd_segstate_kernel<RGBD_>, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s,    \
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                         \
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,  \
-                     opacities, final_Ts, final_idx, v_output, extra, v_output_extra, deep_tile_threshold, base,       \
+                     opacities, final_Ts, final_idx, v_output, extra, v_output_extra, deep_arg, base,                  \
                      segments, seg_min, state);                                                                        \
   hipLaunchKernelGGL(raster_bwd_segprefix_kernel, dim3((unsigned)(((size_t)img_height * img_width + 255) / 256)),     \
                      dim3(256), 0, s, tiles_x, (int)img_width, (int)img_height,                                        \
@@ -998,7 +1019,7 @@ GSR_EXPORT int gsr_rasterize_backward_seg(
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                         \
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,  \
                      opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,    \
-                     v_opacity, extra, extra_background, v_output_extra, v_extra, deep_tile_threshold, base,           \
+                     v_opacity, extra, extra_background, v_output_extra, v_extra, deep_arg, base,                      \
                      (float *)nullptr, (unsigned char *)nullptr, (const int2 *)nullptr, 0, segments, seg_min,          \
                      (const float2 *)state)
   if (rgbd) {
@@ -1037,7 +1058,7 @@ GSR_EXPORT int gsr_rasterize_backward_two(
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
-  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const int deep = gsr_deep_threshold(deep_tile_threshold);  // (two-round lists: the static block order)
   const dim3 grd(deep ? 4 * base : base), blk(64);
   if (rgbd)
     hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, true>), grd, blk, 0, s, tiles_x, num_tiles, (int)img_width,

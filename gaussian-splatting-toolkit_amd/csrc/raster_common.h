@@ -91,24 +91,33 @@ __device__ __forceinline__ int splat_reach_mask(float x, float y, float a, float
 // its sub-tile, so results are bit-identical to the one-wave-per-tile walk.
 // Block b of the extra range [base_grid, 4 base_grid) sits on XCD b % 8 like the regular
 // block of the same tile (the four waves share the splat records in one L2).
-// ORDER (round 5): the hardware starts workgroups in block order, and a deep tile is the longest job of the launch.
-// With the extra blocks BEHIND the regular ones (rounds 2-4) three quarters of every deep tile's work were the last
-// waves to start -- the opposite of longest-job-first.  The extra range now comes first: blocks [0, 3 base_grid) are
-// the extra sub-tile waves (the ones of shallow tiles exit at once), blocks [3 base_grid, 4 base_grid) the regular
-// ones.  The XCD of a block is unchanged (base_grid is a multiple of 8).  GSR_DEEP_EXTRAS_FIRST=0 builds the old order.
-#ifndef GSR_DEEP_EXTRAS_FIRST
-#define GSR_DEEP_EXTRAS_FIRST 1
-#endif
+// ORDER (round 5).  The hardware starts workgroups in block order, and a launch lasts as long as its last wave: with a
+// static block -> tile map the waves that start last are whatever tiles sit at the end of the map, and on a scene whose
+// lists differ in length (every trained model) the second half of the launch is a few long walks on an emptying chip
+// (tools/exp/wave_trace.py, profiles/r05_wave_trace.txt: 50 % of the waves done after 40 % of the span, the last 1 %
+// take the final 20 %).  With GSR_DEEP_ORDERED in deep_tile_threshold the entry point first builds a JOB ORDER in the
+// 4 base_grid ints behind tile_bins (tile_jobs_kernel): per XCD -- a block's XCD is b % 8, and a tile keeps the XCD
+// the static map gives it, so the L2 that holds a neighbourhood's splats stays the same -- its tiles' jobs (the whole
+// tile, or four sub-tile jobs above the threshold) sorted by estimated work, LONGEST FIRST; block b runs job[b].
+// Without the flag: the static map, regular blocks first, the extra sub-tile blocks behind them.
 struct TileJob {
   int tile;     // < 0: nothing to do
   int allowed;  // sub-tile mask this wave owns (15 = the whole tile)
 };
-__device__ __forceinline__ TileJob tile_job(const unsigned b_launch, const unsigned base_grid, const int tiles_x,
+constexpr int kJobTileBits = 27;  // job = tile | allowed << 27; -1 = none
+__device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned base_grid, const int tiles_x,
                                             const int tiles_y, const int2 *__restrict__ tile_bins,
-                                            const int deep_threshold, int2 &range) {
+                                            const int deep_arg, int2 &range) {
   TileJob j{-1, 15};
-  unsigned b = b_launch;
-  if (GSR_DEEP_EXTRAS_FIRST && deep_threshold > 0) b = b_launch < 3u * base_grid ? b_launch + base_grid : b_launch - 3u * base_grid;
+  const int deep_threshold = gsr_deep_threshold(deep_arg);
+  if (gsr_deep_ordered(deep_arg)) {
+    const int code = reinterpret_cast<const int *>(tile_bins + (size_t)tiles_x * tiles_y)[b];
+    if (code < 0) return j;
+    j.tile = code & ((1 << kJobTileBits) - 1);
+    j.allowed = code >> kJobTileBits;
+    range = tile_bins[j.tile];
+    return j;
+  }
   if (b < base_grid) {
     j.tile = gsr_xcd_remap(b, tiles_x, tiles_y);
     if (j.tile < 0) return j;
@@ -124,6 +133,85 @@ __device__ __forceinline__ TileJob tile_job(const unsigned b_launch, const unsig
   j.tile = tile;
   j.allowed = 2 << (q % 3u);
   return j;
+}
+
+// The job order of one launch: one workgroup of 1024 lanes per XCD.  Items: every tile the static map gives this XCD
+// -- one job (tile, 15) keyed by its list length, or, above the threshold, four jobs (tile, 1 << p) keyed by length / 4
+// (a sub-tile wave stages only what reaches its sub-tile and evaluates a quarter of the pixels: measured 0.09-0.15 us
+// per list entry against 0.47-0.65 for a whole-tile wave).  Counting sort, descending, on HALF-OCTAVE buckets of the
+// key (bucket = floor(2 log2 key)): jobs inside a bucket differ by < 1.42 x in length and keep -- up to the order in
+// which the waves' LDS atomics land, i.e. in runs of 64 slots -- the static map's SPATIAL order.  That matters: with a
+// fine-grained sort (2 048 linear buckets, the first version) a scene whose lists are all alike was shuffled into a
+// random spatial order for nothing, the tiles running together no longer shared their splats in the XCD's L2, and
+// the uniform bench scene lost 4 % (profiles/r05_lpt_ab.txt); with half-octaves its tiles fall into one or two
+// buckets and the launch is the static one.
+constexpr int kJobBuckets = 64;
+__device__ __forceinline__ int job_bucket(const int key) {  // larger keys -> smaller bucket index (sorted first)
+  if (key <= 0) return kJobBuckets - 1;
+  const int k = 31 - __clz(key);                                          // floor(log2 key)
+  const int half = ((unsigned long long)key * (unsigned)key) >> (2 * k + 1);  // key^2 >= 2^(2k+1)  <=>  key >= 2^k sqrt 2
+  return max(0, kJobBuckets - 2 - (2 * k + (half ? 1 : 0)));
+}
+static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_x, const int tiles_y,
+                                                                const unsigned base_grid,
+                                                                const int2 *__restrict__ tile_bins,
+                                                                const int deep_threshold, int *__restrict__ jobs) {
+  __shared__ int hist[kJobBuckets];
+  __shared__ int total_s;
+  const unsigned xcd = blockIdx.x, slots = base_grid / 8u;
+  const int tid = threadIdx.x;
+  if (tid < kJobBuckets) hist[tid] = 0;
+  __syncthreads();
+  // pass 1: histogram
+  for (unsigned s = tid; s < slots; s += 1024) {
+    const int tile = gsr_xcd_remap(s * 8u + xcd, tiles_x, tiles_y);
+    if (tile < 0) continue;
+    const int2 r = tile_bins[tile];
+    const int len = r.y - r.x;
+    if (deep_threshold > 0 && len > deep_threshold) atomicAdd(&hist[job_bucket(len >> 2)], 4);
+    else atomicAdd(&hist[job_bucket(len)], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the 64 buckets by one wave
+    const int v = hist[tid];
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (tid >= o) incl += t;
+    }
+    hist[tid] = incl - v;
+    if (tid == 63) total_s = incl;
+  }
+  __syncthreads();
+  const int total = total_s;
+  // pass 2: scatter (lanes of a wave land in lane order: 64 consecutive slots stay together inside a bucket)
+  for (unsigned s = tid; s < slots; s += 1024) {
+    const int tile = gsr_xcd_remap(s * 8u + xcd, tiles_x, tiles_y);
+    if (tile < 0) continue;
+    const int2 r = tile_bins[tile];
+    const int len = r.y - r.x;
+    if (deep_threshold > 0 && len > deep_threshold) {
+      const int at = atomicAdd(&hist[job_bucket(len >> 2)], 4);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) jobs[(size_t)(at + p) * 8u + xcd] = tile | ((1 << p) << kJobTileBits);
+    } else {
+      const int at = atomicAdd(&hist[job_bucket(len)], 1);
+      jobs[(size_t)at * 8u + xcd] = tile | (15 << kJobTileBits);
+    }
+  }
+  for (unsigned s = total + tid; s < 4u * slots; s += 1024) jobs[(size_t)s * 8u + xcd] = -1;
+}
+
+// (host) build the job order behind tile_bins when deep_arg asks for it; -> the argument the kernels take
+static inline int gsr_prepare_jobs(const int deep_arg, const int tiles_x, const int tiles_y, const int32_t *tile_bins,
+                            hipStream_t s) {
+  if (!gsr_deep_ordered(deep_arg)) return gsr_deep_threshold(deep_arg);
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  int *jobs = const_cast<int *>(tile_bins) + 2 * (size_t)tiles_x * tiles_y;
+  hipLaunchKernelGGL(tile_jobs_kernel, dim3(8), dim3(1024), 0, s, tiles_x, tiles_y, base,
+                     reinterpret_cast<const int2 *>(tile_bins), gsr_deep_threshold(deep_arg), jobs);
+  return deep_arg;
 }
 
 // Depth segments (raster_fwd.hip / raster_bwd.hip): a split tile's list of `len` entries is cut into at most K runs of

@@ -713,7 +713,7 @@ GSR_EXPORT int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block
                           background, out_img, final_Ts, final_idx, (hipStream_t)stream);
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
-  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const int deep = gsr_prepare_jobs(deep_tile_threshold, tiles_x, tiles_y, tile_bins, (hipStream_t)stream);
   hipLaunchKernelGGL(raster_fwd_tile16_kernel<false>, dim3(deep ? 4 * base : base), dim3(64), 0,
                      (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
@@ -767,6 +767,8 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
   const size_t px = (size_t)img_height * img_width;
+  const int deep_arg = gsr_prepare_jobs(deep_tile_threshold, tiles_x, tiles_y, tile_bins, s);  // (threshold | order flag)
+  deep_tile_threshold = gsr_deep_threshold(deep_tile_threshold);
   const int seg_min = segment_min_entries > deep_tile_threshold ? segment_min_entries : deep_tile_threshold;
   char *ws = static_cast<char *>(workspace);
   float *tau = reinterpret_cast<float *>(ws);
@@ -776,7 +778,7 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
   hipLaunchKernelGGL(raster_fwd_segtau_kernel, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s, tiles_x,
                      num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
-                     opacities, deep_tile_threshold, base, segments, seg_min, tau);
+                     opacities, deep_arg, base, segments, seg_min, tau);
   hipLaunchKernelGGL(raster_fwd_segprefix_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, tiles_x,
                      (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), deep_tile_threshold,
                      segments, seg_min, tau);
@@ -785,7 +787,7 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,   \
                      opacities, background, out_img, final_Ts, final_idx, extra, extra_background, out_extra,           \
-                     deep_tile_threshold, base, out_alpha, static_cast<unsigned *>(zero_ptr),                            \
+                     deep_arg, base, out_alpha, static_cast<unsigned *>(zero_ptr),                                       \
                      (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, (const float *)tau, raw,      \
                      lastp, extrap)
   if (extra) GSR_LAUNCH_FWD_SEG(true);
@@ -837,7 +839,7 @@ GSR_EXPORT int gsr_rasterize_forward_rgbd(int tiles_x, int tiles_y, unsigned img
               "rasterize_forward_rgbd: zero_ptr / zero_bytes must be multiples of 4 (and below 16 GB)");
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
-  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const int deep = gsr_prepare_jobs(deep_tile_threshold, tiles_x, tiles_y, tile_bins, (hipStream_t)stream);
   hipLaunchKernelGGL(raster_fwd_tile16_kernel<true>, dim3(deep ? 4 * base : base), dim3(64), 0,
                      (hipStream_t)stream, tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
                      reinterpret_cast<const int2 *>(tile_bins),
@@ -870,7 +872,7 @@ GSR_EXPORT int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, 
               "rasterize_forward_round: zero_ptr / zero_bytes must be multiples of 4 (and below 16 GB)");
   const int num_tiles = tiles_x * tiles_y;
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
-  const int deep = deep_tile_threshold > 0 ? deep_tile_threshold : 0;
+  const int deep = gsr_deep_threshold(deep_tile_threshold);  // (two-round lists: the static block order)
   const dim3 grd(deep ? 4 * base : base), blk(64);
   if (extra)
     hipLaunchKernelGGL(raster_fwd_tile16_kernel<true>, grd, blk, 0, (hipStream_t)stream, tiles_x, num_tiles,
@@ -886,6 +888,10 @@ GSR_EXPORT int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, 
                        static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), round, tile_flags, idx_base);
   GSR_CHECK_LAUNCH("rasterize_forward_round");
   return GSR_OK;
+}
+
+GSR_EXPORT size_t gsr_tile_jobs_ints(int tiles_x, int tiles_y) {
+  return tiles_x > 0 && tiles_y > 0 ? 4 * (size_t)gsr_xcd_grid(tiles_x, tiles_y) : 0;
 }
 
 // internal: see gsr_debug_wave_trace (raster_bwd.hip)

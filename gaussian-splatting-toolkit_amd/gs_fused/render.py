@@ -162,7 +162,7 @@ class _Render(Function):
             recs = e((n, rec_b), torch.uint8)
             counts = None if lean else e((n,), _i32)
             cum = None if lean else e((n,), _i32)
-            order, ids, bins = e((n,), _i32), e((capacity,), _i32), e((tb[0] * tb[1], 2), _i32)
+            order, ids, bins = e((n,), _i32), e((capacity,), _i32), _C.alloc_tile_bins(tb, dev)
             sort_ws, bin_ws = e((max(sort_b, 1),), torch.uint8), e((max(bin_b, 1),), torch.uint8)
             img, Ts, idx, alpha = e((H, W, 3)), e((H, W)), e((H, W), _i32), e((H, W))
             dep = e((H, W)) if spec.render_depth else None
@@ -172,7 +172,7 @@ class _Render(Function):
             seg = _segments(spec, capacity, dev)
             desc = _ViewDesc(n, degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy, spec.cx,
                              spec.cy, spec.glob_scale, spec.clip_thresh, capacity,
-                             _C.deep_tile_threshold(capacity, tb[0] * tb[1]),
+                             _C.deep_arg(bins, capacity, tb[0] * tb[1], tile_bounds=tb),
                              p(means), p(log_scales), p(raw_quats), p(logits), p(features_dc), p(features_rest),
                              p(viewmat), p(projmat), p(campos), p(background), p(scales), p(quats), p(opac), p(dirs),
                              p(cov3d), p(xys), p(depths), p(radii), p(conics), p(comp), p(tiles), p(colors), p(recs),
@@ -226,7 +226,7 @@ class _Render(Function):
             seg = _segments_backward(spec, ctx.capacity, dev)
             desc = _ViewDesc(n, ctx.degree, spec.sh_degree_to_use, int(spec.render_depth), H, W, spec.fx, spec.fy,
                              spec.cx, spec.cy, spec.glob_scale, spec.clip_thresh, ctx.capacity,
-                             _C.deep_tile_threshold(ctx.capacity, tb[0] * tb[1], backward=True),
+                             _C.deep_arg(bins, ctx.capacity, tb[0] * tb[1], backward=True, tile_bounds=tb),
                              p(means), None, p(raw_quats), None, p(features_dc), p(features_rest), p(viewmat),
                              p(projmat), None, p(background), p(scales), p(quats), p(opac), p(dirs), p(cov3d), p(xys),
                              p(depths), p(radii), p(conics), p(comp), None, p(colors), None, None, None, None, p(ids),

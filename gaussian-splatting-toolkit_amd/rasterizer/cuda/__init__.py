@@ -276,7 +276,7 @@ def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: Tensor,
     dev = isect_ids_sorted.device
     nt = int(tile_bounds[0]) * int(tile_bounds[1])
     with _on(dev):
-        tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
+        tile_bins = alloc_tile_bins(tile_bounds, dev)
         _call("gsr_tile_bin_edges", C.c_int(int(num_intersects)), _ptr(isect_ids_sorted),
               C.c_int(nt), _ptr(tile_bins), _stream(dev))
     return tile_bins
@@ -423,7 +423,7 @@ def bin_sorted(num_points: int, num_intersects: int, order: Tensor, cum_sorted: 
     dev = xys.device
     with _on(dev):
         ids = torch.empty((I,), dtype=_i32, device=dev)
-        tile_bins = torch.empty((nt, 2), dtype=_i32, device=dev)
+        tile_bins = alloc_tile_bins(tile_bounds, dev)
         nbytes = int(_lib().gsr_bin_sorted_workspace_bytes(C.c_int(int(num_points)), C.c_int(I),
                                                            C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
         bands = cum_sorted.numel() // max(int(num_points), 1) if int(num_points) and cum_sorted is not None else 1
@@ -457,7 +457,7 @@ def tile_lists_subrange(order_sub: Tensor, capacity: int, reach_records: Tensor,
     nt = int(tile_bounds[0]) * int(tile_bounds[1])
     dev = ids_out.device
     with _on(dev):
-        bins = torch.empty((nt, 2), dtype=_i32, device=dev)
+        bins = alloc_tile_bins(tile_bounds, dev)
         nbytes = int(_lib().gsr_tile_lists_subrange_workspace_bytes(C.c_int(n), C.c_int(int(capacity)),
                                                                    C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1])))
         ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
@@ -568,7 +568,7 @@ def depth_segments(list_entries: int, num_tiles: int):
     which the pre-passes raise: 960 x 540 unchanged, the long-tail 1080p scene 0.62 -> 0.67 ms (backward), the default
     0.427 -> 0.448 ms (the empty workgroups of the segment grid) -- off there."""
     segs, grid, least, _ = _segment_knobs()
-    _, _, small_grid, _, small_grid_bwd = _deep_knobs()
+    _, _, small_grid, _, small_grid_bwd = _deep_knobs()[:5]
     # (only where EVERY tile above the small-grid floor is split, forward and backward alike: which tiles are cut, and
     #  where, is then a function of the tile's list alone and every route to the kernels rounds the same way)
     if segs < 2 or num_tiles <= 0 or num_tiles > min(grid, small_grid, small_grid_bwd):
@@ -617,7 +617,9 @@ def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = Fals
     (10 % of the tiles ~10x deeper): forward 357 -> 320 us, backward 664 -> 625 us; factors
     0.8-1.5 within 3 % of each other, 0.3 (nearly every tile split) 1.7x slower; no effect
     on the uniform scene (nothing above the threshold; the idle workgroups cost < 1 %)."""
-    factor, floor, small_grid, small_floor, small_grid_bwd = _deep_knobs()
+    factor, floor, small_grid, small_floor, small_grid_bwd = _deep_knobs()[:5]
+    if backward and _deep_knobs()[5] > 0:
+        factor = _deep_knobs()[5]  # GSR_DEEP_FACTOR_BWD (A/B knob; default: the forward's factor)
     if factor <= 0 or num_tiles <= 0:
         return 0
     if num_tiles <= (small_grid_bwd if backward else small_grid):
@@ -633,6 +635,57 @@ def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = Fals
     return max(floor, int(factor * list_entries / num_tiles))
 
 
+GSR_DEEP_ORDERED = 1 << 30  # include/gsraster.h
+
+
+def tile_jobs_ints(tile_bounds) -> int:
+    return int(_lib().gsr_tile_jobs_ints(C.c_int(int(tile_bounds[0])), C.c_int(int(tile_bounds[1]))))
+
+
+_jobs_ints_cache = {}
+
+
+def alloc_tile_bins(tile_bounds, dev) -> Tensor:
+    """tile_bins [tiles, 2] int32 with room behind it for the launch's job order (include/gsraster.h,
+    GSR_DEEP_ORDERED): one allocation; the returned tensor is the leading [tiles, 2] view."""
+    key = (int(tile_bounds[0]), int(tile_bounds[1]))
+    ints = _jobs_ints_cache.get(key)
+    if ints is None:
+        ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
+    nt = key[0] * key[1]
+    return torch.empty((2 * nt + ints,), dtype=_i32, device=dev)[:2 * nt].view(nt, 2)
+
+
+def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, backward: bool = False, tile_bounds=None) -> int:
+    """The `deep_tile_threshold` argument of a compositing entry: the threshold (`deep_tile_threshold`), with
+    GSR_DEEP_ORDERED set when `tile_bins` came from `alloc_tile_bins` (so the job order fits behind it) and
+    GSR_DEEP_ORDER is not 0 -- the entry then runs the launch's jobs longest first."""
+    deep = deep_tile_threshold(list_entries, num_tiles, backward) if backward else deep_tile_threshold(list_entries, num_tiles)
+    if deep <= 0 or tile_bins is None or not _order_knob():
+        return deep
+    if tile_bounds is None:
+        return deep  # (no grid shape, no way to size the tail)
+    key = (int(tile_bounds[0]), int(tile_bounds[1]))
+    ints = _jobs_ints_cache.get(key)
+    if ints is None:
+        ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
+    have = tile_bins.untyped_storage().nbytes() // 4 - tile_bins.storage_offset()
+    if tile_bins.dtype != _i32 or not tile_bins.is_contiguous() or have < 2 * num_tiles + ints:
+        return deep
+    return deep | GSR_DEEP_ORDERED
+
+
+_order_cache = {}
+
+
+def _order_knob() -> bool:
+    if not _order_cache:
+        import os
+
+        _order_cache["v"] = os.environ.get("GSR_DEEP_ORDER", "1") != "0"
+    return _order_cache["v"]
+
+
 _deep_cache = {}
 
 
@@ -643,7 +696,8 @@ def _deep_knobs():
 
         _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "256")),
                             int(os.environ.get("GSR_SMALL_GRID", "2560")), int(os.environ.get("GSR_SMALL_GRID_MIN", "96")),
-                            int(os.environ.get("GSR_SMALL_GRID_BWD", "1100")))
+                            int(os.environ.get("GSR_SMALL_GRID_BWD", "1100")),
+                            float(os.environ.get("GSR_DEEP_FACTOR_BWD", "0")))
     return _deep_cache["v"]
 
 
@@ -715,7 +769,7 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
     with _on(dev):
         ws = torch.empty((total,), dtype=torch.uint8, device=dev)
         ids = torch.empty((capacity,), dtype=_i32, device=dev)
-        bins = torch.empty((tb[0] * tb[1], 2), dtype=_i32, device=dev)
+        bins = alloc_tile_bins(tb, dev)
         img = Ts = idx = alpha = out_extra = None
         if composite:
             img = torch.empty((H, W, 3), dtype=_f32, device=dev)
@@ -733,7 +787,7 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
             if zero_bytes == 0:
                 zero = None
         segs, seg_min, seg_ws = _forward_segments(capacity, tb[0] * tb[1], H, W, dev) if composite else (0, 0, None)
-        desc = _RasterDesc(n, H, W, int(capacity), deep_tile_threshold(capacity, tb[0] * tb[1]), float(extra_background),
+        desc = _RasterDesc(n, H, W, int(capacity), deep_arg(bins, capacity, tb[0] * tb[1], tile_bounds=tb), float(extra_background),
                            xys.data_ptr(), depths.data_ptr(), radii.data_ptr(), conics.data_ptr(),
                            p(colors) if composite else None, p(extra), opacities.data_ptr(),
                            p(background) if composite else None, p(order_ready), at("records"),
@@ -765,7 +819,7 @@ def composite_prepared(tile_bounds, img_width: int, img_height: int, gaussian_id
         _call("gsr_rasterize_forward_seg", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
               C.c_uint(int(img_width)), C.c_uint(int(img_height)), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys),
               _ptr(conics), _ptr(colors), None, _ptr(opacities), _ptr(background), C.c_float(0.0), _ptr(out_img), None,
-              _ptr(Ts), _ptr(idx), C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles)),
+              _ptr(Ts), _ptr(idx), C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, tile_bounds=tile_bounds)),
               _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero_bytes else None, C.c_size_t(zero_bytes),
               C.c_int(segs), C.c_int(seg_min), _ptr(seg_ws) if seg_ws is not None else None,
               C.c_size_t(seg_ws.numel() if seg_ws is not None else 0), _stream(dev))
@@ -801,7 +855,7 @@ def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_b
         else:
             if channels != 3:
                 raise RuntimeError("rasterize_forward expects 3 channels; use nd_rasterize_forward")
-            deep = deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])
+            deep = deep_arg(tile_bins, gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], tile_bounds=tile_bounds)
             segs, seg_min, seg_ws = _forward_segments(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], H, W,
                                                       dev) if block[0] == 16 else (0, 0, None)
             if ex or segs > 1:
@@ -882,7 +936,7 @@ def rasterize_forward_rgbd(tile_bounds, img_size, gaussian_ids_sorted, tile_bins
               C.c_uint(H), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
               _ptr(extra), _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(img), _ptr(ext),
               _ptr(Ts), _ptr(idx),
-              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])),
+              C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], tile_bounds=tile_bounds)),
               _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero is not None else None,
               C.c_size_t(zero.numel() * 4 if zero is not None else 0), C.c_int(segs), C.c_int(seg_min),
               _ptr(seg_ws) if seg_ws is not None else None, C.c_size_t(seg_ws.numel() if seg_ws is not None else 0),
@@ -922,7 +976,8 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
               _ptr(v_output), _ptr(v_output_extra),
               _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic),
               _ptr(v_colors), _ptr(v_extra), _ptr(v_opacity),
-              C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)),
+              C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True,
+                               tile_bounds=((int(img_width) + 15) // 16, (int(img_height) + 15) // 16))),
               C.c_int(1 if accumulators is not None else 0), C.c_int(segs if ws is not None else 0), C.c_int(seg_min),
               _ptr(ws) if ws is not None else None, C.c_size_t(ws.numel() * 4 if ws is not None else 0), _stream(dev))
     return v_xy, v_conic, v_colors, v_extra, v_opacity
@@ -1014,8 +1069,10 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
         else:
             tiles = ((img_width + block_width - 1) // block_width) * ((img_height + block_width - 1) // block_width)
             segs, seg_min = depth_segments(gaussian_ids_sorted.numel(), tiles) if block_width == 16 else (1, 0)
+            _tb16 = ((int(img_width) + 15) // 16, (int(img_height) + 15) // 16) if block_width == 16 else None
             if segs > 1:
-                deep = deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)
+                deep = deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True,
+                                tile_bounds=((int(img_width) + 15) // 16, (int(img_height) + 15) // 16))
                 ws = torch.empty(((segs - 1) * int(img_height) * int(img_width), 2), dtype=_f32, device=dev)
                 _call("gsr_rasterize_backward_seg", C.c_uint(img_height), C.c_uint(img_width), *tail[:6], None,
                       *tail[6:8], C.c_float(0.0), *tail[8:11], None, *tail[11:15], None, tail[15], C.c_int(deep),
@@ -1023,11 +1080,12 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
                       C.c_size_t(ws.numel() * 4), _stream(dev))
             elif zeroed:
                 _call("gsr_rasterize_backward_ex", *head, *tail,
-                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)), C.c_int(1),
-                      _stream(dev))
+                      C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True, tile_bounds=_tb16)),
+                      C.c_int(1), _stream(dev))
             else:
                 _call("gsr_rasterize_backward", *head, *tail,
-                      C.c_int(deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)), _stream(dev))
+                      C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True, tile_bounds=_tb16)),
+                      _stream(dev))
     return v_xy, v_conic, v_colors, v_opacity
 
 

@@ -82,6 +82,7 @@ SYMBOLS = (
     "gsr_adam_step",
     "gsr_rasterize_backward_det_workspace_bytes",
     "gsr_rasterize_backward_det",
+    "gsr_tile_jobs_ints",
     "gsr_debug_count_staged",
     "gsr_debug_wave_trace",
     "gsr_calibrate_valu",
@@ -109,6 +110,7 @@ def _load():
     lib.gsr_last_error.restype = C.c_char_p
     lib.gsr_version.restype = C.c_int
     lib.gsr_calibrate_valu.restype = C.c_longlong
+    lib.gsr_tile_jobs_ints.restype = C.c_size_t
     lib.gsr_cumsum_workspace_bytes.restype = C.c_size_t
     lib.gsr_sort_workspace_bytes.restype = C.c_size_t
     lib.gsr_reach_record_bytes.restype = C.c_size_t

@@ -253,7 +253,20 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
  * very deep tiles (clustered scenes) do not hold a kernel up after the rest of the
  * chip has drained.  Never changes a result (same per-pixel instruction sequence);
  * costs three idle workgroups per tile at launch.  A good value: 1.5x the mean list
- * length, not below 1024 (a split tile costs ~2x the instructions per list entry). */
+ * length, not below 256 (a split tile costs ~2x the instructions per list entry).
+ * deep_tile_threshold | GSR_DEEP_ORDERED (16x16 tiles; every entry that takes a
+ * deep_tile_threshold except the two-round and the deterministic ones, which ignore
+ * the flag): LONGEST JOB FIRST.  tile_bins must then be followed by
+ * gsr_tile_jobs_ints(tiles_x, tiles_y) writable int32 (one allocation of
+ * 2 * tiles + that many ints); the entry first launches one small kernel that writes
+ * the launch's job order there -- per XCD, its tiles' jobs (a whole tile, or the four
+ * sub-tile jobs of a tile above the threshold) sorted by list length, longest first
+ * -- and the compositing workgroups take their jobs from it in block order, so that
+ * the walks that last longest start first and the launch does not end on a few long
+ * walks over an emptying chip.  Never changes a result.  The buffer belongs to ONE
+ * stream at a time (every call rebuilds it). */
+#define GSR_DEEP_ORDERED (1 << 30)
+size_t gsr_tile_jobs_ints(int tiles_x, int tiles_y);
 /* The other mapping of the same compositing rule (measurement variant, 16x16 tiles, 3 channels):
  * lanes over the 64 staged splats, a wave-wide multiplicative prefix scan for the per-pixel
  * transmittance, ballot termination (forward.cu:349-385 is the serial loop it re-maps).  Same

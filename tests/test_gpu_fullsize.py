@@ -52,7 +52,17 @@ WITHIN_FLOOR = 0.999  # share of ALL visible Gaussians within 1e-3 relative outr
 STABLE_VISIBLE_FLOOR = 0.049  # measured 0.0547 (9 876 of 180 416 visible Gaussians), round 3
 
 
-def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0):
+FLIPPED_PIXELS = 4.0  # how many peak-pixel-equivalents of a Gaussian's terms a legitimately flipped decision may move
+
+
+def peak_pixel_share(conics):
+    """Share of a splat's summed per-pixel weight that its PEAK pixel carries: 1 / (2 pi sigma_x sigma_y) in px^2
+    = sqrt(det conic) / (2 pi) (the conic is the inverse 2-D covariance), at most 1."""
+    det = np.maximum(conics[:, 0].astype(np.float64) * conics[:, 2] - conics[:, 1].astype(np.float64) ** 2, 0.0)
+    return np.minimum(1.0, np.sqrt(det) / (2.0 * np.pi))
+
+
+def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, peak_share=None):
     """Per-Gaussian gradients are sums over up to ~1e4 pixels with heavy cancellation.
       * STABLE Gaussians (see `stable_gaussians`): north_star's bar, |err| <= 1e-3 |ref|
         elementwise, with |ref| floored at 1e-4 max|ref| (elements that cancel to ~0);
@@ -67,8 +77,18 @@ def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0):
     if abs_sum is not None:
         bound = 1e-3 * np.abs(ref) + 5e-4 * abs_sum
         ratio = err / np.maximum(bound, 1e-30)
-        assert (ratio > 1).mean() <= 1e-4 and ratio.max() < worst_cap, (
-            f"{name}: {(ratio > 1).sum()} elements exceed 1e-3|ref| + 5e-4*abs_sum (worst {ratio.max():.2f}x)")
+        assert (ratio > 1).mean() <= 1e-4, f"{name}: {(ratio > 1).sum()} elements exceed 1e-3|ref| + 5e-4*abs_sum"
+        if peak_share is None:
+            assert ratio.max() < worst_cap, f"{name}: worst element {ratio.max():.2f}x the bound"
+        else:
+            # no constant: a flipped decision moves an element by that pixel's term, at most the share of abs_sum the
+            # splat's peak pixel carries (its footprint decides: 0.1 % for a 30-px splat, 4 % at sigma = 2 px) --
+            # FLIPPED_PIXELS such pixels' worth on top of the bound, for EVERY element
+            share = peak_share.reshape((-1,) + (1,) * (err.ndim - 1))
+            outer = bound + FLIPPED_PIXELS * share * abs_sum
+            worst = float((err / np.maximum(outer, 1e-30)).max())
+            print(f"{name}: worst unstable element {ratio.max():.1f}x the tight bound, {worst:.3f} of the footprint bound")
+            assert worst <= 1.0, f"{name}: an element is off by more than {FLIPPED_PIXELS} peak pixels' terms ({worst:.2f}x)"
     assert err.max() <= 1e-3 * np.abs(ref).max(), f"{name}: max abs err {err.max():.3e} vs max|ref| {np.abs(ref).max():.3e}"
     l2 = np.linalg.norm(mine - ref) / max(np.linalg.norm(ref), 1e-30)
     assert l2 <= 1e-4, f"{name}: L2 relative error {l2:.3e}"
@@ -89,8 +109,10 @@ def test_bench_default_1m_sh3_vs_oracle():
     """The TIMED workload itself against the oracle, with config 2's assertions: projection bit-identical, image and
     alpha within 1e-4 on decision-stable pixels, every parameter's gradient within 1e-3 (forward.cu:278-395,
     backward.cu:133-303).  bench.py reports the same comparison in its line (`parity_vs_oracle`)."""
-    # (the cap on the worst decision-UNSTABLE element -- a pixel's discrete decision may legitimately differ there --
-    # was calibrated on config 2's 0.4 M elements; five times as many draw a longer tail: 25.5 x seen, run to run)
+    # The worst decision-UNSTABLE element is no longer held to a constant multiple of the tight bound (20 x on config 2,
+    # raised to 60 x here in round 4 when 25.5 x was seen: VERDICT r4, weak 1b) but to what a flipped decision CAN move:
+    # `grad_close(peak_share=...)` bounds every element by the tight bound + FLIPPED_PIXELS peak pixels' worth of the
+    # Gaussian's own terms, from its footprint.  (`worst_cap` only applies where no footprint is passed.)
     _forward_backward_vs_oracle(1_000_000, 0.0025, 0.025, STABLE_VISIBLE_FLOOR_1M, "bench_default_stable_fraction.json", 60.0)
 
 
@@ -176,8 +198,10 @@ def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file
         pass
     assert frac > stable_floor, report
     assert ok_xy.mean() > WITHIN_FLOOR and ok_op.mean() > WITHIN_FLOOR, report
-    grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable, worst_cap=worst_cap)
-    grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable, worst_cap=worst_cap)
+    share = peak_pixel_share(gc)
+    grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable, worst_cap=worst_cap, peak_share=share)
+    grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable, worst_cap=worst_cap,
+               peak_share=share)
     vsh = O.compute_sh_backward(n, deg, deg, dirs, (vcol * (sh + 0.5 > 0)).astype(np.float32))
     grad_close(npy(params["sh_coeffs"].grad), vsh, name="sh_coeffs", stable=stable)
     zeros = np.zeros(n, np.float32)
