@@ -108,9 +108,13 @@ __device__ __forceinline__ bool gsr_cov2d_bounds(float c0, float c1, float c2,
 
 // deep_tile_threshold carries one flag bit besides the threshold (include/gsraster.h, GSR_DEEP_ORDERED): the buffer
 // behind tile_bins holds the launch's JOB ORDER (raster_common.h), built by the entry point itself.
-#define GSR_DEEP_FLAGS GSR_DEEP_ORDERED
-__host__ __device__ __forceinline__ int gsr_deep_threshold(int v) { return v > 0 ? (v & ~GSR_DEEP_FLAGS) : 0; }
+// bits 0-23: the threshold; bits 24-29: with GSR_DEEP_ORDERED, the share (in 1/64ths) of the launch's whole-tile jobs
+// that run LAST and are cut into four sub-tile jobs whatever their length (GSR_DEEP_TAIL_64THS): finer work to fill
+// the launch's drain; bit 30: GSR_DEEP_ORDERED.
+#define GSR_DEEP_THRESHOLD_MASK 0xFFFFFF
+__host__ __device__ __forceinline__ int gsr_deep_threshold(int v) { return v > 0 ? (v & GSR_DEEP_THRESHOLD_MASK) : 0; }
 __host__ __device__ __forceinline__ bool gsr_deep_ordered(int v) { return v > 0 && (v & GSR_DEEP_ORDERED) != 0; }
+__host__ __device__ __forceinline__ int gsr_deep_tail64(int v) { return gsr_deep_ordered(v) ? ((v >> 24) & 63) : 0; }
 
 // XCD-aware workgroup -> tile remap.  Workgroup b is dispatched to XCD b % 8
 // (observed, used for speed only).  The tile grid is cut into blocks of 8 x 4 tiles

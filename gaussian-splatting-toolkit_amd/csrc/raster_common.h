@@ -152,15 +152,22 @@ __device__ __forceinline__ int job_bucket(const int key) {  // larger keys -> sm
   const int half = ((unsigned long long)key * (unsigned)key) >> (2 * k + 1);  // key^2 >= 2^(2k+1)  <=>  key >= 2^k sqrt 2
   return max(0, kJobBuckets - 2 - (2 * k + (half ? 1 : 0)));
 }
+// tail64 > 0: the last tail64 / 64 of this XCD's whole-tile jobs (the shortest ones; on a scene whose lists are all
+// alike simply the last ones) are cut into four sub-tile jobs each and run behind everything else: a launch of N
+// equal jobs on S slots ends with a drain of one job's length over which the chip empties (wave_trace.py: the last
+// 20 % of the uniform scene's backward runs below 1.6 waves per SIMD, where a SIMD no longer saturates its VALU);
+// quarter-length jobs at the end shorten it.
 static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_x, const int tiles_y,
                                                                 const unsigned base_grid,
                                                                 const int2 *__restrict__ tile_bins,
-                                                                const int deep_threshold, int *__restrict__ jobs) {
+                                                                const int deep_threshold, const int tail64,
+                                                                int *__restrict__ jobs) {
   __shared__ int hist[kJobBuckets];
-  __shared__ int total_s;
+  __shared__ int histw[kJobBuckets];  // whole-tile jobs only: their rank among themselves
+  __shared__ int total_s, whole_s;
   const unsigned xcd = blockIdx.x, slots = base_grid / 8u;
   const int tid = threadIdx.x;
-  if (tid < kJobBuckets) hist[tid] = 0;
+  if (tid < kJobBuckets) hist[tid] = histw[tid] = 0;
   __syncthreads();
   // pass 1: histogram
   for (unsigned s = tid; s < slots; s += 1024) {
@@ -168,23 +175,32 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
     if (tile < 0) continue;
     const int2 r = tile_bins[tile];
     const int len = r.y - r.x;
-    if (deep_threshold > 0 && len > deep_threshold) atomicAdd(&hist[job_bucket(len >> 2)], 4);
-    else atomicAdd(&hist[job_bucket(len)], 1);
+    if (deep_threshold > 0 && len > deep_threshold) {
+      atomicAdd(&hist[job_bucket(len >> 2)], 4);
+    } else {
+      atomicAdd(&hist[job_bucket(len)], 1);
+      atomicAdd(&histw[job_bucket(len)], 1);
+    }
   }
   __syncthreads();
-  if (tid < 64) {  // exclusive scan of the 64 buckets by one wave
-    const int v = hist[tid];
-    int incl = v;
+  if (tid < 64) {  // exclusive scans of the 64 buckets by one wave
+    const int v = hist[tid], w = histw[tid];
+    int incl = v, inclw = w;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if (tid >= o) incl += t;
+      const int t = __shfl_up(incl, o), u = __shfl_up(inclw, o);
+      if (tid >= o) incl += t, inclw += u;
     }
     hist[tid] = incl - v;
-    if (tid == 63) total_s = incl;
+    histw[tid] = inclw - w;
+    if (tid == 63) total_s = incl, whole_s = inclw;
   }
   __syncthreads();
-  const int total = total_s;
+  const int total = total_s, whole = whole_s;
+  // the whole-tile jobs ranked [whole - n_tail, whole) among themselves leave the order and come back as four sub-tile
+  // jobs each behind it (as many as the 4 base_grid slots leave room for)
+  const int n_tail = min((int)(((long long)whole * tail64) >> 6), max(0, (int)(4u * slots) - total) / 4);
+  const int tail_first = whole - n_tail;
   // pass 2: scatter (lanes of a wave land in lane order: 64 consecutive slots stay together inside a bucket)
   for (unsigned s = tid; s < slots; s += 1024) {
     const int tile = gsr_xcd_remap(s * 8u + xcd, tiles_x, tiles_y);
@@ -197,10 +213,23 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
       for (int p = 0; p < 4; ++p) jobs[(size_t)(at + p) * 8u + xcd] = tile | ((1 << p) << kJobTileBits);
     } else {
       const int at = atomicAdd(&hist[job_bucket(len)], 1);
-      jobs[(size_t)at * 8u + xcd] = tile | (15 << kJobTileBits);
+      const int rank = n_tail > 0 ? atomicAdd(&histw[job_bucket(len)], 1) : 0;
+      if (n_tail > 0 && rank >= tail_first && len > 0) {
+        jobs[(size_t)at * 8u + xcd] = -1;
+        const int t0 = total + 4 * (rank - tail_first);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) jobs[(size_t)(t0 + p) * 8u + xcd] = tile | ((1 << p) << kJobTileBits);
+      } else {
+        jobs[(size_t)at * 8u + xcd] = tile | (15 << kJobTileBits);
+        if (n_tail > 0 && rank >= tail_first) {  // (an empty tile in the tail: stays whole, its four slots stay empty)
+          const int t0 = total + 4 * (rank - tail_first);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) jobs[(size_t)(t0 + p) * 8u + xcd] = -1;
+        }
+      }
     }
   }
-  for (unsigned s = total + tid; s < 4u * slots; s += 1024) jobs[(size_t)s * 8u + xcd] = -1;
+  for (unsigned s = total + 4 * n_tail + tid; s < 4u * slots; s += 1024) jobs[(size_t)s * 8u + xcd] = -1;
 }
 
 // (host) build the job order behind tile_bins when deep_arg asks for it; -> the argument the kernels take
@@ -210,7 +239,8 @@ static inline int gsr_prepare_jobs(const int deep_arg, const int tiles_x, const 
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
   int *jobs = const_cast<int *>(tile_bins) + 2 * (size_t)tiles_x * tiles_y;
   hipLaunchKernelGGL(tile_jobs_kernel, dim3(8), dim3(1024), 0, s, tiles_x, tiles_y, base,
-                     reinterpret_cast<const int2 *>(tile_bins), gsr_deep_threshold(deep_arg), jobs);
+                     reinterpret_cast<const int2 *>(tile_bins), gsr_deep_threshold(deep_arg), gsr_deep_tail64(deep_arg),
+                     jobs);
   return deep_arg;
 }
 

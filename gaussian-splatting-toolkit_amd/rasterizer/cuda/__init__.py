@@ -672,7 +672,7 @@ def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, bac
     have = tile_bins.untyped_storage().nbytes() // 4 - tile_bins.storage_offset()
     if tile_bins.dtype != _i32 or not tile_bins.is_contiguous() or have < 2 * num_tiles + ints:
         return deep
-    return deep | GSR_DEEP_ORDERED
+    return min(deep, 0xFFFFFF) | GSR_DEEP_ORDERED | (_order_cache["tail"] << 24)
 
 
 _order_cache = {}
@@ -683,6 +683,8 @@ def _order_knob() -> bool:
         import os
 
         _order_cache["v"] = os.environ.get("GSR_DEEP_ORDER", "1") != "0"
+        # the share (in 1/64ths) of a launch's whole-tile jobs that run last as four sub-tile jobs each (csrc/raster_common.h)
+        _order_cache["tail"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL", "0"))))
     return _order_cache["v"]
 
 

@@ -264,8 +264,13 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
  * -- and the compositing workgroups take their jobs from it in block order, so that
  * the walks that last longest start first and the launch does not end on a few long
  * walks over an emptying chip.  Never changes a result.  The buffer belongs to ONE
- * stream at a time (every call rebuilds it). */
+ * stream at a time (every call rebuilds it).
+ * With GSR_DEEP_ORDERED, bits 24-29 of the argument (GSR_DEEP_TAIL_64THS(k), k = 0..63)
+ * ask that the last k / 64 of the launch's whole-tile jobs -- the shortest -- run as
+ * four sub-tile jobs each behind everything else, whatever their length: quarter-length
+ * jobs to fill the launch's drain.  The threshold itself occupies bits 0-23. */
 #define GSR_DEEP_ORDERED (1 << 30)
+#define GSR_DEEP_TAIL_64THS(k) (((k) & 63) << 24)
 size_t gsr_tile_jobs_ints(int tiles_x, int tiles_y);
 /* The other mapping of the same compositing rule (measurement variant, 16x16 tiles, 3 channels):
  * lanes over the 64 staged splats, a wave-wide multiplicative prefix scan for the per-pixel
