@@ -112,7 +112,7 @@ __device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned bas
   const int deep_threshold = gsr_deep_threshold(deep_arg);
   if (gsr_deep_ordered(deep_arg)) {
     const int code = reinterpret_cast<const int *>(tile_bins + (size_t)tiles_x * tiles_y)[b];
-    if (code < 0) return j;
+    if (code < 0 || (code & ((1 << kJobTileBits) - 1)) >= tiles_x * tiles_y) return j;  // (none / not a job order)
     j.tile = code & ((1 << kJobTileBits) - 1);
     j.allowed = code >> kJobTileBits;
     range = tile_bins[j.tile];
@@ -155,45 +155,95 @@ __device__ __forceinline__ int job_bucket(const int key) {  // larger keys -> sm
 // tail64 > 0: the last tail64 / 64 of this XCD's whole-tile jobs (the shortest ones; on a scene whose lists are all
 // alike simply the last ones) are cut into four sub-tile jobs each and run behind everything else: a launch of N
 // equal jobs on S slots ends with a drain of one job's length over which the chip empties (wave_trace.py: the last
-// 20 % of the uniform scene's backward runs below 1.6 waves per SIMD, where a SIMD no longer saturates its VALU);
-// quarter-length jobs at the end shorten it.
+// 20 % of the uniform scene's launches run below 1.6 waves per SIMD, where a SIMD no longer saturates its VALU);
+// quarter-length jobs at the end shorten it.  (Forward only by default: a split tile costs the backward 1.7 x the
+// instructions -- the butterfly per sub-tile wave -- and it loses what the drain gains.)
+// The sort is STABLE and deterministic: inside a bucket the jobs keep the static map's order (ranks by wave-wide key
+// matching, a per-(wave chunk, bucket) table, one prefix down the chunks) -- spatial neighbours stay neighbours in time.
+constexpr int kJobChunks = 64;  // wave chunks of 64 slots per XCD: up to 4 096 tiles per XCD (32 768 tiles: 8K x 4K)
 static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_x, const int tiles_y,
                                                                 const unsigned base_grid,
                                                                 const int2 *__restrict__ tile_bins,
                                                                 const int deep_threshold, const int tail64,
                                                                 int *__restrict__ jobs) {
-  __shared__ int hist[kJobBuckets];
-  __shared__ int histw[kJobBuckets];  // whole-tile jobs only: their rank among themselves
+  // bucket-major tables: a wave scans one bucket's chunks with its lanes (conflict-free rows)
+  __shared__ int cnt[kJobBuckets][kJobChunks];   // slots taken by chunk c's jobs of bucket q -> their offset in the bucket
+  __shared__ int cntw[kJobBuckets][kJobChunks];  // the same for whole-tile jobs only (their rank among themselves)
+  __shared__ int tot[kJobBuckets], totw[kJobBuckets];
   __shared__ int total_s, whole_s;
   const unsigned xcd = blockIdx.x, slots = base_grid / 8u;
-  const int tid = threadIdx.x;
-  if (tid < kJobBuckets) hist[tid] = histw[tid] = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nchunks = (int)((slots + 63u) >> 6);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int i = tid; i < kJobBuckets * nchunks; i += 1024) {
+    cnt[i / nchunks][i % nchunks] = 0;
+    cntw[i / nchunks][i % nchunks] = 0;
+  }
+  // one item per slot: bucket, weight (4 = a split tile's four jobs), and the lanes of its wave chunk that share its bucket
+  auto item = [&](const unsigned s, int &tile, int &len, int &q, int &weight, unsigned long long &same,
+                  unsigned long long &four) {
+    tile = s < slots ? gsr_xcd_remap(s * 8u + xcd, tiles_x, tiles_y) : -1;
+    len = 0;
+    if (tile >= 0) {
+      const int2 r = tile_bins[tile];
+      len = r.y - r.x;
+    }
+    const bool split = tile >= 0 && deep_threshold > 0 && len > deep_threshold;
+    weight = tile < 0 ? 0 : (split ? 4 : 1);
+    q = tile < 0 ? kJobBuckets - 1 : job_bucket(split ? len >> 2 : len);
+    same = __ballot(tile >= 0);
+#pragma unroll
+    for (int bit = 0; bit < 6; ++bit) {
+      const unsigned long long b = __ballot((q >> bit) & 1);
+      same &= ((q >> bit) & 1) ? b : ~b;
+    }
+    four = __ballot(weight == 4) & same;
+  };
+  const unsigned rounds = (slots + 1023u) / 1024u;
+  int tile0, len0, q0, weight0;  // round 0's item stays in registers (the only round up to 8 192 tiles)
+  unsigned long long same0, four0;
+  item(tid, tile0, len0, q0, weight0, same0, four0);
   __syncthreads();
-  // pass 1: histogram
-  for (unsigned s = tid; s < slots; s += 1024) {
-    const int tile = gsr_xcd_remap(s * 8u + xcd, tiles_x, tiles_y);
-    if (tile < 0) continue;
-    const int2 r = tile_bins[tile];
-    const int len = r.y - r.x;
-    if (deep_threshold > 0 && len > deep_threshold) {
-      atomicAdd(&hist[job_bucket(len >> 2)], 4);
-    } else {
-      atomicAdd(&hist[job_bucket(len)], 1);
-      atomicAdd(&histw[job_bucket(len)], 1);
+  // pass 1: per (bucket, chunk) slot counts
+  for (unsigned it = 0; it < rounds; ++it) {
+    const unsigned s = it * 1024u + tid;
+    const int c = (int)(s >> 6);
+    int tile = tile0, len = len0, q = q0, weight = weight0;
+    unsigned long long same = same0, four = four0;
+    if (it) item(s, tile, len, q, weight, same, four);
+    if (tile >= 0 && (same & below) == 0) {  // the first lane of its bucket in this chunk
+      cnt[q][c] = __popcll(same) + 3 * __popcll(four);
+      cntw[q][c] = __popcll(same & ~four);
     }
   }
   __syncthreads();
-  if (tid < 64) {  // exclusive scans of the 64 buckets by one wave
-    const int v = hist[tid], w = histw[tid];
+  // exclusive prefix down the chunks of every bucket: wave w takes buckets w, w + 16, ...; lane = chunk
+  for (int q = wave; q < kJobBuckets; q += 16) {
+    const int v = lane < nchunks ? cnt[q][lane] : 0, w = lane < nchunks ? cntw[q][lane] : 0;
+    int incl = v, inclw = w;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o), u = __shfl_up(inclw, o);
+      if (lane >= o) incl += t, inclw += u;
+    }
+    if (lane < nchunks) {
+      cnt[q][lane] = incl - v;
+      cntw[q][lane] = inclw - w;
+    }
+    if (lane == 63) tot[q] = incl, totw[q] = inclw;
+  }
+  __syncthreads();
+  if (tid < kJobBuckets) {  // ... and over the buckets (one wave; lane = bucket)
+    const int v = tot[tid], w = totw[tid];
     int incl = v, inclw = w;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int t = __shfl_up(incl, o), u = __shfl_up(inclw, o);
       if (tid >= o) incl += t, inclw += u;
     }
-    hist[tid] = incl - v;
-    histw[tid] = inclw - w;
-    if (tid == 63) total_s = incl, whole_s = inclw;
+    tot[tid] = incl - v;
+    totw[tid] = inclw - w;
+    if (tid == kJobBuckets - 1) total_s = incl, whole_s = inclw;
   }
   __syncthreads();
   const int total = total_s, whole = whole_s;
@@ -201,31 +251,33 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
   // jobs each behind it (as many as the 4 base_grid slots leave room for)
   const int n_tail = min((int)(((long long)whole * tail64) >> 6), max(0, (int)(4u * slots) - total) / 4);
   const int tail_first = whole - n_tail;
-  // pass 2: scatter (lanes of a wave land in lane order: 64 consecutive slots stay together inside a bucket)
-  for (unsigned s = tid; s < slots; s += 1024) {
-    const int tile = gsr_xcd_remap(s * 8u + xcd, tiles_x, tiles_y);
+  // pass 2: every job to its slot
+  for (unsigned it = 0; it < rounds; ++it) {
+    const unsigned s = it * 1024u + tid;
+    const int c = (int)(s >> 6);
+    int tile = tile0, len = len0, q = q0, weight = weight0;
+    unsigned long long same = same0, four = four0;
+    if (it) item(s, tile, len, q, weight, same, four);
     if (tile < 0) continue;
-    const int2 r = tile_bins[tile];
-    const int len = r.y - r.x;
-    if (deep_threshold > 0 && len > deep_threshold) {
-      const int at = atomicAdd(&hist[job_bucket(len >> 2)], 4);
+    const unsigned long long before = same & below;
+    const int at = tot[q] + cnt[q][c] + __popcll(before) + 3 * __popcll(before & four);
+    if (weight == 4) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) jobs[(size_t)(at + p) * 8u + xcd] = tile | ((1 << p) << kJobTileBits);
+      continue;
+    }
+    const int rank = totw[q] + cntw[q][c] + __popcll(before & ~four);
+    const bool in_tail = n_tail > 0 && rank >= tail_first;
+    if (in_tail && len > 0) {
+      jobs[(size_t)at * 8u + xcd] = -1;
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        jobs[(size_t)(total + 4 * (rank - tail_first) + p) * 8u + xcd] = tile | ((1 << p) << kJobTileBits);
     } else {
-      const int at = atomicAdd(&hist[job_bucket(len)], 1);
-      const int rank = n_tail > 0 ? atomicAdd(&histw[job_bucket(len)], 1) : 0;
-      if (n_tail > 0 && rank >= tail_first && len > 0) {
-        jobs[(size_t)at * 8u + xcd] = -1;
-        const int t0 = total + 4 * (rank - tail_first);
+      jobs[(size_t)at * 8u + xcd] = tile | (15 << kJobTileBits);
+      if (in_tail) {  // (an empty tile in the tail stays whole: its four tail slots stay empty)
 #pragma unroll
-        for (int p = 0; p < 4; ++p) jobs[(size_t)(t0 + p) * 8u + xcd] = tile | ((1 << p) << kJobTileBits);
-      } else {
-        jobs[(size_t)at * 8u + xcd] = tile | (15 << kJobTileBits);
-        if (n_tail > 0 && rank >= tail_first) {  // (an empty tile in the tail: stays whole, its four slots stay empty)
-          const int t0 = total + 4 * (rank - tail_first);
-#pragma unroll
-          for (int p = 0; p < 4; ++p) jobs[(size_t)(t0 + p) * 8u + xcd] = -1;
-        }
+        for (int p = 0; p < 4; ++p) jobs[(size_t)(total + 4 * (rank - tail_first) + p) * 8u + xcd] = -1;
       }
     }
   }
@@ -237,6 +289,7 @@ static inline int gsr_prepare_jobs(const int deep_arg, const int tiles_x, const 
                             hipStream_t s) {
   if (!gsr_deep_ordered(deep_arg)) return gsr_deep_threshold(deep_arg);
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  if (base / 8u > (unsigned)kJobChunks * 64u) return gsr_deep_threshold(deep_arg);  // (beyond the sort's tables: static map)
   int *jobs = const_cast<int *>(tile_bins) + 2 * (size_t)tiles_x * tiles_y;
   hipLaunchKernelGGL(tile_jobs_kernel, dim3(8), dim3(1024), 0, s, tiles_x, tiles_y, base,
                      reinterpret_cast<const int2 *>(tile_bins), gsr_deep_threshold(deep_arg), gsr_deep_tail64(deep_arg),

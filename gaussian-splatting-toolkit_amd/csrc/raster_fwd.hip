@@ -153,7 +153,11 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       if (split && inside && seg_k > 0) {  // the transmittance the runs in front of this one leave (0: finished
         // there): ONE load -- raster_fwd_segprefix_kernel has turned the runs' products into prefix products
         const size_t pixels = (size_t)img_w * img_h, pid = (size_t)row * img_w + col;
-        T[p] = seg_tau[(size_t)(seg_k - 1) * pixels + pid];
+        // (a prefix of 0 -- the pixel finished in front of this run: raster_fwd_segprefix_kernel -- enters DEAD, with a
+        //  negative marker, so that the combine pass sees a finished pixel here even if rounding kept the run that
+        //  really finished it from noticing)
+        const float tin = seg_tau[(size_t)(seg_k - 1) * pixels + pid];
+        T[p] = tin > 0.f ? tin : -1.17549435e-38f;
       }
     }
   }
@@ -379,6 +383,11 @@ __global__ __launch_bounds__(256) void raster_fwd_segprefix_kernel(
   for (int k = 0; k + 1 < nseg; ++k) {
     float *q = seg_tau + (size_t)k * pixels + pid;
     t *= *q;
+    // The single walk never carries T <= 1e-4 (the splat that would take it there is not drawn: the pixel finishes
+    // in front of it), so a prefix that small means "finished in an earlier run" -- written as 0: the runs behind skip
+    // the pixel instead of walking it from a denormal T, and a prefix can no longer underflow into a +0 that is
+    // neither live nor finished.
+    if (t <= GSR_T_EPS) t = 0.f;
     *q = t;
   }
 }

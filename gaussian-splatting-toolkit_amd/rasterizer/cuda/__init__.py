@@ -619,7 +619,10 @@ def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = Fals
     on the uniform scene (nothing above the threshold; the idle workgroups cost < 1 %)."""
     factor, floor, small_grid, small_floor, small_grid_bwd = _deep_knobs()[:5]
     if backward and _deep_knobs()[5] > 0:
-        factor = _deep_knobs()[5]  # GSR_DEEP_FACTOR_BWD (A/B knob; default: the forward's factor)
+        # GSR_DEEP_FACTOR_BWD (2.0; 0 = the forward's factor): with the longest jobs first, the backward gains from
+        # splitting only its longest tiles (four sub-tile waves run four butterflies): trained model 0.405 (1.2) ->
+        # 0.348 ms (2.0) -> 0.40 (3.0+); long-tail scene 0.588 -> 0.559 -> 0.504 (6.0)
+        factor = _deep_knobs()[5]
     if factor <= 0 or num_tiles <= 0:
         return 0
     if num_tiles <= (small_grid_bwd if backward else small_grid):
@@ -653,26 +656,38 @@ def alloc_tile_bins(tile_bounds, dev) -> Tensor:
     if ints is None:
         ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
     nt = key[0] * key[1]
-    return torch.empty((2 * nt + ints,), dtype=_i32, device=dev)[:2 * nt].view(nt, 2)
+    bins = torch.empty((2 * nt + ints,), dtype=_i32, device=dev)[:2 * nt].view(nt, 2)
+    bins._gsr_job_tail = True
+    return bins
 
 
 def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, backward: bool = False, tile_bounds=None) -> int:
     """The `deep_tile_threshold` argument of a compositing entry: the threshold (`deep_tile_threshold`), with
-    GSR_DEEP_ORDERED set when `tile_bins` came from `alloc_tile_bins` (so the job order fits behind it) and
-    GSR_DEEP_ORDER is not 0 -- the entry then runs the launch's jobs longest first."""
+    GSR_DEEP_ORDERED set when `tile_bins` came from `alloc_tile_bins` (so the job order fits behind it), the grid
+    is not a small one and GSR_DEEP_ORDER is not 0 -- the entry then runs the launch's jobs longest first (DESIGN.md
+    section 4.18)."""
     deep = deep_tile_threshold(list_entries, num_tiles, backward) if backward else deep_tile_threshold(list_entries, num_tiles)
-    if deep <= 0 or tile_bins is None or not _order_knob():
+    if deep <= 0 or tile_bins is None or tile_bounds is None or not _order_knob():
         return deep
-    if tile_bounds is None:
-        return deep  # (no grid shape, no way to size the tail)
-    key = (int(tile_bounds[0]), int(tile_bounds[1]))
-    ints = _jobs_ints_cache.get(key)
-    if ints is None:
-        ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
-    have = tile_bins.untyped_storage().nbytes() // 4 - tile_bins.storage_offset()
-    if tile_bins.dtype != _i32 or not tile_bins.is_contiguous() or have < 2 * num_tiles + ints:
+    # small grids (every tile split, depth segments): the launch is a few hundred short jobs per run -- nothing to
+    # order, and the step is bound by the host, where one more launch costs what it costs
+    if num_tiles <= _deep_knobs()[2]:
         return deep
-    return min(deep, 0xFFFFFF) | GSR_DEEP_ORDERED | (_order_cache["tail"] << 24)
+    ok = getattr(tile_bins, "_gsr_job_tail", None)  # (decided once per tensor object)
+    if ok is None:
+        key = (int(tile_bounds[0]), int(tile_bounds[1]))
+        ints = _jobs_ints_cache.get(key)
+        if ints is None:
+            ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
+        have = tile_bins.untyped_storage().nbytes() // 4 - tile_bins.storage_offset()
+        ok = tile_bins.dtype == _i32 and tile_bins.is_contiguous() and have >= 2 * num_tiles + ints
+        try:
+            tile_bins._gsr_job_tail = ok
+        except AttributeError:
+            pass
+    if not ok:
+        return deep
+    return min(deep, 0xFFFFFF) | GSR_DEEP_ORDERED | (_order_cache["tail_bwd" if backward else "tail"] << 24)
 
 
 _order_cache = {}
@@ -684,7 +699,10 @@ def _order_knob() -> bool:
 
         _order_cache["v"] = os.environ.get("GSR_DEEP_ORDER", "1") != "0"
         # the share (in 1/64ths) of a launch's whole-tile jobs that run last as four sub-tile jobs each (csrc/raster_common.h)
-        _order_cache["tail"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL", "0"))))
+        # forward 8 / 64 (uniform bench scene: forward 0.233 -> 0.208 ms), backward 0 (a split tile costs the backward
+        # 1.7 x the instructions: 8 / 64 there 0.443 -> 0.461 ms) -- profiles/r05_lpt_tail_and_factors.txt
+        _order_cache["tail"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL", "8"))))
+        _order_cache["tail_bwd"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL_BWD", "0"))))
     return _order_cache["v"]
 
 
@@ -699,7 +717,7 @@ def _deep_knobs():
         _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "256")),
                             int(os.environ.get("GSR_SMALL_GRID", "2560")), int(os.environ.get("GSR_SMALL_GRID_MIN", "96")),
                             int(os.environ.get("GSR_SMALL_GRID_BWD", "1100")),
-                            float(os.environ.get("GSR_DEEP_FACTOR_BWD", "0")))
+                            float(os.environ.get("GSR_DEEP_FACTOR_BWD", "2.0")))
     return _deep_cache["v"]
 
 

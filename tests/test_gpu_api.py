@@ -372,6 +372,66 @@ def test_lists_built_ahead_of_time_are_used_only_with_proven_opacities():
         R._spec_knobs["mode"] = saved
 
 
+def test_lists_are_built_ahead_for_the_models_exact_pattern():
+    """The recipe detection of rasterizer/ahead.py must still FIRE on the installed torch: it reads
+    `type(opacity.grad_fn).__name__` and `grad_fn.next_functions[0][0].variable` -- a renamed attribute would cost the
+    130 us per view the machinery exists for, silently.  The models' exact pattern under the DEFAULT mode (auto):
+    project -> `if radii.sum() == 0` -> SH -> `assert (num_tiles_hit > 0).any()` -> `torch.sigmoid(self.opacities)` ->
+    rasterize (`render_view(caller_syncs=True)`); after the first views the lists are built ahead and USED."""
+    from rasterizer import ahead as A
+    from rasterizer import rasterize as R
+
+    cam = S.make_camera(640, 360)
+    n = 150_000
+    sc = S.make_scene(n, cam, sh_degree=1, seed=23, scale_lo=0.004, scale_hi=0.04)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    logits = torch.logit(cu(sc["opacities"]).clamp(1e-3, 1 - 1e-3)).requires_grad_(True)
+    means, scales, quats, coeffs = cu(sc["means3d"], True), cu(sc["scales"]), cu(sc["quats"]), cu(sc["sh_coeffs"], True)
+    bg = torch.tensor(S.BACKGROUND, device=DEV)
+    R._speculation_mode()
+    saved = R._spec_knobs["mode"]
+    R._spec_knobs["mode"] = "auto"
+    try:
+        c0 = dict(R.counters)
+        for _ in range(8):
+            out = render_view(means, scales, quats, torch.sigmoid(logits), coeffs, ct, bg, 1, caller_syncs=True)
+            out["rgb"].sum().backward()
+        c1 = dict(R.counters)
+        st = A._spec.get(means.device)
+        assert st is not None and st["recipe"] is not None and st["recipe"][0] == "unary" and st["recipe"][1] == "SigmoidBackward0", st
+        assert c1["list_builds_ahead"] - c0["list_builds_ahead"] >= 3 and c1["ahead_hits"] - c0["ahead_hits"] >= 3, (c0, c1)
+        assert c1["ahead_recipes_off"] == c0["ahead_recipes_off"]
+        # an opacity this module cannot trace to a leaf (a product): logged once, recipe detection switches itself off
+        # for the device, results unaffected
+        ref = render_view(means, scales, quats, torch.sigmoid(logits) * 0.5, coeffs, ct, bg, 1)["rgb"].detach()
+        for _ in range(A.UNKNOWN_RECIPE_LIMIT + 2):
+            out = render_view(means, scales, quats, torch.sigmoid(logits) * 0.5, coeffs, ct, bg, 1, caller_syncs=True)
+        c2 = dict(R.counters)
+        assert c2["ahead_recipes_off"] == c1["ahead_recipes_off"] + 1 and A._spec[means.device].get("recipes_off")
+        assert torch.equal(out["rgb"].detach(), ref)
+    finally:
+        R._spec_knobs["mode"] = saved
+        st = A._spec.get(means.device)
+        if st is not None:
+            st["recipes_off"], st["unknown_run"] = False, 0
+
+
+@pytest.mark.parametrize("mode", ["0", "lists"])
+def test_the_oracle_subset_passes_with_speculation_off_and_forced(mode):
+    """The tests of this file that compare with the reference-generated goldens and the oracle, in a process of its own
+    with GSR_SPECULATE=0 (nothing built ahead) and =lists (always built ahead, whatever the caller's stream does)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GSR_SPECULATE=mode)
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                          "(golden or oracle or single_gaussian or empty_scene or gradcheck) and not subset"],
+                         capture_output=True, text=True, timeout=1200, env=env, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout.splitlines()[-1]
+
+
 def test_caller_read_backs_do_not_change_the_view():
     """`render_view(caller_syncs=...)` blocks the host where the unchanged models do (vanilla_gs.py:784, :811, and the
     intrinsics' .item() calls): same image, same gradients, whatever the overlap with the side stream."""

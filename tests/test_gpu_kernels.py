@@ -890,6 +890,70 @@ def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, rgbd, monk
         run(17, 64)  # at most 16 runs
 
 
+@pytest.mark.parametrize("tail,threshold", [(0, 300), (8, 300), (16, 10**6), (63, 40)])
+def test_job_order_is_a_partition_longest_first_and_changes_no_result(tail, threshold, monkeypatch):
+    """GSR_DEEP_ORDERED (round 5): the compositing entries build, behind tile_bins, the order in which their workgroups
+    take jobs -- per XCD, every tile exactly once (whole, or as its four sub-tile jobs), by decreasing half-octave bucket
+    of the list length (a split tile's jobs keyed by a quarter of it), stable inside a bucket, the last `tail`/64 of the
+    whole-tile jobs cut into sub-tile jobs behind everything else.  Forward images and backward gradients are those of
+    the static block order (bit for bit / to the float atomics' summation order)."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 60_000, 640, 368, 16
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=9, scale_lo=0.005, scale_hi=0.05, longtail=True)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    nt = tb[0] * tb[1]
+    colors = np.random.default_rng(2).uniform(0, 1, (n, 3)).astype(np.float32)
+    order, cum = C.depth_order(cu(depths), cu(radii), cu(tiles))
+    ids, bins = C.bin_sorted(n, int(cum[-1].item()), order, cum, cu(xys), cu(radii), tb, bw)
+    lens = (bins[:, 1] - bins[:, 0]).cpu().numpy()
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    a = (tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors), cu(sc["opacities"]), bg)
+    monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
+    monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))
+    C._order_knob()
+    monkeypatch.setitem(C._order_cache, "v", False)
+    f0 = C.rasterize_forward_ex(*a, want_alpha=True)
+    v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
+    v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
+    b0 = C.rasterize_backward(H, W, bw, *a[3:], f0[1], f0[2], v_img, v_alpha)
+    monkeypatch.setitem(C._order_cache, "v", True)
+    monkeypatch.setitem(C._order_cache, "tail", tail)
+    monkeypatch.setitem(C._order_cache, "tail_bwd", tail)
+    assert C.deep_arg(bins, ids.numel(), nt, tile_bounds=tb) & C.GSR_DEEP_ORDERED
+    f1 = C.rasterize_forward_ex(*a, want_alpha=True)
+    for x, y in zip(f0, f1):
+        assert torch.equal(x, y)
+    ints = C.tile_jobs_ints(tb)
+    jobs = torch.empty(0, dtype=torch.int32, device=DEV).set_(bins.untyped_storage(), bins.storage_offset() + 2 * nt,
+                                                               (ints,)).cpu().numpy().reshape(-1, 8)
+    b1 = C.rasterize_backward(H, W, bw, *a[3:], f0[1], f0[2], v_img, v_alpha)
+    for x, y in zip(b0, b1):
+        assert (x - y).abs().max().item() <= 2e-5 * x.abs().max().item()
+    seen = np.zeros(nt, np.int32)
+    for xcd in range(8):
+        col = jobs[:, xcd]
+        live = col[col >= 0]
+        tile, allowed = live & ((1 << 27) - 1), live >> 27
+        np.add.at(seen, tile, allowed)
+        whole = allowed == 15
+        deep = lens[tile] > threshold
+        assert np.all(deep[~whole] | (lens[tile][~whole] > 0))  # sub-tile jobs: deep tiles, or non-empty tail tiles
+        # the sorted part (before the tail's sub-tile jobs of shallow tiles): non-increasing half-octave buckets
+        key = np.where(whole, lens[tile], lens[tile] // 4)
+        q = np.where(key > 0, np.floor(2 * np.log2(np.maximum(key, 1)) + 1e-9), -1)
+        body = whole | deep
+        assert np.all(np.diff(q[body]) <= 0), (xcd, q[body][:40])
+        n_tail_tiles = int((~body).sum()) // 4
+        n_whole_total = int(whole.sum()) + n_tail_tiles
+        assert n_tail_tiles <= (n_whole_total * tail) // 64
+        if tail == 0:
+            assert n_tail_tiles == 0
+    assert np.all(seen == 15), "every tile exactly once: whole (15) or its four sub-tiles (1 + 2 + 4 + 8)"
+
+
 @pytest.mark.parametrize("segs,least", [(1, 0), (5, 64), (16, 64)])
 @pytest.mark.parametrize("opaque", [False, True])
 @pytest.mark.parametrize("rgbd", [False, True])
