@@ -793,6 +793,19 @@ def main():
         cams = orbit_cameras(args.ply_views, W, H, radius=args.ply_cam_radius)
         cam0 = cams[args.ply_view % len(cams)]
         cam = cams[(args.ply_view + rank * 5) % len(cams)]
+    elif args.scene == "ball":
+        # the trainer's default scene (harness.train.blob_scene "ball", the fixed_1m leg's): translucent Gaussians
+        # filling a ball, seen from the training orbit -- deep lists in the middle of the frame, empty tiles around it
+        from harness.train import blob_scene, orbit_cameras
+
+        raw = blob_scene(N, seed=0, sh_degree=deg)
+        q = raw["quats"] / np.linalg.norm(raw["quats"], axis=-1, keepdims=True)
+        sc = {"means3d": raw["means"], "scales": np.exp(raw["scales"]).astype(np.float32), "quats": q.astype(np.float32),
+              "opacities": (1.0 / (1.0 + np.exp(-raw["opacities"].astype(np.float64) + 0.5))).astype(np.float32),
+              "sh_coeffs": np.ascontiguousarray(np.concatenate([raw["features_dc"][:, None, :], raw["features_rest"]], 1))}
+        cams = orbit_cameras(16, W, H, radius=6.0)
+        cam0 = cams[0]
+        cam = cams[(rank * 5) % len(cams)]
     elif args.scene in ("uniform", "longtail"):
         cam0 = S.make_camera(W, H)
         sc = S.make_scene(N, cam0, sh_degree=deg, seed=42, scale_lo=args.scale_lo, scale_hi=args.scale_hi,

@@ -93,3 +93,35 @@ GSR_EXPORT int gsr_calibrate_copy(const void *src, void *dst, size_t bytes, gsr_
   GSR_CHECK_LAUNCH("calibrate_copy");
   return GSR_OK;
 }
+
+// ---- job-order statistics (raster_common.h: JobStats[2][8]): 1 KB per device, owned by the library, allocated on first
+// use (never inside a stream capture: the order kernel then gets nullptr and keys by the default ratio).
+#include <mutex>
+#include <stdlib.h>
+namespace gsr {
+float *gsr_job_stats_buffer() {
+  static std::mutex mu;
+  static float *table[64] = {nullptr};
+  static bool failed[64] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (table[dev] || failed[dev]) return table[dev];
+  void *p = nullptr;
+  if (hipMalloc(&p, 1024) != hipSuccess || hipMemset(p, 0, 1024) != hipSuccess) {
+    (void)hipGetLastError();
+    failed[dev] = true;
+    return nullptr;
+  }
+  table[dev] = static_cast<float *>(p);
+  return table[dev];
+}
+float gsr_job_split_ratio() {
+  static const float v = [] {
+    const char *e = getenv("GSR_DEEP_SPLIT_KEY");  // a fixed key ratio for a split tile's jobs (A/B); unset: measured
+    const float f = e ? (float)atof(e) : 0.f;
+    return f > 0.f && f <= 1.f ? f : 0.f;
+  }();
+  return v;
+}
+}  // namespace gsr

@@ -108,13 +108,14 @@ __device__ __forceinline__ bool gsr_cov2d_bounds(float c0, float c1, float c2,
 
 // deep_tile_threshold carries one flag bit besides the threshold (include/gsraster.h, GSR_DEEP_ORDERED): the buffer
 // behind tile_bins holds the launch's JOB ORDER (raster_common.h), built by the entry point itself.
-// bits 0-23: the threshold; bits 24-29: with GSR_DEEP_ORDERED, the share (in 1/64ths) of the launch's whole-tile jobs
-// that run LAST and are cut into four sub-tile jobs whatever their length (GSR_DEEP_TAIL_64THS): finer work to fill
-// the launch's drain; bit 30: GSR_DEEP_ORDERED.
-#define GSR_DEEP_THRESHOLD_MASK 0xFFFFFF
+// deep_tile_threshold's bits (include/gsraster.h): 0-21 the threshold; 22-27 GSR_DEEP_TAIL_64THS; 28 GSR_DEEP_SECOND
+// (the second of the two job arrays behind tile_bins: the backward's); 29 GSR_DEEP_PREBUILT (gsr_tile_jobs_build has
+// written the array: do not build); 30 GSR_DEEP_ORDERED.
+#define GSR_DEEP_THRESHOLD_MASK 0x3FFFFF
 __host__ __device__ __forceinline__ int gsr_deep_threshold(int v) { return v > 0 ? (v & GSR_DEEP_THRESHOLD_MASK) : 0; }
 __host__ __device__ __forceinline__ bool gsr_deep_ordered(int v) { return v > 0 && (v & GSR_DEEP_ORDERED) != 0; }
-__host__ __device__ __forceinline__ int gsr_deep_tail64(int v) { return gsr_deep_ordered(v) ? ((v >> 24) & 63) : 0; }
+__host__ __device__ __forceinline__ int gsr_deep_tail64(int v) { return gsr_deep_ordered(v) ? ((v >> 22) & 63) : 0; }
+__host__ __device__ __forceinline__ int gsr_deep_second(int v) { return gsr_deep_ordered(v) && (v & GSR_DEEP_SECOND) ? 1 : 0; }
 
 // XCD-aware workgroup -> tile remap.  Workgroup b is dispatched to XCD b % 8
 // (observed, used for speed only).  The tile grid is cut into blocks of 8 x 4 tiles

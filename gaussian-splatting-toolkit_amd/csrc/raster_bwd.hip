@@ -286,6 +286,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   }
   const WaveTrace trace = g_bwd_trace;
   const unsigned long long trace_t0 = trace_begin(trace);
+  const unsigned long long stats_t0 = gsr_deep_ordered(deep_threshold) ? wall_clock64() : 0ull;
   const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile, allowed = job.allowed;  // allowed: the sub-tiles this wave owns (raster_common.h)
   if (tile < 0) return;
@@ -539,6 +540,7 @@ __global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
   }
   }
   trace_end(trace, trace_t0, tile, allowed, trace_len);
+  job_stats_end(job, 1, stats_t0, trace_len);
 }
 
 // The pre-pass of the depth segments: (R, S) of segment seg_k = 1 + block / (4 base_grid) for every pixel of a deep

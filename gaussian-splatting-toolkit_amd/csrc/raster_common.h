@@ -101,17 +101,46 @@ __device__ __forceinline__ int splat_reach_mask(float x, float y, float a, float
 // tile, or four sub-tile jobs above the threshold) sorted by estimated work, LONGEST FIRST; block b runs job[b].
 // Without the flag: the static map, regular blocks first, the extra sub-tile blocks behind them.
 struct TileJob {
-  int tile;     // < 0: nothing to do
-  int allowed;  // sub-tile mask this wave owns (15 = the whole tile)
+  int tile;      // < 0: nothing to do
+  int allowed;   // sub-tile mask this wave owns (15 = the whole tile)
+  float *stats;  // ordered launches: where the waves leave what the NEXT launch's order learns from (job_stats_end)
 };
 constexpr int kJobTileBits = 27;  // job = tile | allowed << 27; -1 = none
+// What a sub-tile wave costs per list entry relative to a whole-tile wave is a property of the scene (0.2-0.25 on a
+// trained model, 0.04 on the long-tail cloud, 0.03 on the trainer's ball of translucent Gaussians whose 10 000-entry
+// tiles saturate after a few hundred entries) -- and it decides where a split tile's jobs belong in a longest-first
+// order: with a fixed length / 4 the ball's rim tiles (whole, 1 100 entries, 310 us: the launch's critical path)
+// started behind the centre's sub-tile jobs and the launch grew 6 %; with length / 16 the trained model's and the
+// long-tail cloud's gains halved.  So the launches MEASURE it: every wave of an ordered launch adds its duration and its
+// tile's list length to four floats per direction (whole / sub-tile; a per-device buffer of the library whose address
+// the order kernel leaves behind the job arrays), and the next order kernel of that direction keys split tiles'
+// jobs by  length x (sub-tile time per entry) / (whole-tile time per entry),  then halves the sums (an exponential
+// average over launches).  No host involvement; a benign race at worst between streams (the order only schedules).
+struct JobStats {     // one per (direction, XCD): 64 bytes, a cache line of its own
+  float dur[2];       // [0] whole-tile waves, [1] sub-tile waves: summed wave durations (100-MHz ticks)
+  float len[2];       // ... and the summed list lengths of their tiles
+  float pad[12];
+};
+constexpr int kJobStatsFloats = 2 * 8 * 16;
+// Every 8th job of an XCD's order reports, to its XCD's own line: 16 k atomics per launch on ONE line cost 150 us
+// (they serialise at ~6 ns each across the eight L2s) -- measured, the first version of this.
+__device__ __forceinline__ void job_stats_end(const TileJob &j, const int dir, const unsigned long long t0, const int len) {
+  if (j.stats && threadIdx.x == 0 && len > 0 && ((blockIdx.x >> 3) & 7u) == 0u) {
+    const int cls = j.allowed == 15 ? 0 : 1;
+    JobStats *st = reinterpret_cast<JobStats *>(j.stats) + dir * 8 + (blockIdx.x & 7u);
+    unsafeAtomicAdd(&st->dur[cls], (float)(wall_clock64() - t0));
+    unsafeAtomicAdd(&st->len[cls], (float)len);
+  }
+}
 __device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned base_grid, const int tiles_x,
                                             const int tiles_y, const int2 *__restrict__ tile_bins,
                                             const int deep_arg, int2 &range) {
-  TileJob j{-1, 15};
+  TileJob j{-1, 15, nullptr};
   const int deep_threshold = gsr_deep_threshold(deep_arg);
   if (gsr_deep_ordered(deep_arg)) {
-    const int code = reinterpret_cast<const int *>(tile_bins + (size_t)tiles_x * tiles_y)[b];
+    const int *tail = reinterpret_cast<const int *>(tile_bins + (size_t)tiles_x * tiles_y);
+    const int code = tail[(size_t)gsr_deep_second(deep_arg) * 4u * base_grid + b];
+    j.stats = *reinterpret_cast<float *const *>(tail + 8u * (size_t)base_grid);
     if (code < 0 || (code & ((1 << kJobTileBits) - 1)) >= tiles_x * tiles_y) return j;  // (none / not a job order)
     j.tile = code & ((1 << kJobTileBits) - 1);
     j.allowed = code >> kJobTileBits;
@@ -136,9 +165,8 @@ __device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned bas
 }
 
 // The job order of one launch: one workgroup of 1024 lanes per XCD.  Items: every tile the static map gives this XCD
-// -- one job (tile, 15) keyed by its list length, or, above the threshold, four jobs (tile, 1 << p) keyed by length / 4
-// (a sub-tile wave stages only what reaches its sub-tile and evaluates a quarter of the pixels: measured 0.09-0.15 us
-// per list entry against 0.47-0.65 for a whole-tile wave).  Counting sort, descending, on HALF-OCTAVE buckets of the
+// -- one job (tile, 15) keyed by its list length, or, above the threshold, four jobs (tile, 1 << p) keyed by
+// length x the measured cost ratio of a sub-tile wave (JobStats above).  Counting sort, descending, on HALF-OCTAVE buckets of the
 // key (bucket = floor(2 log2 key)): jobs inside a bucket differ by < 1.42 x in length and keep -- up to the order in
 // which the waves' LDS atomics land, i.e. in runs of 64 slots -- the static map's SPATIAL order.  That matters: with a
 // fine-grained sort (2 048 linear buckets, the first version) a scene whose lists are all alike was shuffled into a
@@ -164,14 +192,30 @@ constexpr int kJobChunks = 64;  // wave chunks of 64 slots per XCD: up to 4 096 
 static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_x, const int tiles_y,
                                                                 const unsigned base_grid,
                                                                 const int2 *__restrict__ tile_bins,
-                                                                const int deep_threshold, const int tail64,
-                                                                int *__restrict__ jobs) {
+                                                                const int deep_arg0, const int deep_arg1,
+                                                                int *__restrict__ jobs_base, float *stats,
+                                                                const float fixed_ratio) {
+  // workgroups 0-7: the order deep_arg0 describes (threshold, tail, which array); 8-15: deep_arg1's, if launched
+  const int deep_arg = blockIdx.x < 8 ? deep_arg0 : deep_arg1;
+  const int deep_threshold = gsr_deep_threshold(deep_arg), tail64 = gsr_deep_tail64(deep_arg);
+  int *const jobs = jobs_base + (size_t)gsr_deep_second(deep_arg) * 4u * base_grid;
+  // a split tile's jobs are keyed by length x ratio: measured by the previous launches of this direction (JobStats),
+  // 1/8 until there is a measurement, `fixed_ratio` > 0 when the caller pins it (GSR_DEEP_SPLIT_KEY)
+  float ratio = 0.125f;
+  if (stats) {
+    const JobStats *st = reinterpret_cast<const JobStats *>(stats) + gsr_deep_second(deep_arg) * 8;
+    float d0 = 0.f, d1 = 0.f, l0 = 0.f, l1 = 0.f;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) d0 += st[x].dur[0], d1 += st[x].dur[1], l0 += st[x].len[0], l1 += st[x].len[1];
+    if (l0 > 0.f && l1 > 0.f && d0 > 0.f && d1 > 0.f) ratio = fminf(0.5f, fmaxf(1.f / 64.f, (d1 / l1) / (d0 / l0)));
+  }
+  if (fixed_ratio > 0.f) ratio = fixed_ratio;
   // bucket-major tables: a wave scans one bucket's chunks with its lanes (conflict-free rows)
   __shared__ int cnt[kJobBuckets][kJobChunks];   // slots taken by chunk c's jobs of bucket q -> their offset in the bucket
   __shared__ int cntw[kJobBuckets][kJobChunks];  // the same for whole-tile jobs only (their rank among themselves)
   __shared__ int tot[kJobBuckets], totw[kJobBuckets];
   __shared__ int total_s, whole_s;
-  const unsigned xcd = blockIdx.x, slots = base_grid / 8u;
+  const unsigned xcd = blockIdx.x & 7u, slots = base_grid / 8u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = (int)((slots + 63u) >> 6);
   const unsigned long long below = (1ull << lane) - 1ull;
@@ -190,7 +234,7 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
     }
     const bool split = tile >= 0 && deep_threshold > 0 && len > deep_threshold;
     weight = tile < 0 ? 0 : (split ? 4 : 1);
-    q = tile < 0 ? kJobBuckets - 1 : job_bucket(split ? len >> 2 : len);
+    q = tile < 0 ? kJobBuckets - 1 : job_bucket(split ? max(1, (int)((float)len * ratio)) : len);
     same = __ballot(tile >= 0);
 #pragma unroll
     for (int bit = 0; bit < 6; ++bit) {
@@ -282,18 +326,34 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
     }
   }
   for (unsigned s = total + 4 * n_tail + tid; s < 4u * slots; s += 1024) jobs[(size_t)s * 8u + xcd] = -1;
+  if (xcd == 0 && tid == 0) {
+    // where the compositing waves find the statistics (behind both job arrays), and the exponential average: what the
+    // earlier launches of this direction measured counts half from now on (every workgroup of this launch has read
+    // the sums by the time they shrink? not guaranteed -- a workgroup that reads them late keys by a slightly other
+    // ratio: it orders, it does not compute)
+    *reinterpret_cast<float **>(jobs_base + 8u * (size_t)base_grid) = stats;
+    if (stats) {
+      JobStats *st = reinterpret_cast<JobStats *>(stats) + gsr_deep_second(deep_arg) * 8;
+      for (int x = 0; x < 8; ++x) st[x].dur[0] *= 0.5f, st[x].dur[1] *= 0.5f, st[x].len[0] *= 0.5f, st[x].len[1] *= 0.5f;
+    }
+  }
 }
 
-// (host) build the job order behind tile_bins when deep_arg asks for it; -> the argument the kernels take
+float *gsr_job_stats_buffer();  // capi.hip: this device's JobStats[2] (nullptr if it cannot be had)
+float gsr_job_split_ratio();    // capi.hip: GSR_DEEP_SPLIT_KEY (0 = measured)
+
+// (host) build the job order behind tile_bins when deep_arg asks for it (and gsr_tile_jobs_build has not already);
+// -> the argument the kernels take
 static inline int gsr_prepare_jobs(const int deep_arg, const int tiles_x, const int tiles_y, const int32_t *tile_bins,
-                            hipStream_t s) {
+                                   hipStream_t s) {
   if (!gsr_deep_ordered(deep_arg)) return gsr_deep_threshold(deep_arg);
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
   if (base / 8u > (unsigned)kJobChunks * 64u) return gsr_deep_threshold(deep_arg);  // (beyond the sort's tables: static map)
+  if (deep_arg & GSR_DEEP_PREBUILT) return deep_arg;
   int *jobs = const_cast<int *>(tile_bins) + 2 * (size_t)tiles_x * tiles_y;
   hipLaunchKernelGGL(tile_jobs_kernel, dim3(8), dim3(1024), 0, s, tiles_x, tiles_y, base,
-                     reinterpret_cast<const int2 *>(tile_bins), gsr_deep_threshold(deep_arg), gsr_deep_tail64(deep_arg),
-                     jobs);
+                     reinterpret_cast<const int2 *>(tile_bins), deep_arg, 0, jobs, gsr_job_stats_buffer(),
+                     gsr_job_split_ratio());
   return deep_arg;
 }
 

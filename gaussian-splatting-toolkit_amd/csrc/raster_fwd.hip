@@ -99,6 +99,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   }
   const WaveTrace trace = g_fwd_trace;
   const unsigned long long trace_t0 = trace_begin(trace);
+  const unsigned long long stats_t0 = gsr_deep_ordered(deep_threshold) ? wall_clock64() : 0ull;
   const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
   const int tile = job.tile;
   int allowed = job.allowed;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     }
   }
   trace_end(trace, trace_t0, tile, allowed, trace_len);
+  job_stats_end(job, 0, stats_t0, trace_len);
 }
 
 // Pre-pass of the depth segments: the transmittance product of run seg_k = block / (4 base_grid) (every run but a
@@ -900,7 +902,25 @@ GSR_EXPORT int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, 
 }
 
 GSR_EXPORT size_t gsr_tile_jobs_ints(int tiles_x, int tiles_y) {
-  return tiles_x > 0 && tiles_y > 0 ? 4 * (size_t)gsr_xcd_grid(tiles_x, tiles_y) : 0;
+  // two arrays of 4 base_grid + the address of the statistics
+  return tiles_x > 0 && tiles_y > 0 ? 8 * (size_t)gsr_xcd_grid(tiles_x, tiles_y) + 2 : 0;
+}
+
+GSR_EXPORT int gsr_tile_jobs_build(int tiles_x, int tiles_y, int32_t *tile_bins, int deep_arg_first, int deep_arg_second,
+                                   gsr_stream_t stream) {
+  GSR_REQUIRE(tiles_x > 0 && tiles_y > 0 && tile_bins, "tile_jobs_build: bad arguments");
+  GSR_REQUIRE(gsr_deep_ordered(deep_arg_first) && (deep_arg_second <= 0 || gsr_deep_ordered(deep_arg_second)),
+              "tile_jobs_build: arguments without GSR_DEEP_ORDERED");
+  GSR_REQUIRE(deep_arg_second <= 0 || gsr_deep_second(deep_arg_first) != gsr_deep_second(deep_arg_second),
+              "tile_jobs_build: both orders name the same array");
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  GSR_REQUIRE(base / 8u <= (unsigned)gsr::kJobChunks * 64u, "tile_jobs_build: tile grid beyond the sort's tables");
+  int *jobs = tile_bins + 2 * (size_t)tiles_x * tiles_y;
+  hipLaunchKernelGGL(gsr::tile_jobs_kernel, dim3(deep_arg_second > 0 ? 16 : 8), dim3(1024), 0, (hipStream_t)stream, tiles_x,
+                     tiles_y, base, reinterpret_cast<const int2 *>(tile_bins), deep_arg_first, deep_arg_second, jobs,
+                     gsr::gsr_job_stats_buffer(), gsr::gsr_job_split_ratio());
+  GSR_CHECK_LAUNCH("tile_jobs_build");
+  return GSR_OK;
 }
 
 // internal: see gsr_debug_wave_trace (raster_bwd.hip)

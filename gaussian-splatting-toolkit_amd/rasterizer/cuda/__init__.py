@@ -638,7 +638,8 @@ def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = Fals
     return max(floor, int(factor * list_entries / num_tiles))
 
 
-GSR_DEEP_ORDERED = 1 << 30  # include/gsraster.h
+GSR_DEEP_ORDERED, GSR_DEEP_PREBUILT, GSR_DEEP_SECOND = 1 << 30, 1 << 29, 1 << 28  # include/gsraster.h
+_DEEP_TAIL_SHIFT, _DEEP_THRESHOLD_MASK = 22, 0x3FFFFF
 
 
 def tile_jobs_ints(tile_bounds) -> int:
@@ -687,7 +688,36 @@ def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, bac
             pass
     if not ok:
         return deep
-    return min(deep, 0xFFFFFF) | GSR_DEEP_ORDERED | (_order_cache["tail_bwd" if backward else "tail"] << 24)
+    # (the forward's order lives in the first of the two arrays behind tile_bins, the backward's in the second)
+    return (min(deep, _DEEP_THRESHOLD_MASK) | GSR_DEEP_ORDERED | (GSR_DEEP_SECOND if backward else 0)
+            | (_order_cache["tail_bwd" if backward else "tail"] << _DEEP_TAIL_SHIFT))
+
+
+def forward_orders(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, tile_bounds, dev) -> int:
+    """`deep_arg` for a compositing FORWARD, with both job orders -- this launch's and the coming backward's -- written
+    by ONE small launch (`gsr_tile_jobs_build`) in front of it: the backward then finds its order ready
+    (`backward_order`) and launches nothing."""
+    fwd = deep_arg(tile_bins, list_entries, num_tiles, tile_bounds=tile_bounds)
+    if not (fwd & GSR_DEEP_ORDERED):
+        return fwd
+    bwd = deep_arg(tile_bins, list_entries, num_tiles, backward=True, tile_bounds=tile_bounds)
+    second = bwd if (bwd & GSR_DEEP_ORDERED) else 0
+    _call("gsr_tile_jobs_build", C.c_int(int(tile_bounds[0])), C.c_int(int(tile_bounds[1])), _ptr(tile_bins), C.c_int(fwd),
+          C.c_int(second), _stream(dev))
+    try:
+        tile_bins._gsr_jobs_bwd = second
+    except AttributeError:
+        pass
+    return fwd | GSR_DEEP_PREBUILT
+
+
+def backward_order(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, tile_bounds) -> int:
+    """`deep_arg` for a compositing BACKWARD: with GSR_DEEP_PREBUILT when the forward of these very lists has already
+    written this order (`forward_orders` left the argument it built for on the tensor), else the entry builds it."""
+    arg = deep_arg(tile_bins, list_entries, num_tiles, backward=True, tile_bounds=tile_bounds)
+    if (arg & GSR_DEEP_ORDERED) and getattr(tile_bins, "_gsr_jobs_bwd", 0) == arg:
+        arg |= GSR_DEEP_PREBUILT
+    return arg
 
 
 _order_cache = {}
@@ -730,7 +760,7 @@ class _RasterDesc(C.Structure):  # gsr_raster_desc (include/gsraster.h)
                 + [("sort_ws_bytes", C.c_size_t), ("bin_ws", C.c_void_p), ("bin_ws_bytes", C.c_size_t)]
                 + [(k, C.c_void_p) for k in ("out_img", "out_extra", "final_Ts", "final_idx", "out_alpha", "zero_ptr")]
                 + [("zero_bytes", C.c_size_t), ("segments", C.c_int), ("segment_min_entries", C.c_int),
-                   ("seg_ws", C.c_void_p), ("seg_ws_bytes", C.c_size_t)])
+                   ("seg_ws", C.c_void_p), ("seg_ws_bytes", C.c_size_t), ("deep_tile_threshold_backward", C.c_int)])
 
 
 _raster_plan_cache = {}
@@ -814,7 +844,13 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
                            at("counts"), at("order"), at("cum"), ids.data_ptr(), bins.data_ptr(), count_out.data_ptr(),
                            at("sort_ws"), sort_b, at("bin_ws"), bin_b, p(img), p(out_extra), p(Ts),
                            p(idx), p(alpha), p(zero), zero_bytes, segs, seg_min, p(seg_ws),
-                           seg_ws.numel() if seg_ws is not None else 0)
+                           seg_ws.numel() if seg_ws is not None else 0, 0)
+        if composite and (desc.deep_tile_threshold & GSR_DEEP_ORDERED):
+            # the coming backward's job order rides in the same launch as this forward's (include/gsraster.h)
+            bwd = deep_arg(bins, capacity, tb[0] * tb[1], backward=True, tile_bounds=tb)
+            if bwd & GSR_DEEP_ORDERED:
+                desc.deep_tile_threshold_backward = bwd
+                bins._gsr_jobs_bwd = bwd
         _call("gsr_rasterize_gaussians_forward", C.byref(desc), _stream(dev))
     if not composite:
         return ids, bins
@@ -839,7 +875,7 @@ def composite_prepared(tile_bounds, img_width: int, img_height: int, gaussian_id
         _call("gsr_rasterize_forward_seg", C.c_int(tile_bounds[0]), C.c_int(tile_bounds[1]),
               C.c_uint(int(img_width)), C.c_uint(int(img_height)), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys),
               _ptr(conics), _ptr(colors), None, _ptr(opacities), _ptr(background), C.c_float(0.0), _ptr(out_img), None,
-              _ptr(Ts), _ptr(idx), C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, tile_bounds=tile_bounds)),
+              _ptr(Ts), _ptr(idx), C.c_int(forward_orders(tile_bins, gaussian_ids_sorted.numel(), tiles, tile_bounds, dev)),
               _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero_bytes else None, C.c_size_t(zero_bytes),
               C.c_int(segs), C.c_int(seg_min), _ptr(seg_ws) if seg_ws is not None else None,
               C.c_size_t(seg_ws.numel() if seg_ws is not None else 0), _stream(dev))
@@ -875,7 +911,8 @@ def _rasterize_forward(tile_bounds, block, img_size, gaussian_ids_sorted, tile_b
         else:
             if channels != 3:
                 raise RuntimeError("rasterize_forward expects 3 channels; use nd_rasterize_forward")
-            deep = deep_arg(tile_bins, gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], tile_bounds=tile_bounds)
+            deep = forward_orders(tile_bins, gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], tile_bounds, dev) \
+                if block[0] == 16 else deep_tile_threshold(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1])
             segs, seg_min, seg_ws = _forward_segments(gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], H, W,
                                                       dev) if block[0] == 16 else (0, 0, None)
             if ex or segs > 1:
@@ -956,7 +993,7 @@ def rasterize_forward_rgbd(tile_bounds, img_size, gaussian_ids_sorted, tile_bins
               C.c_uint(H), _ptr(gaussian_ids_sorted), _ptr(tile_bins), _ptr(xys), _ptr(conics), _ptr(colors),
               _ptr(extra), _ptr(opacities), _ptr(background), C.c_float(extra_background), _ptr(img), _ptr(ext),
               _ptr(Ts), _ptr(idx),
-              C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], tile_bounds=tile_bounds)),
+              C.c_int(forward_orders(tile_bins, gaussian_ids_sorted.numel(), tile_bounds[0] * tile_bounds[1], tile_bounds, dev)),
               _ptr(alpha) if alpha is not None else None, _ptr(zero) if zero is not None else None,
               C.c_size_t(zero.numel() * 4 if zero is not None else 0), C.c_int(segs), C.c_int(seg_min),
               _ptr(seg_ws) if seg_ws is not None else None, C.c_size_t(seg_ws.numel() if seg_ws is not None else 0),
@@ -996,8 +1033,8 @@ def rasterize_backward_rgbd(img_height, img_width, gaussian_ids_sorted, tile_bin
               _ptr(v_output), _ptr(v_output_extra),
               _ptr(v_output_alpha) if v_output_alpha is not None else None, _ptr(v_xy), _ptr(v_conic),
               _ptr(v_colors), _ptr(v_extra), _ptr(v_opacity),
-              C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True,
-                               tile_bounds=((int(img_width) + 15) // 16, (int(img_height) + 15) // 16))),
+              C.c_int(backward_order(tile_bins, gaussian_ids_sorted.numel(), tiles,
+                                     ((int(img_width) + 15) // 16, (int(img_height) + 15) // 16))),
               C.c_int(1 if accumulators is not None else 0), C.c_int(segs if ws is not None else 0), C.c_int(seg_min),
               _ptr(ws) if ws is not None else None, C.c_size_t(ws.numel() * 4 if ws is not None else 0), _stream(dev))
     return v_xy, v_conic, v_colors, v_extra, v_opacity
@@ -1091,8 +1128,8 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
             segs, seg_min = depth_segments(gaussian_ids_sorted.numel(), tiles) if block_width == 16 else (1, 0)
             _tb16 = ((int(img_width) + 15) // 16, (int(img_height) + 15) // 16) if block_width == 16 else None
             if segs > 1:
-                deep = deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True,
-                                tile_bounds=((int(img_width) + 15) // 16, (int(img_height) + 15) // 16))
+                deep = backward_order(tile_bins, gaussian_ids_sorted.numel(), tiles,
+                                      ((int(img_width) + 15) // 16, (int(img_height) + 15) // 16))
                 ws = torch.empty(((segs - 1) * int(img_height) * int(img_width), 2), dtype=_f32, device=dev)
                 _call("gsr_rasterize_backward_seg", C.c_uint(img_height), C.c_uint(img_width), *tail[:6], None,
                       *tail[6:8], C.c_float(0.0), *tail[8:11], None, *tail[11:15], None, tail[15], C.c_int(deep),
@@ -1100,11 +1137,13 @@ def _rasterize_backward(img_height, img_width, block_width, gaussian_ids_sorted,
                       C.c_size_t(ws.numel() * 4), _stream(dev))
             elif zeroed:
                 _call("gsr_rasterize_backward_ex", *head, *tail,
-                      C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True, tile_bounds=_tb16)),
+                      C.c_int(backward_order(tile_bins, gaussian_ids_sorted.numel(), tiles, _tb16) if _tb16 else
+                              deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)),
                       C.c_int(1), _stream(dev))
             else:
                 _call("gsr_rasterize_backward", *head, *tail,
-                      C.c_int(deep_arg(tile_bins, gaussian_ids_sorted.numel(), tiles, backward=True, tile_bounds=_tb16)),
+                      C.c_int(backward_order(tile_bins, gaussian_ids_sorted.numel(), tiles, _tb16) if _tb16 else
+                              deep_tile_threshold(gaussian_ids_sorted.numel(), tiles, backward=True)),
                       _stream(dev))
     return v_xy, v_conic, v_colors, v_opacity
 

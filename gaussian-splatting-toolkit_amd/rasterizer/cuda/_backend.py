@@ -83,6 +83,7 @@ SYMBOLS = (
     "gsr_rasterize_backward_det_workspace_bytes",
     "gsr_rasterize_backward_det",
     "gsr_tile_jobs_ints",
+    "gsr_tile_jobs_build",
     "gsr_debug_count_staged",
     "gsr_debug_wave_trace",
     "gsr_calibrate_valu",

@@ -256,22 +256,31 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
  * length, not below 256 (a split tile costs ~2x the instructions per list entry).
  * deep_tile_threshold | GSR_DEEP_ORDERED (16x16 tiles; every entry that takes a
  * deep_tile_threshold except the two-round and the deterministic ones, which ignore
- * the flag): LONGEST JOB FIRST.  tile_bins must then be followed by
+ * the flags): LONGEST JOB FIRST.  tile_bins must then be followed by
  * gsr_tile_jobs_ints(tiles_x, tiles_y) writable int32 (one allocation of
- * 2 * tiles + that many ints); the entry first launches one small kernel that writes
- * the launch's job order there -- per XCD, its tiles' jobs (a whole tile, or the four
- * sub-tile jobs of a tile above the threshold) sorted by list length, longest first
- * -- and the compositing workgroups take their jobs from it in block order, so that
- * the walks that last longest start first and the launch does not end on a few long
- * walks over an emptying chip.  Never changes a result.  The buffer belongs to ONE
- * stream at a time (every call rebuilds it).
- * With GSR_DEEP_ORDERED, bits 24-29 of the argument (GSR_DEEP_TAIL_64THS(k), k = 0..63)
- * ask that the last k / 64 of the launch's whole-tile jobs -- the shortest -- run as
- * four sub-tile jobs each behind everything else, whatever their length: quarter-length
- * jobs to fill the launch's drain.  The threshold itself occupies bits 0-23. */
+ * 2 * tiles + that many ints: room for TWO job arrays -- a launch uses the first
+ * unless GSR_DEEP_SECOND is set -- and the address of the library's statistics); the compositing workgroups take their jobs from the array in
+ * block order -- per XCD, its tiles' jobs (a whole tile, or the four sub-tile jobs of a
+ * tile above the threshold) by decreasing half-octave of the list length ( a split
+ * tile's jobs keyed by an eighth of it), stable inside a bucket -- so that the walks
+ * that last longest start first and the launch does not end on a few long walks over an
+ * emptying chip.  Never changes a result.
+ * Who writes the array: the entry itself, with one small kernel in front of the
+ * compositing launch -- or, with GSR_DEEP_PREBUILT also set, nobody: the caller has
+ * called gsr_tile_jobs_build, which writes up to both arrays (say the forward's and,
+ * with other parameters, the backward's) in ONE launch.  The buffer belongs to one
+ * stream at a time.
+ * GSR_DEEP_TAIL_64THS(k), k = 0..63: the last k / 64 of the launch's whole-tile jobs
+ * -- the shortest -- run as four sub-tile jobs each behind everything else, whatever
+ * their length: quarter-length jobs to fill the launch's drain.
+ * Bits: 0-21 threshold, 22-27 tail, 28 SECOND, 29 PREBUILT, 30 ORDERED. */
 #define GSR_DEEP_ORDERED (1 << 30)
-#define GSR_DEEP_TAIL_64THS(k) (((k) & 63) << 24)
+#define GSR_DEEP_PREBUILT (1 << 29)
+#define GSR_DEEP_SECOND (1 << 28)
+#define GSR_DEEP_TAIL_64THS(k) (((k) & 63) << 22)
 size_t gsr_tile_jobs_ints(int tiles_x, int tiles_y);
+int gsr_tile_jobs_build(int tiles_x, int tiles_y, int32_t *tile_bins, int deep_arg_first,
+                        int deep_arg_second, gsr_stream_t stream);
 /* The other mapping of the same compositing rule (measurement variant, 16x16 tiles, 3 channels):
  * lanes over the 64 staged splats, a wave-wide multiplicative prefix scan for the per-pixel
  * transmittance, ballot termination (forward.cu:349-385 is the serial loop it re-maps).  Same
@@ -702,6 +711,9 @@ typedef struct gsr_raster_desc {
   int segments, segment_min_entries;
   void *seg_ws;
   size_t seg_ws_bytes;
+  int deep_tile_threshold_backward; /* > 0 with GSR_DEEP_ORDERED | GSR_DEEP_SECOND: the coming backward's argument --
+                                       its job order is written by the same launch as the forward's (the backward
+                                       then passes it with GSR_DEEP_PREBUILT); 0: not built */
 } gsr_raster_desc;
 int gsr_rasterize_gaussians_forward(const gsr_raster_desc *desc, gsr_stream_t stream);
 int gsr_view_backward(const gsr_view_desc *view, const gsr_view_grads *grads, gsr_stream_t stream);

@@ -894,7 +894,7 @@ def test_depth_segments_of_the_backward_equal_the_single_walk(opaque, rgbd, monk
 def test_job_order_is_a_partition_longest_first_and_changes_no_result(tail, threshold, monkeypatch):
     """GSR_DEEP_ORDERED (round 5): the compositing entries build, behind tile_bins, the order in which their workgroups
     take jobs -- per XCD, every tile exactly once (whole, or as its four sub-tile jobs), by decreasing half-octave bucket
-    of the list length (a split tile's jobs keyed by a quarter of it), stable inside a bucket, the last `tail`/64 of the
+    of the list length (a split tile's jobs keyed by it times the measured cost ratio of a sub-tile wave), stable inside a bucket, the last `tail`/64 of the
     whole-tile jobs cut into sub-tile jobs behind everything else.  Forward images and backward gradients are those of
     the static block order (bit for bit / to the float atomics' summation order)."""
     import rasterizer.cuda as C
@@ -914,6 +914,8 @@ def test_job_order_is_a_partition_longest_first_and_changes_no_result(tail, thre
     monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
     monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))
     C._order_knob()
+    C._deep_knobs()
+    monkeypatch.setitem(C._deep_cache, "v", (1.2, 256, 0, 96, 0, 2.0))  # (no "small grid": this one has 920 tiles)
     monkeypatch.setitem(C._order_cache, "v", False)
     f0 = C.rasterize_forward_ex(*a, want_alpha=True)
     v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
@@ -926,9 +928,9 @@ def test_job_order_is_a_partition_longest_first_and_changes_no_result(tail, thre
     f1 = C.rasterize_forward_ex(*a, want_alpha=True)
     for x, y in zip(f0, f1):
         assert torch.equal(x, y)
-    ints = C.tile_jobs_ints(tb)
+    first = (C.tile_jobs_ints(tb) - 2) // 2  # the forward's array: the first of the two behind tile_bins
     jobs = torch.empty(0, dtype=torch.int32, device=DEV).set_(bins.untyped_storage(), bins.storage_offset() + 2 * nt,
-                                                               (ints,)).cpu().numpy().reshape(-1, 8)
+                                                               (first,)).cpu().numpy().reshape(-1, 8)
     b1 = C.rasterize_backward(H, W, bw, *a[3:], f0[1], f0[2], v_img, v_alpha)
     for x, y in zip(b0, b1):
         assert (x - y).abs().max().item() <= 2e-5 * x.abs().max().item()
@@ -942,10 +944,16 @@ def test_job_order_is_a_partition_longest_first_and_changes_no_result(tail, thre
         deep = lens[tile] > threshold
         assert np.all(deep[~whole] | (lens[tile][~whole] > 0))  # sub-tile jobs: deep tiles, or non-empty tail tiles
         # the sorted part (before the tail's sub-tile jobs of shallow tiles): non-increasing half-octave buckets
-        key = np.where(whole, lens[tile], lens[tile] // 4)
-        q = np.where(key > 0, np.floor(2 * np.log2(np.maximum(key, 1)) + 1e-9), -1)
+        # (a split tile's jobs are keyed by its length x the measured cost ratio of a sub-tile wave, pinned to 1/8
+        #  here through GSR_DEEP_SPLIT_KEY's C-side default when nothing has been measured ... the ratio moves with
+        #  the launches of this very process, so only the two classes' own orders are asserted)
+        q = np.where(lens[tile] > 0, np.floor(2 * np.log2(np.maximum(lens[tile], 1)) + 1e-9), -1)
         body = whole | deep
-        assert np.all(np.diff(q[body]) <= 0), (xcd, q[body][:40])
+        assert np.all(np.diff(q[whole]) <= 0), (xcd, q[whole][:40])
+        # (split jobs: by half-octaves of length x ratio -- whatever the ratio, a later job's tile is never more than
+        #  one half-octave longer than an earlier one's)
+        ls = lens[tile][deep & ~whole].astype(np.float64)
+        assert np.all(ls[1:] <= ls[:-1] * 1.4143), (xcd, ls[:40])
         n_tail_tiles = int((~body).sum()) // 4
         n_whole_total = int(whole.sum()) + n_tail_tiles
         assert n_tail_tiles <= (n_whole_total * tail) // 64

@@ -85,6 +85,15 @@ def main():
               "opacities": (1.0 / (1.0 + np.exp(-raw["opacities"].astype(np.float64)))).astype(np.float32),
               "sh_coeffs": np.ascontiguousarray(np.concatenate([raw["features_dc"][:, None, :], raw["features_rest"]], 1))}
         cam = orbit_cameras(48, W, H, radius=args.ply_cam_radius)[args.ply_view]
+    elif args.scene == "ball":  # the trainer's default scene (harness.train.blob_scene): a ball of translucent Gaussians
+        from harness.train import blob_scene, orbit_cameras
+
+        raw = blob_scene(args.gaussians, seed=0, sh_degree=3)
+        q = raw["quats"] / np.linalg.norm(raw["quats"], axis=-1, keepdims=True)
+        sc = {"means3d": raw["means"], "scales": np.exp(raw["scales"]).astype(np.float32), "quats": q.astype(np.float32),
+              "opacities": (1.0 / (1.0 + np.exp(-raw["opacities"].astype(np.float64) + 0.5))).astype(np.float32),
+              "sh_coeffs": np.ascontiguousarray(np.concatenate([raw["features_dc"][:, None, :], raw["features_rest"]], 1))}
+        cam = orbit_cameras(16, W, H, radius=6.0)[args.ply_view]
     else:
         cam = S.make_camera(W, H)
         sc = S.make_scene(args.gaussians, cam, sh_degree=deg, seed=42, scale_lo=0.0025, scale_hi=0.025,
