@@ -866,34 +866,6 @@ def main():
 
     for _ in range(max(args.warmup, 1)):  # (at least one: the workload's statistics below come from a rendered view)
         out = step()
-    # A fixed DURATION of the workload ahead of the timed steps, whatever --warmup says: the driver runs
-    # `--steps 20 --warmup 5` (25 ms of GPU time in all), and a box whose clocks have not settled reads several
-    # per cent low.  The number of extra steps is derived from the rate of ten more steps (the
-    # first ones carry one-off costs) and agreed across ranks (every step carries collectives under data parallelism).
-    torch.cuda.synchronize()
-    t_w = time.perf_counter()
-    for _ in range(10):
-        out = step()
-    torch.cuda.synchronize()
-    est_ms = 1e3 * (time.perf_counter() - t_w) / 10
-    if dp:
-        tt_ = torch.tensor([est_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
-        est_ms = float(tt_.item())
-    t_w = time.perf_counter()
-    if dp:  # a count every rank agrees on (with margin: the estimate runs slower than the settled rate)
-        fixed_warmup_steps = int(min(4000, max(0, np.ceil(1.5e3 * FIXED_WARMUP_SECONDS / max(est_ms, 1e-3)))))
-        for _ in range(fixed_warmup_steps):
-            out = step()
-        torch.cuda.synchronize()
-    else:  # by the clock
-        fixed_warmup_steps = 0
-        while time.perf_counter() - t_w < FIXED_WARMUP_SECONDS and fixed_warmup_steps < 20000:
-            for _ in range(20):
-                out = step()
-            torch.cuda.synchronize()
-            fixed_warmup_steps += 20
-    fixed_warmup_s = time.perf_counter() - t_w
     num_intersects = int(out["num_tiles_hit"].sum().item())  # the reference's lists (3-sigma boxes)
     from rasterizer import rasterize as _R
     list_entries = int(_R._bin_cache["value"][0])  # what the kernels walk (dead pairs left out)
@@ -931,8 +903,46 @@ def main():
     import gc
 
     gc.collect()
+    # (one bracketed step now: the per-kernel HIP events are created on first use, and the first timed step is a
+    #  bracketed one -- with 20 timed steps that one-off showed as a 1.8-ms first step)
+    timers.enabled = args.event_every > 0
+    step()
+    timers.enabled = False
+    for k_ in timers.pairs:
+        timers.pairs[k_] = []
+    # A fixed DURATION of the workload ahead of the timed steps, whatever --warmup says: the driver runs
+    # `--steps 20 --warmup 5` (25 ms of GPU time in all), and a box whose clocks have not settled reads several
+    # per cent low.  It runs HERE, directly in front of the timed region -- behind the
+    # statistics, the staged-entry count and the collector pass above, which idle the GPU for tens of milliseconds (in its
+    # first place, ahead of them, the driver-form run still read 1.10 ms against 1.02: per-step times falling from 1.09 to
+    # 1.00 over the 20 timed steps).  The number of extra steps is derived from the rate of ten more steps (the
+    # first ones carry one-off costs) and agreed across ranks (every step carries collectives under data parallelism).
+    torch.cuda.synchronize()
+    t_w = time.perf_counter()
+    for _ in range(10):
+        out = step()
+    torch.cuda.synchronize()
+    est_ms = 1e3 * (time.perf_counter() - t_w) / 10
+    if dp:
+        tt_ = torch.tensor([est_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+        est_ms = float(tt_.item())
+    t_w = time.perf_counter()
+    if dp:  # a count every rank agrees on (with margin: the estimate runs slower than the settled rate)
+        fixed_warmup_steps = int(min(4000, max(0, np.ceil(1.5e3 * FIXED_WARMUP_SECONDS / max(est_ms, 1e-3)))))
+        for _ in range(fixed_warmup_steps):
+            out = step()
+        torch.cuda.synchronize()
+    else:  # by the clock
+        fixed_warmup_steps = 0
+        while time.perf_counter() - t_w < FIXED_WARMUP_SECONDS and fixed_warmup_steps < 20000:
+            for _ in range(20):
+                out = step()
+            torch.cuda.synchronize()
+            fixed_warmup_steps += 20
+    fixed_warmup_s = time.perf_counter() - t_w
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # (created before the barrier below)
     barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     bracketed_steps = 0
     t0 = time.perf_counter()
     marks[0].record()
@@ -1209,6 +1219,7 @@ def main():
                            "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, 10)), 4),
                                                    round(float(np.percentile(step_ms, 90)), 4)],
                            "fixed_warmup_steps": fixed_warmup_steps, "fixed_warmup_s": round(fixed_warmup_s, 3),
+                           "ms_per_step_each": ([round(float(v), 4) for v in step_ms] if args.steps <= 40 else None),
                            "what": f"--warmup steps, then {FIXED_WARMUP_SECONDS} s of the same workload untimed, then "
                                    "exactly --steps timed steps (per-step figures: HIP events between steps)"},
                 "calibration": calib,
