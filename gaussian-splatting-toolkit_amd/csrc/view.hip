@@ -86,14 +86,16 @@ GSR_EXPORT int gsr_rasterize_gaussians_forward(const gsr_raster_desc *v, gsr_str
   GSR_TRY(gsr_bin_sorted_dev(n, v->capacity, order, v->counts ? v->cum : nullptr, v->xys, v->radii, v->reach_records,
                              tiles_x, tiles_y, 16, 1, v->ids, v->tile_bins, v->count_out, nullptr, v->bin_ws,
                              v->bin_ws_bytes, stream));
-  if (v->out_img == nullptr) return GSR_OK;  // the lists only (built ahead of time, composited by a later call)
-  GSR_REQUIRE(v->extra == nullptr || v->out_extra != nullptr, "rasterize_gaussians_forward: extra channel without out_extra");
   int deep = v->deep_tile_threshold;
   if (deep > 0 && (deep & GSR_DEEP_ORDERED) && !(deep & GSR_DEEP_PREBUILT) && v->deep_tile_threshold_backward > 0) {
-    // both job orders in one launch: the forward's now, the backward's for later
+    // both job orders in one launch, right behind the lists (also when only the lists were asked for: lists built
+    // ahead of time on a side stream come with their orders, and the compositing call that takes them later -- on
+    // the critical path behind the models' read-back -- launches nothing in front of its kernel)
     GSR_TRY(gsr_tile_jobs_build(tiles_x, tiles_y, v->tile_bins, deep, v->deep_tile_threshold_backward, stream));
     deep |= GSR_DEEP_PREBUILT;
   }
+  if (v->out_img == nullptr) return GSR_OK;  // the lists only (built ahead of time, composited by a later call)
+  GSR_REQUIRE(v->extra == nullptr || v->out_extra != nullptr, "rasterize_gaussians_forward: extra channel without out_extra");
   GSR_TRY(gsr_rasterize_forward_seg(tiles_x, tiles_y, (unsigned)v->img_width, (unsigned)v->img_height, v->ids,
                                     v->tile_bins, v->xys, v->conics, v->colors, v->extra, v->opac, v->background,
                                     v->extra_background, v->out_img, v->extra ? v->out_extra : nullptr, v->final_Ts,

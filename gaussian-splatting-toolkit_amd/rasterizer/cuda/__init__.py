@@ -702,10 +702,12 @@ def forward_orders(tile_bins: Optional[Tensor], list_entries: int, num_tiles: in
         return fwd
     bwd = deep_arg(tile_bins, list_entries, num_tiles, backward=True, tile_bounds=tile_bounds)
     second = bwd if (bwd & GSR_DEEP_ORDERED) else 0
+    if second and getattr(tile_bins, "_gsr_jobs_fwd", 0) == fwd and getattr(tile_bins, "_gsr_jobs_bwd", 0) == second:
+        return fwd | GSR_DEEP_PREBUILT  # (the call that built these lists has written both orders behind them)
     _call("gsr_tile_jobs_build", C.c_int(int(tile_bounds[0])), C.c_int(int(tile_bounds[1])), _ptr(tile_bins), C.c_int(fwd),
           C.c_int(second), _stream(dev))
     try:
-        tile_bins._gsr_jobs_bwd = second
+        tile_bins._gsr_jobs_bwd, tile_bins._gsr_jobs_fwd = second, (fwd if second else 0)
     except AttributeError:
         pass
     return fwd | GSR_DEEP_PREBUILT
@@ -845,12 +847,14 @@ def rasterize_gaussians_forward(xys, depths, radii, conics, colors, opacities, b
                            at("sort_ws"), sort_b, at("bin_ws"), bin_b, p(img), p(out_extra), p(Ts),
                            p(idx), p(alpha), p(zero), zero_bytes, segs, seg_min, p(seg_ws),
                            seg_ws.numel() if seg_ws is not None else 0, 0)
-        if composite and (desc.deep_tile_threshold & GSR_DEEP_ORDERED):
-            # the coming backward's job order rides in the same launch as this forward's (include/gsraster.h)
+        if desc.deep_tile_threshold & GSR_DEEP_ORDERED:
+            # both job orders -- this forward's (or, for lists built ahead, the later compositing call's) and the
+            # coming backward's -- ride in one launch behind the lists (include/gsraster.h)
             bwd = deep_arg(bins, capacity, tb[0] * tb[1], backward=True, tile_bounds=tb)
             if bwd & GSR_DEEP_ORDERED:
                 desc.deep_tile_threshold_backward = bwd
                 bins._gsr_jobs_bwd = bwd
+                bins._gsr_jobs_fwd = int(desc.deep_tile_threshold)
         _call("gsr_rasterize_gaussians_forward", C.byref(desc), _stream(dev))
     if not composite:
         return ids, bins
