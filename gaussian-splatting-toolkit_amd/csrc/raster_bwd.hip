@@ -36,6 +36,9 @@
 #ifndef GSR_BWD_GROUP
 #define GSR_BWD_GROUP 4
 #endif
+#ifndef GSR_BWD_MIN_WAVES
+#define GSR_BWD_MIN_WAVES 1  // (A/B: 5 or 6 asks the compiler for <= 96 / 80 VGPRs, i.e. more resident waves per SIMD)
+#endif
 #ifndef GSR_BWD_FOLD_VALID
 #define GSR_BWD_FOLD_VALID 1
 #endif
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
 // segment as a product of segment products instead of one chain: equal to the single walk to rounding, not bitwise.
 
 template <int G, bool RGBD, bool SEG = false>
-__global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
+__global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
     const float2 *__restrict__ xys, const float *__restrict__ conics,

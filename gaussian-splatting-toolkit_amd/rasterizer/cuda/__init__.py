@@ -61,22 +61,6 @@ def _on(dev):
     return _ALREADY if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
 
 
-def _carve(sizes, dev):
-    """One float32 allocation cut into 1-D pieces of `sizes` elements, each starting on a 256-byte boundary (what a
-    separate `torch.empty` would give: the kernels read rows as float2 / float4) -- one allocator round trip
-    instead of len(sizes).  The pieces are tensors of their OWN over the shared storage (`set_`), not views of one
-    base: each has its own version counter, so a caller's in-place op on one output (`depths.clamp_()`, a masked
-    `radii`) neither invalidates the others that an autograd node saved nor trips "a view created inside a custom
-    Function was modified in place" (ADVICE r4).  What remains of the sharing: the block lives as long as any piece
-    does, and `torch.save` of one piece writes the whole storage -- `.clone()` an output that is kept for long."""
-    offs, total = [], 0
-    for sz in sizes:
-        offs.append(total)
-        total += (int(sz) + 63) & ~63
-    store = torch.empty((max(total, 1),), dtype=_f32, device=dev).untyped_storage()
-    return [torch.empty((0,), dtype=_f32, device=dev).set_(store, o, (int(sz),), (1,)) for o, sz in zip(offs, sizes)]
-
-
 def _stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -116,12 +100,14 @@ def project_gaussians_forward(
     dev = means3d.device
     _opt0 = lambda t: None if t is None else _ptr(t)
     with _on(dev):
-        # one allocation, seven outputs (15 words per Gaussian; all of them live until the backward anyway): six
-        # allocator round trips less per view
-        parts = _carve([2 * n, n, n, 3 * n, n, n] + ([] if precomp else [6 * n]), dev)
-        xys, depths, conics, compensation = parts[0].view(n, 2), parts[1], parts[3].view(n, 3), parts[4]
-        radii, num_tiles_hit = parts[2].view(_i32), parts[5].view(_i32)
-        cov3d = cov3d_precomp if precomp else parts[6].view(n, 6)
+        # seven outputs, seven allocations (the caching allocator hands each out in ~1 us): in round 4 they were carved
+        # out of ONE allocation, which made them views sharing a storage and a version counter (a caller's
+        # in-place op on one invalidated the others that autograd had saved, and keeping `radii` alive pinned all 15
+        # words per Gaussian); independent tensors over a shared storage (`set_`) cost 3 us apiece -- more than this
+        e = lambda shape, dt=_f32: torch.empty(shape, dtype=dt, device=dev)  # noqa: E731
+        xys, depths, conics, compensation = e((n, 2)), e((n,)), e((n, 3)), e((n,))
+        radii, num_tiles_hit = e((n,), _i32), e((n,), _i32)
+        cov3d = cov3d_precomp if precomp else e((n, 6))
         _call(
             "gsr_project_forward", C.c_int(n), _ptr(means3d), _opt0(scales), _cf(glob_scale),
             _opt0(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),
@@ -160,10 +146,10 @@ def project_gaussians_backward(
     )
     _opt = lambda t: None if t is None else _ptr(t)
     with _on(dev):
-        parts = _carve([3 * n, 6 * n, 3 * n] + ([] if precomp else [3 * n, 4 * n]), dev)  # one allocation, five outputs
-        v_cov2d, v_cov3d, v_mean3d = parts[0].view(n, 3), parts[1].view(n, 6), parts[2].view(n, 3)
-        v_scale = None if precomp else parts[3].view(n, 3)
-        v_quat = None if precomp else parts[4].view(n, 4)
+        e = lambda shape: torch.empty(shape, dtype=_f32, device=dev)  # noqa: E731
+        v_cov2d, v_cov3d, v_mean3d = e((n, 3)), e((n, 6)), e((n, 3))
+        v_scale = None if precomp else e((n, 3))
+        v_quat = None if precomp else e((n, 4))
         _call(
             "gsr_project_backward", C.c_int(n), _ptr(means3d), _opt(scales), _cf(glob_scale),
             _opt(quats), _ptr(viewmat), _ptr(projmat), _cf(fx), _cf(fy), _cf(cx), _cf(cy),

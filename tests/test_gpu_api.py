@@ -432,6 +432,28 @@ def test_the_oracle_subset_passes_with_speculation_off_and_forced(mode):
     assert " passed" in out.stdout and "failed" not in out.stdout.splitlines()[-1]
 
 
+def test_projection_outputs_are_independent_tensors():
+    """the seven outputs of `project_gaussians` were views of one allocation (one storage, one version
+    counter): an in-place op by the caller on one of them invalidated the others autograd had saved.  They are
+    independent tensors, as the reference's are: in-place edits of `depths` / `num_tiles_hit` (which the node does not
+    save; `radii`, `conics`, `cov3d` it does, as the reference, project_gaussians.py:151-163) leave the backward intact."""
+    from rasterizer import project_gaussians
+
+    cam = S.make_camera(320, 176)
+    sc = S.make_scene(5000, cam, sh_degree=0, seed=3)
+    ct = CameraTensors.from_numpy(cam, DEV)
+    means = cu(sc["means3d"], True)
+    out = project_gaussians(means, cu(sc["scales"]), 1.0, cu(sc["quats"]), ct.viewmat[:3], ct.projmat, cam.fx, cam.fy,
+                            cam.cx, cam.cy, cam.height, cam.width, 16)
+    xys, depths, radii, conics, comp, tiles, cov3d = out
+    assert len({t.untyped_storage().data_ptr() for t in out}) == 7
+    with torch.no_grad():
+        depths.clamp_(min=0.5)
+        tiles.mul_(2)
+    (xys.sum() + conics.sum()).backward()  # (raised "modified by an inplace operation" with shared version counters)
+    assert torch.isfinite(means.grad).all() and means.grad.abs().sum() > 0
+
+
 def test_caller_read_backs_do_not_change_the_view():
     """`render_view(caller_syncs=...)` blocks the host where the unchanged models do (vanilla_gs.py:784, :811, and the
     intrinsics' .item() calls): same image, same gradients, whatever the overlap with the side stream."""
