@@ -24,11 +24,16 @@ log = logging.getLogger("rasterizer.ahead")
 UNKNOWN_RECIPE_LIMIT = 16
 
 
+_sibling = []
+
+
 def _R():
     """The sibling module (imported late: it imports this one)."""
-    from . import rasterize
+    if not _sibling:
+        from . import rasterize
 
-    return rasterize
+        _sibling.append(rasterize)
+    return _sibling[0]
 
 
 # ---- lists built ahead of time, while the caller is busy elsewhere ---------------------------------------------

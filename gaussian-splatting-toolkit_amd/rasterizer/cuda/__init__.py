@@ -61,7 +61,15 @@ def _on(dev):
     return _ALREADY if (idx is None or idx == torch.cuda.current_device()) else torch.cuda.device(dev)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device) -> C.c_void_p:
+    """The device's current stream as the C ABI takes it (the raw handle where torch hands it out directly: the
+    `torch.cuda.Stream` object of `current_stream()` costs ~5 us, and every wrapper asks)."""
+    idx = device.index
+    if _raw_stream is not None and idx is not None:
+        return C.c_void_p(_raw_stream(idx))
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -658,7 +666,7 @@ def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, bac
         return deep
     # small grids (every tile split, depth segments): the launch is a few hundred short jobs per run -- nothing to
     # order, and the step is bound by the host, where one more launch costs what it costs
-    if num_tiles <= _deep_knobs()[2]:
+    if num_tiles <= (_order_cache["grid"] if _order_cache["grid"] >= 0 else _deep_knobs()[2]):
         return deep
     ok = getattr(tile_bins, "_gsr_job_tail", None)  # (decided once per tensor object)
     if ok is None:
@@ -721,6 +729,8 @@ def _order_knob() -> bool:
         # 1.7 x the instructions: 8 / 64 there 0.443 -> 0.461 ms) -- profiles/r05_lpt_tail_and_factors.txt
         _order_cache["tail"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL", "8"))))
         _order_cache["tail_bwd"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL_BWD", "0"))))
+        # grids of up to this many tiles run in the static order (-1: GSR_SMALL_GRID)
+        _order_cache["grid"] = int(os.environ.get("GSR_DEEP_ORDER_GRID", "-1"))
     return _order_cache["v"]
 
 
