@@ -197,7 +197,8 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
                                                                 const float fixed_ratio) {
   // workgroups 0-7: the order deep_arg0 describes (threshold, tail, which array); 8-15: deep_arg1's, if launched
   const int deep_arg = blockIdx.x < 8 ? deep_arg0 : deep_arg1;
-  const int deep_threshold = gsr_deep_threshold(deep_arg), tail64 = gsr_deep_tail64(deep_arg);
+  int deep_threshold = gsr_deep_threshold(deep_arg);
+  const int tail64 = gsr_deep_tail64(deep_arg);
   int *const jobs = jobs_base + (size_t)gsr_deep_second(deep_arg) * 4u * base_grid;
   // a split tile's jobs are keyed by length x ratio: measured by the previous launches of this direction (JobStats),
   // 1/8 until there is a measurement, `fixed_ratio` > 0 when the caller pins it (GSR_DEEP_SPLIT_KEY)
@@ -215,10 +216,46 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
   __shared__ int cntw[kJobBuckets][kJobChunks];  // the same for whole-tile jobs only (their rank among themselves)
   __shared__ int tot[kJobBuckets], totw[kJobBuckets];
   __shared__ int total_s, whole_s;
+  __shared__ int longest_s, filled_s;
+  __shared__ unsigned long long entries_s;
   const unsigned xcd = blockIdx.x & 7u, slots = base_grid / 8u;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nchunks = (int)((slots + 63u) >> 6);
   const unsigned long long below = (1ull << lane) - 1ull;
+  // Lists that are ALL ALIKE (the longest within 1.5 x the mean of the non-empty ones: a random cloud, never a trained
+  // model) leave nothing to balance: their tiles keep the static map's order (one bucket) and the BACKWARD splits none
+  // of them, whatever the threshold says -- the grid-scaled backward threshold of small grids (rasterizer/cuda:
+  // deep_tile_threshold) is below such a scene's mean, and four sub-tile waves per tile would cost it 1.7 x the
+  // instructions for no shorter launch (1 M uniform Gaussians at 960 x 540: backward 0.33 -> 0.41 ms).
+  if (tid == 0) longest_s = 0, filled_s = 0, entries_s = 0ull;
+  __syncthreads();
+  {
+    int longest = 0, filled = 0;
+    unsigned long long entries = 0ull;
+    for (unsigned s = tid; s < slots; s += 1024u) {
+      const int tile = gsr_xcd_remap(s * 8u + xcd, tiles_x, tiles_y);
+      if (tile < 0) continue;
+      const int2 r = tile_bins[tile];
+      const int len = r.y - r.x;
+      longest = max(longest, len);
+      filled += len > 0;
+      entries += (unsigned)max(len, 0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      longest = max(longest, __shfl_xor(longest, o));
+      filled += __shfl_xor(filled, o);
+      entries += __shfl_xor(entries, o);
+    }
+    if (lane == 0) {
+      atomicMax(&longest_s, longest);
+      atomicAdd(&filled_s, filled);
+      atomicAdd(&entries_s, entries);
+    }
+  }
+  __syncthreads();
+  const bool alike = filled_s > 0 && 2ull * (unsigned long long)longest_s * (unsigned)filled_s <= 3ull * entries_s;
+  if (alike && gsr_deep_second(deep_arg)) deep_threshold = max(deep_threshold, longest_s);
   for (int i = tid; i < kJobBuckets * nchunks; i += 1024) {
     cnt[i / nchunks][i % nchunks] = 0;
     cntw[i / nchunks][i % nchunks] = 0;
@@ -234,7 +271,7 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
     }
     const bool split = tile >= 0 && deep_threshold > 0 && len > deep_threshold;
     weight = tile < 0 ? 0 : (split ? 4 : 1);
-    q = tile < 0 ? kJobBuckets - 1 : job_bucket(split ? max(1, (int)((float)len * ratio)) : len);
+    q = tile < 0 ? kJobBuckets - 1 : alike ? 0 : job_bucket(split ? max(1, (int)((float)len * ratio)) : len);
     same = __ballot(tile >= 0);
 #pragma unroll
     for (int bit = 0; bit < 6; ++bit) {

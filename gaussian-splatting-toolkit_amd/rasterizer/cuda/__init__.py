@@ -610,13 +610,23 @@ def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = Fals
     the default splits tiles above ~1.5x the mean.  Measured on the long-tail bench scene
     (10 % of the tiles ~10x deeper): forward 357 -> 320 us, backward 664 -> 625 us; factors
     0.8-1.5 within 3 % of each other, 0.3 (nearly every tile split) 1.7x slower; no effect
-    on the uniform scene (nothing above the threshold; the idle workgroups cost < 1 %)."""
+    on the uniform scene (nothing above the threshold; the idle workgroups cost < 1 %).
+    Backward: GSR_DEEP_FACTOR_BWD (2.0, quoted on a 1080p grid) scaled by tiles / 8 160 on grids above
+    GSR_SMALL_GRID_BWD -- i.e. a tile is split when its list exceeds total entries / 4 096, the share of one of
+    the backward's resident wave slots (GSR_DEEP_FACTOR_BWD_SCALED=0: the fixed factor)."""
     factor, floor, small_grid, small_floor, small_grid_bwd = _deep_knobs()[:5]
     if backward and _deep_knobs()[5] > 0:
         # GSR_DEEP_FACTOR_BWD (2.0; 0 = the forward's factor): with the longest jobs first, the backward gains from
         # splitting only its longest tiles (four sub-tile waves run four butterflies): trained model 0.405 (1.2) ->
         # 0.348 ms (2.0) -> 0.40 (3.0+); long-tail scene 0.588 -> 0.559 -> 0.504 (6.0)
         factor = _deep_knobs()[5]
+        if _deep_knobs()[6] and num_tiles > small_grid_bwd:
+            # ... at 1080p.  The best factor follows the grid (trained model rendered at five sizes, job order on,
+            # profiles/r05_midgrid_factors.txt): 2 040 tiles 0.5-0.7, 3 600 0.7-1.0, 4 590 1.4, 8 160 2.0, 14 400 3.0+
+            # -- one per 4 096 tiles, the backward's resident waves (4 per SIMD): a tile is split when its list is
+            # longer than the share of the launch's entries one wave slot would get.  960 x 540, the middle stage of
+            # the reference's coarse-to-fine schedule: backward 0.637 -> 0.352 ms, config 3 879 -> 930+ iterations/s.
+            factor *= num_tiles / _BWD_FACTOR_GRID
     if factor <= 0 or num_tiles <= 0:
         return 0
     if num_tiles <= (small_grid_bwd if backward else small_grid):
@@ -666,7 +676,7 @@ def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, bac
         return deep
     # small grids (every tile split, depth segments): the launch is a few hundred short jobs per run -- nothing to
     # order, and the step is bound by the host, where one more launch costs what it costs
-    if num_tiles <= (_order_cache["grid"] if _order_cache["grid"] >= 0 else _deep_knobs()[2]):
+    if num_tiles <= (_order_cache["grid"] if _order_cache["grid"] >= 0 else _deep_knobs()[4]):
         return deep
     ok = getattr(tile_bins, "_gsr_job_tail", None)  # (decided once per tensor object)
     if ok is None:
@@ -729,12 +739,14 @@ def _order_knob() -> bool:
         # 1.7 x the instructions: 8 / 64 there 0.443 -> 0.461 ms) -- profiles/r05_lpt_tail_and_factors.txt
         _order_cache["tail"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL", "8"))))
         _order_cache["tail_bwd"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL_BWD", "0"))))
-        # grids of up to this many tiles run in the static order (-1: GSR_SMALL_GRID)
+        # grids of up to this many tiles run in the static order (-1: GSR_SMALL_GRID_BWD, the grids on which both
+        # directions split every tile and cut the lists into depth segments)
         _order_cache["grid"] = int(os.environ.get("GSR_DEEP_ORDER_GRID", "-1"))
     return _order_cache["v"]
 
 
 _deep_cache = {}
+_BWD_FACTOR_GRID = 8160.0  # (the grid GSR_DEEP_FACTOR_BWD is quoted on: 1920 x 1080)
 
 
 def _deep_knobs():
@@ -745,7 +757,8 @@ def _deep_knobs():
         _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "256")),
                             int(os.environ.get("GSR_SMALL_GRID", "2560")), int(os.environ.get("GSR_SMALL_GRID_MIN", "96")),
                             int(os.environ.get("GSR_SMALL_GRID_BWD", "1100")),
-                            float(os.environ.get("GSR_DEEP_FACTOR_BWD", "2.0")))
+                            float(os.environ.get("GSR_DEEP_FACTOR_BWD", "2.0")),
+                            os.environ.get("GSR_DEEP_FACTOR_BWD_SCALED", "1") != "0")
     return _deep_cache["v"]
 
 

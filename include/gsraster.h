@@ -270,6 +270,10 @@ int gsr_bin_sorted_dev(int num_points, int capacity, const int32_t *order,
  * called gsr_tile_jobs_build, which writes up to both arrays (say the forward's and,
  * with other parameters, the backward's) in ONE launch.  The buffer belongs to one
  * stream at a time.
+ * With GSR_DEEP_SECOND (the backward's order) a launch whose lists are ALL ALIKE --
+ * the longest within 1.5x the mean of the non-empty ones -- splits no tile, whatever
+ * the threshold, and either order then keeps the static map's sequence: there is
+ * nothing to balance and a split tile costs the backward 1.7x the instructions.
  * GSR_DEEP_TAIL_64THS(k), k = 0..63: the last k / 64 of the launch's whole-tile jobs
  * -- the shortest -- run as four sub-tile jobs each behind everything else, whatever
  * their length: quarter-length jobs to fill the launch's drain.

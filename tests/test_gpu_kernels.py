@@ -915,7 +915,7 @@ def test_job_order_is_a_partition_longest_first_and_changes_no_result(tail, thre
     monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))
     C._order_knob()
     C._deep_knobs()
-    monkeypatch.setitem(C._deep_cache, "v", (1.2, 256, 0, 96, 0, 2.0))  # (no "small grid": this one has 920 tiles)
+    monkeypatch.setitem(C._deep_cache, "v", (1.2, 256, 0, 96, 0, 2.0, False))  # (no "small grid": this one has 920 tiles)
     monkeypatch.setitem(C._order_cache, "v", False)
     f0 = C.rasterize_forward_ex(*a, want_alpha=True)
     v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
@@ -960,6 +960,63 @@ def test_job_order_is_a_partition_longest_first_and_changes_no_result(tail, thre
         if tail == 0:
             assert n_tail_tiles == 0
     assert np.all(seen == 15), "every tile exactly once: whole (15) or its four sub-tiles (1 + 2 + 4 + 8)"
+
+
+def test_lists_that_are_all_alike_keep_the_backward_unsplit(monkeypatch):
+    """The order kernel's guard (raster_common.h, `alike`): when the longest list is within 1.5 x the mean of the
+    non-empty ones -- a random cloud -- the backward's order holds whole-tile jobs only, whatever the threshold says
+    (the grid-scaled threshold of small grids is below such a scene's mean), while the forward's order splits as told;
+    results are those of the static order."""
+    import rasterizer.cuda as C
+
+    n, W, H, bw = 150_000, 640, 368, 16
+    cam = S.make_camera(W, H)
+    sc = S.make_scene(n, cam, sh_degree=0, seed=11, scale_lo=0.004, scale_hi=0.02)
+    cov3d, xys, depths, radii, conics, comp, tiles = project_cpu(cam, sc, bw)
+    tb = ((W + bw - 1) // bw, (H + bw - 1) // bw, 1)
+    nt = tb[0] * tb[1]
+    colors = np.random.default_rng(2).uniform(0, 1, (n, 3)).astype(np.float32)
+    order, cum = C.depth_order(cu(depths), cu(radii), cu(tiles))
+    ids, bins = C.bin_sorted(n, int(cum[-1].item()), order, cum, cu(xys), cu(radii), tb, bw)
+    lens = (bins[:, 1] - bins[:, 0]).cpu().numpy()
+    assert lens.max() <= 1.5 * lens[lens > 0].mean(), (lens.max(), lens.mean())  # the premise: lists all alike
+    threshold = int(0.6 * lens.mean())
+    assert (lens > threshold).mean() > 0.9
+    bg = cu(np.array(S.BACKGROUND, np.float32))
+    a = (tb, (bw, bw, 1), (W, H, 1), ids, bins, cu(xys), cu(conics), cu(colors), cu(sc["opacities"]), bg)
+    monkeypatch.setattr(C, "deep_tile_threshold", lambda entries, num_tiles, backward=False: threshold)
+    monkeypatch.setattr(C, "depth_segments", lambda entries, num_tiles: (1, 0))
+    C._order_knob()
+    C._deep_knobs()
+    monkeypatch.setitem(C._deep_cache, "v", (1.2, 256, 0, 96, 0, 2.0, False))
+    monkeypatch.setitem(C._order_cache, "v", False)
+    f0 = C.rasterize_forward_ex(*a, want_alpha=True)
+    v_img = torch.rand(H, W, 3, device=DEV) * 2 - 1
+    v_alpha = torch.rand(H, W, device=DEV) * 2 - 1
+    b0 = C.rasterize_backward(H, W, bw, *a[3:], f0[1], f0[2], v_img, v_alpha)
+    monkeypatch.setitem(C._order_cache, "v", True)
+    monkeypatch.setitem(C._order_cache, "tail", 0)
+    monkeypatch.setitem(C._order_cache, "tail_bwd", 0)
+    monkeypatch.setitem(C._order_cache, "grid", 0)
+    f1 = C.rasterize_forward_ex(*a, want_alpha=True)
+    for x, y in zip(f0, f1):
+        assert torch.equal(x, y)
+    b1 = C.rasterize_backward(H, W, bw, *a[3:], f0[1], f0[2], v_img, v_alpha)
+    for x, y in zip(b0, b1):
+        assert (x - y).abs().max().item() <= 2e-5 * x.abs().max().item()
+    half = (C.tile_jobs_ints(tb) - 2) // 2
+    both = torch.empty(0, dtype=torch.int32, device=DEV).set_(bins.untyped_storage(), bins.storage_offset() + 2 * nt,
+                                                               (2 * half,)).cpu().numpy()
+    for which, arr in (("forward", both[:half]), ("backward", both[half:])):
+        live = arr[arr >= 0]
+        tile, allowed = live & ((1 << 27) - 1), live >> 27
+        seen = np.zeros(nt, np.int32)
+        np.add.at(seen, tile, allowed)
+        assert np.all(seen == 15), which
+        if which == "backward":
+            assert np.all(allowed == 15), "the backward of lists that are all alike runs whole tiles only"
+        else:
+            assert (allowed != 15).mean() > 0.9  # the forward splits as the threshold says
 
 
 @pytest.mark.parametrize("segs,least", [(1, 0), (5, 64), (16, 64)])
