@@ -374,7 +374,7 @@ def train_only(args):
         cfg_u.resolution_schedule = max(1, cfg_u.iters * 2 // 7)
         extra["unchanged_caller"] = train(cfg_u, dev, rank, world)
         extra["refined_1m"] = train(refined_1m(), dev, rank, world)
-    if (full_run and not args.no_cogs) or args.train_small:
+    if (full_run or args.train_small) and not args.no_cogs:
         # BASELINE config 5: the co-gs training loop at 3 M Gaussians / 4K (tests: the same code on a tiny scene)
         cfg_c = cogs_3m_4k(args.cogs_iters)
         if args.train_small:

@@ -60,14 +60,15 @@ def test_plain_invocation_with_two_gpus_spawns_its_ranks():
 def test_eight_ranks_as_the_driver_will_launch_them():
     """`python bench.py --gpus 8 ...` end to end once: the self-spawn of eight ranks, the port
     selection, eight process groups, the timed region with every collective of the exchange, the other ranks leaving,
-    and the training leg's SECOND spawn of eight ranks (config 3 / 4's code on a scene that trains in seconds, the
-    co-gs leg included) -- all eight sharing cuda:0 through gloo, which is not a measurement but is the exact command
-    path of the driver's N = 8 run."""
+    and the training leg's SECOND spawn of eight ranks (config 3 / 4's code on a scene that trains in seconds; the
+    co-gs leg rides in the two-rank test below -- eight ranks on one GPU took this test 11 of the suite's 17 minutes
+    with it) -- all eight sharing cuda:0 through gloo, which is not a measurement but is the exact command path of
+    the driver's N = 8 run."""
     base = [a for a in SMALL if a not in ("--train-iters", "0")]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base +
-                         ["--gpus", "8", "--backend", "gloo", "--train-small", "--train-iters", "80", "--no-cpu-baseline",
-                          "--train-timeout", "1200"], capture_output=True, text=True, timeout=1400, env=env, cwd=ROOT)
+                         ["--gpus", "8", "--backend", "gloo", "--train-small", "--train-iters", "24", "--no-cogs",
+                          "--no-cpu-baseline", "--train-timeout", "1200"], capture_output=True, text=True, timeout=1400, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -77,9 +78,8 @@ def test_eight_ranks_as_the_driver_will_launch_them():
     assert d["allreduce_bytes"] > 0 and "dp8" in d["config"]["parallelism"]
     t = d["train"]
     assert t and "error" not in t, t
-    assert t["n_gpus"] == 8 and t["iters"] == 80 and t["replicas_identical"] is True
+    assert t["n_gpus"] == 8 and t["iters"] == 24 and t["replicas_identical"] is True
     assert t["views_per_s"] > 7.9 * t["iters_per_s"] and t["allreduce_bytes_step_bytes"]
-    assert "error" not in t["cogs_3m_4k"] and t["cogs_3m_4k"]["iters_per_s"] > 0
 
 
 def test_the_drivers_torchrun_form():
