@@ -574,11 +574,15 @@ def _forward_segments(list_entries: int, num_tiles: int, H: int, W: int, dev):
     """-> (segments, minimum entries, workspace or None) of ``gsr_rasterize_forward_seg`` for this tile grid."""
     segs, seg_min = depth_segments(list_entries, num_tiles)
     if segs > 1:
-        # GSR_DEPTH_SEGMENTS_FWD (8; 0 = as the backward): fewer runs for the forward.  Its pre-pass walks every run
-        # from T = 1 to the run's own saturation: on an OPAQUE scene that is most of the list, where the single walk
-        # stops early (300 k opaque Gaussians at 480 x 270: forward 338 us single, 295 with 4 runs, 340 with 8, 432
-        # with 16); a training view of a young, transparent model gains up to the 16, but only ~1 % of config 3's rate
-        # over 8 (profiles/r04_depth_segments.txt): 8 never loses
+        # GSR_DEPTH_SEGMENTS_FWD (16 = as the backward; 8 until the end of round 5): the forward's pre-pass walks
+        # every run from T = 1 to the run's own saturation: on a SATURATING scene that is most of the list, where the
+        # single walk stops early (300 k opaque Gaussians at 480 x 270: forward 338 us single, 295 with 4 runs, 340
+        # with 8, 432 with 16; the trainer's ball, 300 k: 0.30 / 0.37 / 0.44 ms with 4 / 8 / 16), while a translucent
+        # one gains all the way (the model config 3 ends with at 480 x 270: 0.54 / 0.39 / 0.34 / 0.31 ms with
+        # 4 / 8 / 12 / 16; long-tail cloud 0.46 / 0.30 / 0.24 / 0.21).  Small grids are what the reference's
+        # coarse-to-fine schedule renders EARLY in training -- young, translucent models (opacity 0.1 at the start,
+        # vanilla_gs.py:128-174): config 3 923 / 926 -> 957 (12) -> 966 (16) iterations/s on one lease, 952 -> 958-966
+        # on another (profiles/r05_smallgrid_fwd_segments.txt)
         segs = min(segs, _segment_knobs()[3]) if _segment_knobs()[3] > 0 else segs
     if segs < 2:
         return 0, 0, None
@@ -598,7 +602,7 @@ def _segment_knobs():
         _segment_cache["v"] = (min(16, max(1, int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")))),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_GRID", "1100")),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")),
-                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "8")))))
+                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "16")))))
     return _segment_cache["v"]
 
 

@@ -119,3 +119,45 @@ def test_depth_segments_only_where_every_tile_is_split_forward_and_backward(monk
         assert C.depth_segments(1, 256) == (5, 64)
     finally:
         knobs()
+
+
+def test_the_backwards_split_threshold_is_one_wave_slots_share_of_the_launch(monkeypatch):
+    """rasterizer.cuda.deep_tile_threshold(backward=True): GSR_DEEP_FACTOR_BWD is quoted on a 1080p grid
+    and scaled by tiles / 8 160 above the small-grid limit -- the threshold is (entries) / 4 080 whatever the grid;
+    GSR_DEEP_FACTOR_BWD_SCALED=0 restores the fixed factor; small grids keep their constant floor; the job order
+    starts above GSR_SMALL_GRID_BWD."""
+    import rasterizer.cuda as C
+
+    def knobs(**env):
+        for k in ("GSR_DEEP_FACTOR", "GSR_DEEP_MIN", "GSR_DEEP_FACTOR_BWD", "GSR_DEEP_FACTOR_BWD_SCALED", "GSR_SMALL_GRID",
+                  "GSR_SMALL_GRID_BWD", "GSR_SMALL_GRID_MIN", "GSR_DEEP_ORDER_GRID", "GSR_DEEP_ORDER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        C._deep_cache.clear()
+        C._order_cache.clear()
+
+    try:
+        knobs()
+        e = 2_000_000
+        for tiles in (2040, 3600, 4590, 8160, 14400, 32400):
+            want = max(256, int(2.0 * (tiles / 8160.0) * e / tiles))
+            assert C.deep_tile_threshold(e, tiles, backward=True) == want
+            assert abs(want - e / 4080) <= 1
+        assert C.deep_tile_threshold(e, 510, backward=True) == C.deep_tile_threshold(e, 1100, backward=True) == 96
+        assert C.deep_tile_threshold(e, 8160) == int(1.2 * e / 8160)  # the forward's is the mean's multiple as before
+        knobs(GSR_DEEP_FACTOR_BWD_SCALED=0)
+        assert C.deep_tile_threshold(e, 2040, backward=True) == int(2.0 * e / 2040)
+        knobs()
+        import torch
+
+        class _Bins:  # (deep_arg only looks at the attribute alloc_tile_bins leaves on its tensor)
+            _gsr_job_tail = True
+
+        tb = lambda tiles_x, tiles_y: (tiles_x, tiles_y, 1)
+        assert C.deep_arg(_Bins(), e, 60 * 34, backward=True, tile_bounds=tb(60, 34)) & C.GSR_DEEP_ORDERED   # 960 x 540
+        assert not C.deep_arg(_Bins(), e, 30 * 17, backward=True, tile_bounds=tb(30, 17)) & C.GSR_DEEP_ORDERED  # 480 x 270
+        knobs(GSR_DEEP_ORDER_GRID=2560)
+        assert not C.deep_arg(_Bins(), e, 60 * 34, backward=True, tile_bounds=tb(60, 34)) & C.GSR_DEEP_ORDERED
+    finally:
+        knobs()
