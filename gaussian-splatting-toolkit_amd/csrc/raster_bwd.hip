@@ -294,6 +294,7 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
   const int tile = job.tile, allowed = job.allowed;  // allowed: the sub-tiles this wave owns (raster_common.h)
   if (tile < 0) return;
   const int trace_len = range.y - range.x;
+  job_priority(job, trace_len, deep_threshold);
   int seg_behind = 0;  // segments behind this one whose maps are applied first
   if constexpr (SEG) {
     const int len = range.y - range.x;

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   int allowed = job.allowed;
   if (tile < 0) return;
   const int trace_len = range.y - range.x;
+  job_priority(job, trace_len, deep_threshold);
   bool split = false;
   if constexpr (SEG) {
     const int len = range.y - range.x;
