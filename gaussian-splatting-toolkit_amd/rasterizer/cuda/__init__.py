@@ -609,7 +609,7 @@ def _segment_knobs():
 def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = False) -> int:
     """List length above which a 16x16 tile is composited by four waves (one per 8x8
     sub-tile) instead of one (include/gsraster.h, ``deep_tile_threshold``): GSR_DEEP_FACTOR
-    (default 1.2; 0 = off) times the mean list length, not below GSR_DEEP_MIN (1024).
+    (default 1.2; 0 = off) times the mean list length, not below GSR_DEEP_MIN (256; 1024 until round 5).
     `list_entries` is normally the capacity of device-sized lists (~1.25x the real count), so
     the default splits tiles above ~1.5x the mean.  Measured on the long-tail bench scene
     (10 % of the tiles ~10x deeper): forward 357 -> 320 us, backward 664 -> 625 us; factors
