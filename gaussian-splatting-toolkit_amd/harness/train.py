@@ -442,7 +442,7 @@ def _depth_segments_record(device):
         return None
     import rasterizer.cuda as _C
 
-    segs, grid, least, fwd = _C._segment_knobs()
+    segs, grid, least, fwd = _C._segment_knobs()[:4]
     return {"runs": segs, "runs_forward": min(segs, fwd) if fwd > 0 else segs, "tile_grids_up_to": grid,
             "lists_longer_than": least,
             "what": "on such grids the list of every split tile is cut into runs composited by their own waves "

@@ -561,7 +561,7 @@ def depth_segments(list_entries: int, num_tiles: int):
     818 / 825 -> 871 (8 runs) -> 885 iterations/s (16).  On larger grids the kernels are bound by their total work,
     which the pre-passes raise: 960 x 540 unchanged, the long-tail 1080p scene 0.62 -> 0.67 ms (backward), the default
     0.427 -> 0.448 ms (the empty workgroups of the segment grid) -- off there."""
-    segs, grid, least, _ = _segment_knobs()
+    segs, grid, least = _segment_knobs()[:3]
     _, _, small_grid, _, small_grid_bwd = _deep_knobs()[:5]
     # (only where EVERY tile above the small-grid floor is split, forward and backward alike: which tiles are cut, and
     #  where, is then a function of the tile's list alone and every route to the kernels rounds the same way)
@@ -585,7 +585,13 @@ def _forward_segments(list_entries: int, num_tiles: int, H: int, W: int, dev):
         # on another (profiles/r05_smallgrid_fwd_segments.txt)
         segs = min(segs, _segment_knobs()[3]) if _segment_knobs()[3] > 0 else segs
     if segs < 2:
-        return 0, 0, None
+        # forward-only runs on larger grids, for the longest lists alone (GSR_DEPTH_SEGMENTS_FWD_GRID tiles, 0 = off;
+        # lists above GSR_DEPTH_SEGMENTS_FWD_FACTOR x the mean, not below _FWD_MIN entries): the forward's span on a
+        # trained model is the serial walk of its longest tiles' sub-tile waves
+        k = _segment_knobs()
+        if k[4] <= 0 or num_tiles <= 0 or num_tiles > k[4] or k[5] < 2:
+            return 0, 0, None
+        segs, seg_min = k[5], max(k[7], int(k[6] * list_entries / num_tiles))
     nbytes = int(_lib().gsr_rasterize_forward_seg_workspace_bytes(C.c_uint(H), C.c_uint(W), C.c_int(segs)))
     return segs, seg_min, torch.empty((nbytes,), dtype=torch.uint8, device=dev)
 
@@ -602,7 +608,11 @@ def _segment_knobs():
         _segment_cache["v"] = (min(16, max(1, int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")))),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_GRID", "1100")),
                                int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")),
-                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "16")))))
+                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "16")))),
+                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_GRID", "0")),
+                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_RUNS", "4")))),
+                               float(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_FACTOR", "3.0")),
+                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_MIN", "512")))
     return _segment_cache["v"]
 
 
