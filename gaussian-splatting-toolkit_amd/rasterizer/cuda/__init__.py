@@ -589,7 +589,7 @@ def _forward_segments(list_entries: int, num_tiles: int, H: int, W: int, dev):
         # lists above GSR_DEPTH_SEGMENTS_FWD_FACTOR x the mean, not below _FWD_MIN entries): the forward's span on a
         # trained model is the serial walk of its longest tiles' sub-tile waves
         k = _segment_knobs()
-        if k[4] <= 0 or num_tiles <= 0 or num_tiles > k[4] or k[5] < 2:
+        if len(k) < 8 or k[4] <= 0 or num_tiles <= 0 or num_tiles > k[4] or k[5] < 2:
             return 0, 0, None
         segs, seg_min = k[5], max(k[7], int(k[6] * list_entries / num_tiles))
     nbytes = int(_lib().gsr_rasterize_forward_seg_workspace_bytes(C.c_uint(H), C.c_uint(W), C.c_int(segs)))
