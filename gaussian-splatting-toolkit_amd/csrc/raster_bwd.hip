@@ -501,12 +501,26 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
   for (int seg = tile_bins2 ? 1 : 0; seg >= 0; --seg) {
   if (seg) range = range2; else if (tile_bins2) range = tile_bins[tile];  // (tile_job left the first segment in `range`)
   const int top = min(range.y - 1, max_top);
+#if GSR_STAGE_AHEAD
+  // (raster_fwd.hip: the next chunk's loads in flight during the walk over the current one)
+  int g_cur = stage_load_id(top - lane >= range.x, top - lane, ids_sorted);
+  int g_next = stage_load_id(top - kChunk - lane >= range.x, top - kChunk - lane, ids_sorted);
+  StageRegs regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+#endif
   for (int hi = top; hi >= range.x; hi -= kChunk) {
     // back to front: lane l fetches sorted index hi - l; kept splats stay in that order
     const int sidx_l = hi - lane;
+#if GSR_STAGE_AHEAD
+    const int count = stage_commit(lane, sidx_l >= range.x, sidx_l, g_cur, regs, tx0, ty0, sA, sB, sC, sId, staged, allowed);
+    __syncthreads();
+    g_cur = g_next;
+    regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+    g_next = stage_load_id(sidx_l - 2 * kChunk >= range.x, sidx_l - 2 * kChunk, ids_sorted);
+#else
     const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics,
                                   colors, opacities, sA, sB, sC, sId, RGBD ? extra : nullptr, staged, allowed);
     __syncthreads();
+#endif
 
     for (int t0 = 0; t0 < count; t0 += G) {
       float P[NC * G];
@@ -730,8 +744,13 @@ __global__ __launch_bounds__(64) void raster_bwd_segstate_kernel(
   const int top = min(range.y - 1, max_top);
   for (int hi = top; hi >= range.x; hi -= kChunk) {
     const int sidx_l = hi - lane;
+#if GSR_STAGE_AHEAD
+    const int count = stage_chunk_flat(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics, colors,
+                                       opacities, sA, sB, sC, RGBD ? extra : nullptr, allowed);
+#else
     const int count = stage_chunk(lane, sidx_l >= range.x, sidx_l, tx0, ty0, ids_sorted, xys, conics, colors, opacities,
                                   sA, sB, sC, nullptr, RGBD ? extra : nullptr, nullptr, allowed);
+#endif
     __syncthreads();
     for (int t = 0; t < count; ++t) {
       const SplatA A = sA[t];

@@ -6,6 +6,12 @@ namespace gsr {
 
 constexpr int kChunk = 64;  // splats staged per LDS fill (one per lane)
 
+// 1: the tile16 compositing loops keep the NEXT chunk's global loads in flight while they walk the current one
+// (stage_load_id / stage_load_attrs / stage_commit below); 0: stage_chunk in front of every chunk (A/B builds)
+#ifndef GSR_STAGE_AHEAD
+#define GSR_STAGE_AHEAD 1
+#endif
+
 // LDS record of one staged splat; consumed by wave-uniform broadcast reads.
 struct __align__(16) SplatA { float x, y, ha, b; };     // ha = a/2
 struct __align__(16) SplatB { float hc, opac, r, g; };  // hc = c/2
@@ -491,6 +497,75 @@ __device__ __forceinline__ int stage_chunk(
     if (sId) sId[slot] = g;
   }
   return __popcll(kept);
+}
+
+// ---- staging one chunk AHEAD (GSR_STAGE_AHEAD) -------------------------------------------
+// stage_chunk is a chain of three dependent global loads (list entry -> geometry -> colours) in front of every 64 list
+// entries; a wave that is alone on its SIMD -- the long walks a launch ends with -- waits it out every time.  Split in
+// three so that the compositing loops can keep the loads of the NEXT chunk in flight while they walk the current one:
+//   stage_load_id     the chunk's list entries (one per lane; lanes outside the range read nothing and get Gaussian 0)
+//   stage_load_attrs  everything a splat record holds, UNCONDITIONALLY (colours of splats the reach test will drop
+//                     included: 12 bytes more per dropped entry, no third round trip)
+//   stage_commit      the reach test and the LDS records -- the same arithmetic, slots and order as stage_chunk.
+struct StageRegs {
+  float2 xy;
+  float a, b, c, opac, red, green, blue, extra;
+};
+__device__ __forceinline__ int stage_load_id(const bool live, const int sidx, const int *__restrict__ ids_sorted) {
+  return live ? ids_sorted[sidx] : 0;
+}
+__device__ __forceinline__ StageRegs stage_load_attrs(const int g, const float2 *__restrict__ xys,
+                                                      const float *__restrict__ conics,
+                                                      const float *__restrict__ colors,
+                                                      const float *__restrict__ opacities,
+                                                      const float *__restrict__ extra) {
+  StageRegs s;
+  s.xy = xys[g];
+  s.a = conics[3 * g];
+  s.b = conics[3 * g + 1];
+  s.c = conics[3 * g + 2];
+  s.opac = opacities[g];
+  s.red = colors ? colors[3 * g] : 0.f;  // (the forward's transmittance pre-pass composites no colour)
+  s.green = colors ? colors[3 * g + 1] : 0.f;
+  s.blue = colors ? colors[3 * g + 2] : 0.f;
+  s.extra = extra ? extra[g] : 0.f;
+  return s;
+}
+__device__ __forceinline__ int stage_commit(const int lane, const bool live, const int sidx, const int g,
+                                            const StageRegs &s, const float tx0, const float ty0, SplatA *sA,
+                                            SplatB *sB, SplatC *sC, int *sId,
+                                            unsigned long long *staged_counter = nullptr, const int allowed = 15) {
+  if (staged_counter) {
+    const int n = __popcll(__ballot(live));
+    if (lane == 0) atomicAdd(staged_counter, (unsigned long long)n);
+  }
+  int mask = splat_reach_mask(s.xy.x, s.xy.y, s.a, s.b, s.c, s.opac, tx0, ty0);
+#ifdef GSR_NO_CULL
+  mask = 15;
+#endif
+  mask = live ? (mask & allowed) : 0;
+  const unsigned long long kept = __ballot(mask != 0);
+  if (mask != 0) {
+    const int slot = __builtin_amdgcn_mbcnt_hi((unsigned)(kept >> 32),
+                                               __builtin_amdgcn_mbcnt_lo((unsigned)kept, 0u));
+    sA[slot] = SplatA{s.xy.x, s.xy.y, 0.5f * s.a, s.b};
+    sB[slot] = SplatB{0.5f * s.c, s.opac, s.red, s.green};
+    sC[slot] = SplatC{s.blue, sidx, mask, s.extra};
+    if (sId) sId[slot] = g;
+  }
+  return __popcll(kept);
+}
+
+// One chunk in one go through the same three pieces (the pre-pass kernels of the depth segments, whose runs are a
+// chunk or two long): two round trips instead of stage_chunk's three.
+__device__ __forceinline__ int stage_chunk_flat(
+    const int lane, const bool live, const int sidx, const float tx0, const float ty0,
+    const int *__restrict__ ids_sorted, const float2 *__restrict__ xys, const float *__restrict__ conics,
+    const float *__restrict__ colors, const float *__restrict__ opacities, SplatA *sA, SplatB *sB, SplatC *sC,
+    const float *__restrict__ extra, const int allowed) {
+  const int g = stage_load_id(live, sidx, ids_sorted);
+  const StageRegs regs = stage_load_attrs(g, xys, conics, colors, opacities, extra);
+  return stage_commit(lane, live, sidx, g, regs, tx0, ty0, sA, sB, sC, nullptr, nullptr, allowed);
 }
 
 }  // namespace gsr

@@ -174,11 +174,28 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
 
   unsigned long long *const staged = g_fwd_staged;
   int live = live_subtiles();
+#if GSR_STAGE_AHEAD
+  // chunk n's records are committed from registers loaded one iteration ago; behind the commit the loads of chunk
+  // n + 1 (geometry + colours, from the list entries fetched one iteration ago) and the list entries of chunk n + 2
+  // go out, and the walk over chunk n hides them (pays where a chunk's walk is short -- the
+  // sub-tile waves of split tiles, i.e. mid-size grids and deep tiles)
+  int g_cur = stage_load_id(range.x + lane < range.y, range.x + lane, ids_sorted);
+  int g_next = stage_load_id(range.x + kChunk + lane < range.y, range.x + kChunk + lane, ids_sorted);
+  StageRegs regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+#endif
   for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
+#if GSR_STAGE_AHEAD
+    const int count = stage_commit(lane, sidx < range.y, sidx, g_cur, regs, tx0, ty0, sA, sB, sC, nullptr, staged, allowed);
+    __syncthreads();
+    g_cur = g_next;
+    regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+    g_next = stage_load_id(sidx + 2 * kChunk < range.y, sidx + 2 * kChunk, ids_sorted);
+#else
     const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics,
                                   colors, opacities, sA, sB, sC, nullptr, RGBD ? extra : nullptr, staged, allowed);
     __syncthreads();
+#endif
     for (int t = 0; t < count; ++t) {
       if ((t & 7) == 7) {
         live = live_subtiles();
@@ -321,8 +338,13 @@ __global__ __launch_bounds__(64) void raster_fwd_segtau_kernel(
   int live = live_subtiles();
   for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
+#if GSR_STAGE_AHEAD
+    const int count = stage_chunk_flat(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics, nullptr, opacities,
+                                       sA, sB, sC, nullptr, allowed);
+#else
     const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics, colors, opacities, sA,
                                   sB, sC, nullptr, nullptr, nullptr, allowed);
+#endif
     __syncthreads();
     for (int t = 0; t < count; ++t) {
       if ((t & 7) == 7) {
