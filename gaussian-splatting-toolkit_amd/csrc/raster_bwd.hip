@@ -503,9 +503,14 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
   const int top = min(range.y - 1, max_top);
 #if GSR_STAGE_AHEAD
   // (raster_fwd.hip: the next chunk's loads in flight during the walk over the current one)
-  int g_cur = stage_load_id(top - lane >= range.x, top - lane, ids_sorted);
-  int g_next = stage_load_id(top - kChunk - lane >= range.x, top - kChunk - lane, ids_sorted);
-  StageRegs regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+  // (nothing to walk loads nothing: lanes outside a NON-empty range read Gaussian 0, which then exists)
+  int g_cur = 0, g_next = 0;
+  StageRegs regs = {};
+  if (top >= range.x) {
+    g_cur = stage_load_id(top - lane >= range.x, top - lane, ids_sorted);
+    g_next = stage_load_id(top - kChunk - lane >= range.x, top - kChunk - lane, ids_sorted);
+    regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+  }
 #endif
   for (int hi = top; hi >= range.x; hi -= kChunk) {
     // back to front: lane l fetches sorted index hi - l; kept splats stay in that order

@@ -179,9 +179,14 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   // n + 1 (geometry + colours, from the list entries fetched one iteration ago) and the list entries of chunk n + 2
   // go out, and the walk over chunk n hides them (pays where a chunk's walk is short -- the
   // sub-tile waves of split tiles, i.e. mid-size grids and deep tiles)
-  int g_cur = stage_load_id(range.x + lane < range.y, range.x + lane, ids_sorted);
-  int g_next = stage_load_id(range.x + kChunk + lane < range.y, range.x + kChunk + lane, ids_sorted);
-  StageRegs regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+  // (an empty list loads nothing: lanes outside a NON-empty range read Gaussian 0, which then exists)
+  int g_cur = 0, g_next = 0;
+  StageRegs regs = {};
+  if (range.x < range.y) {
+    g_cur = stage_load_id(range.x + lane < range.y, range.x + lane, ids_sorted);
+    g_next = stage_load_id(range.x + kChunk + lane < range.y, range.x + kChunk + lane, ids_sorted);
+    regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+  }
 #endif
   for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
