@@ -180,27 +180,35 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   // go out, and the walk over chunk n hides them (pays where a chunk's walk is short -- the
   // sub-tile waves of split tiles, i.e. mid-size grids and deep tiles)
   // (an empty list loads nothing: lanes outside a NON-empty range read Gaussian 0, which then exists)
+  // NOT in the RGB + depth instantiation: the one workload that trains through it (co-gs, 3 M Gaussians at 4K, tiles
+  // that saturate within a few chunks) lost 14 % of its render phase to the extra requests (profiles/r05_stage_ahead_ab.txt)
+  constexpr bool kAhead = !RGBD;
   int g_cur = 0, g_next = 0;
   StageRegs regs = {};
-  if (range.x < range.y) {
+  if (kAhead && range.x < range.y) {
     g_cur = stage_load_id(range.x + lane < range.y, range.x + lane, ids_sorted);
     g_next = stage_load_id(range.x + kChunk + lane < range.y, range.x + kChunk + lane, ids_sorted);
     regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
   }
+#else
+  constexpr bool kAhead = false;
+  [[maybe_unused]] int g_cur = 0, g_next = 0;
+  [[maybe_unused]] StageRegs regs = {};
 #endif
   for (int base = range.x; base < range.y && live != 0; base += kChunk) {
     const int sidx = base + lane;
-#if GSR_STAGE_AHEAD
-    const int count = stage_commit(lane, sidx < range.y, sidx, g_cur, regs, tx0, ty0, sA, sB, sC, nullptr, staged, allowed);
-    __syncthreads();
-    g_cur = g_next;
-    regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
-    g_next = stage_load_id(sidx + 2 * kChunk < range.y, sidx + 2 * kChunk, ids_sorted);
-#else
-    const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics,
-                                  colors, opacities, sA, sB, sC, nullptr, RGBD ? extra : nullptr, staged, allowed);
-    __syncthreads();
-#endif
+    int count;
+    if constexpr (kAhead) {
+      count = stage_commit(lane, sidx < range.y, sidx, g_cur, regs, tx0, ty0, sA, sB, sC, nullptr, staged, allowed);
+      __syncthreads();
+      g_cur = g_next;
+      regs = stage_load_attrs(g_cur, xys, conics, colors, opacities, RGBD ? extra : nullptr);
+      g_next = stage_load_id(sidx + 2 * kChunk < range.y, sidx + 2 * kChunk, ids_sorted);
+    } else {
+      count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics, colors, opacities, sA, sB, sC,
+                          nullptr, RGBD ? extra : nullptr, staged, allowed);
+      __syncthreads();
+    }
     for (int t = 0; t < count; ++t) {
       if ((t & 7) == 7) {
         live = live_subtiles();
