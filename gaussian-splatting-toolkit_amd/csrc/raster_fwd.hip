@@ -178,10 +178,11 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   // chunk n's records are committed from registers loaded one iteration ago; behind the commit the loads of chunk
   // n + 1 (geometry + colours, from the list entries fetched one iteration ago) and the list entries of chunk n + 2
   // go out, and the walk over chunk n hides them (pays where a chunk's walk is short -- the
-  // sub-tile waves of split tiles, i.e. mid-size grids and deep tiles)
-  // (an empty list loads nothing: lanes outside a NON-empty range read Gaussian 0, which then exists)
-  // NOT in the RGB + depth instantiation: the one workload that trains through it (co-gs, 3 M Gaussians at 4K, tiles
-  // that saturate within a few chunks) lost 14 % of its render phase to the extra requests (profiles/r05_stage_ahead_ab.txt)
+  // sub-tile waves of split tiles, i.e. mid-size grids and deep tiles).  An empty list loads nothing; lanes outside a
+  // NON-empty range read Gaussian 0, which then exists.
+  // Not in the RGB + depth instantiation: the one workload that trains through it (co-gs, 3 M Gaussians at 4K, tiles
+  // that saturate within a few chunks) lost 14 % of its render phase to the extra requests
+  // (profiles/r05_stage_ahead_ab.txt); it stages with stage_chunk as before.
   constexpr bool kAhead = !RGBD;
   int g_cur = 0, g_next = 0;
   StageRegs regs = {};
