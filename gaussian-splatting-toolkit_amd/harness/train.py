@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+from . import cogs_losses
 from . import scene as S
 from .parallel import GradientExchange, allreduce_densify_stats, view_for_rank
 from .pipeline import CameraTensors, render_view
@@ -428,6 +429,21 @@ class TrainConfig:
     # normalisation + masked L1 in gs_fused.depth_l1_loss; False: the models' two `rasterize_gaussians` calls and
     # their torch ops (depth_gs.py:330-363, 531-538)
     fused_depth: bool = True
+    # co-gs: the OPTIONAL loss terms of `DepthGSModelConfig` (depth_gs.py:93-139), every one off by default as in the
+    # reference; restated in harness/cogs_losses.py (plain torch ops, outside the rasterizer's hot path).  With
+    # `use_est_depth` the depth branch is the monocular-depth one (:477-531: local Pearson / scaled log-depth / TV
+    # instead of `depth_l1`); `use_depth_regularization` needs OpenCV's Canny and raises.
+    use_scale_regularization: bool = False
+    max_gauss_ratio: float = 10.0
+    use_sparse_loss: bool = False
+    sparse_lambda: float = 0.1
+    use_est_depth: bool = False
+    use_pearson_depth: bool = False
+    local_patch_size: int = 128
+    depth_loss_stop_iteration: int = 25_000
+    use_scaled_est_depth: bool = False
+    use_depth_regularization: bool = False
+    using_tv_loss: bool = False
 
 
 def quantise_depth_mm(depth: torch.Tensor) -> torch.Tensor:
@@ -768,12 +784,22 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
                                    sh_exchange=exchange if sh_views else None, caller_syncs=cfg.caller_syncs,
                                    render_depth=cogs, fused_depth=cogs and cfg.fused_depth and device.type == "cuda",
                                    normalise_depth=not (cogs and cfg.fused_depth and cfg.fused_loss
-                                                        and device.type == "cuda"))
+                                                        and device.type == "cuda" and not cfg.use_est_depth))
                 rgb = out["rgb"]
                 if ph:
                     ph[1].record()
                 loss = loss_fn(rgb, target)
-                if depth_on:
+                if cogs and cfg.use_scale_regularization and step % 10 == 0:  # depth_gs.py:450-460
+                    loss = loss + cogs_losses.scale_regularisation(model.gauss["scales"], cfg.max_gauss_ratio)
+                if cogs and cfg.use_sparse_loss and step % 100 == 0:  # :462-467 (the raw opacity parameter, as written)
+                    loss = loss + cogs_losses.sparse_loss(model.gauss["opacities"], cfg.sparse_lambda)
+                if depth_on and cfg.use_est_depth:
+                    # the monocular-depth branch (:477-531); the synthetic ground truth is metric: scale 1, shift 0
+                    terms = cogs_losses.optional_depth_terms(cfg, step, out["depth"], downscale_depth(gt_depth[v], d),
+                                                            target, mono_scale_shift=(1.0, 0.0))
+                    for term in terms.values():
+                        loss = loss + term
+                elif depth_on:
                     # `gt_depth = self.get_gt_img(batch["depth"])` (downscaled like the image under a resolution schedule)
                     loss = loss + depth_loss_fn(out, downscale_depth(gt_depth[v], d))
                 if ph:
