@@ -95,11 +95,13 @@ GSR_EXPORT int gsr_calibrate_copy(const void *src, void *dst, size_t bytes, gsr_
 }
 
 // ---- job-order statistics (raster_common.h: JobStats[2][8]): 1 KB per device, owned by the library, allocated on first
-// use (never inside a stream capture: the order kernel then gets nullptr and keys by the default ratio).
+// use -- never inside a stream capture (hipMalloc / hipMemset would invalidate it): a launch whose stream is
+// capturing before the buffer exists gets nullptr (the order kernel keys by the default ratio, the waves report nothing)
+// and the next eager launch allocates it.
 #include <mutex>
 #include <stdlib.h>
 namespace gsr {
-float *gsr_job_stats_buffer() {
+float *gsr_job_stats_buffer(hipStream_t s) {
   static std::mutex mu;
   static float *table[64] = {nullptr};
   static bool failed[64] = {false};
@@ -107,6 +109,12 @@ float *gsr_job_stats_buffer() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
   if (table[dev] || failed[dev]) return table[dev];
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+    (void)hipGetLastError();  // (e.g. the legacy stream while another one captures)
+    return nullptr;
+  }
+  if (cap != hipStreamCaptureStatusNone) return nullptr;  // (not `failed`: the next eager launch allocates)
   void *p = nullptr;
   if (hipMalloc(&p, 1024) != hipSuccess || hipMemset(p, 0, 1024) != hipSuccess) {
     (void)hipGetLastError();

@@ -36,20 +36,8 @@
 #ifndef GSR_BWD_GROUP
 #define GSR_BWD_GROUP 4
 #endif
-#ifndef GSR_BWD_MIN_WAVES
-#define GSR_BWD_MIN_WAVES 1  // (A/B: 5 or 6 asks the compiler for <= 96 / 80 VGPRs, i.e. more resident waves per SIMD)
-#endif
-#ifndef GSR_BWD_FOLD_VALID
-#define GSR_BWD_FOLD_VALID 1
-#endif
-// How the 36 lane-partials of a group of four splats are summed over the wave's four rows of 16 lanes (A/B builds,
-// DESIGN.md section 4.21): 0 = v_permlane32_swap / v_permlane16_swap (27 swaps, 8.2 issue cycles each); 1 = on the
-// matrix pipe (36 v_mfma_f32_16x16x4_f32 with one-hot row selectors: K runs over the four rows); 2 = through LDS
-// (36 stores, 36 conflict-free loads, 27 adds); 3 = as 2, and the sum over a row's 16 lanes through LDS as well
-// (one lane per (splat, component) adds 16 values; one atomic instruction per group instead of two).
-#ifndef GSR_BWD_FOLD
-#define GSR_BWD_FOLD 0
-#endif
+// (the A/B variants of this kernel that lost -- the cross-row sum on the matrix pipe / through LDS, more resident waves,
+//  three selects instead of the validity fold -- live in tools/exp/bwd_variants.patch with their records)
 
 namespace {
 // measurement hook, see raster_fwd.hip
@@ -173,82 +161,6 @@ struct Butterfly<4> {
   }
 };
 
-// ---- the sum over the wave's four rows without permlane swaps (GSR_BWD_FOLD, A/B builds) ----------------------------
-// All three leave R[c] = sum over rows k of P[9 g + c] at lane 16 k + j, in lane (g, j) -- what fold32 + fold16 leave.
-typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kFoldValues = 20;  // values per LDS phase: components 0-4 of the four splats, then components 5-8
-
-// Matrix pipe: v_mfma_f32_16x16x4_f32 computes D[i][j] += sum_k A[i][k] B[k][j] with lane l = 16 k + j holding
-// A[l & 15][l >> 4], B[l >> 4][l & 15] and, in register r, D[4 (l >> 4) + r][l & 15].  B = the lane-partials of
-// one value as they lie, A = the one-hot selector of output row m (sel[m] = 1 in lanes with (l & 15) == m, for
-// every k): row m of D receives the sum over the four rows, column by column.  Value (splat s, component c) goes to
-// accumulator c / 4, row m = 4 s + c % 4, so that lane (g, j) ends with the nine components of splat g.
-// (1 x and 0 x are exact; a NaN / Inf partial would reach the other rows of its accumulator as 0 x Inf.)
-[[maybe_unused]] __device__ __forceinline__ void fold_rows_mfma(const float (&P)[36], const float (&sel)[16], float (&R)[9]) {
-  v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[4 * s + r], P[9 * s + r], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[4 * s + r], P[9 * s + 4 + r], acc1, 0, 0, 0);
-    }
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[4 * s], P[9 * s + 8], acc2, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) R[r] = acc0[r], R[4 + r] = acc1[r];
-  R[8] = acc2[0];
-}
-
-// LDS: value v of lane l at buf[80 v + l] (a stride of 80 words = 16 banks: the four rows of readers, whose values
-// are 5 (or 4) apart, fall into different 16-bank windows with immediate offsets only); lane (g, j) reads the four
-// rows' entries of its splat's values.  Two phases over one 6.4-KB buffer (16 waves per CU keep their LDS); a wave's
-// DS instructions execute in order, the barriers of this one-wave workgroup only pin the compiler.
-constexpr int kFoldStride = 80;
-constexpr int kFoldWords = kFoldStride * kFoldValues;
-[[maybe_unused]] __device__ __forceinline__ void fold_rows_lds(const float (&P)[36], float *buf, int lane, float (&R)[9]) {
-  const int g = lane >> 4, j = lane & 15;
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int c = 0; c < 5; ++c) buf[kFoldStride * (5 * s + c) + lane] = P[9 * s + c];
-  __syncthreads();
-  {
-    const float *v = buf + kFoldStride * 5 * g + j;
-#pragma unroll
-    for (int c = 0; c < 5; ++c)
-      R[c] = (v[kFoldStride * c] + v[kFoldStride * c + 16]) + (v[kFoldStride * c + 32] + v[kFoldStride * c + 48]);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) buf[kFoldStride * (4 * s + c) + lane] = P[9 * s + 5 + c];
-  __syncthreads();
-  {
-    const float *v = buf + kFoldStride * 4 * g + j;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      R[5 + c] = (v[kFoldStride * c] + v[kFoldStride * c + 16]) + (v[kFoldStride * c + 32] + v[kFoldStride * c + 48]);
-  }
-}
-
-// LDS for the row as well: R[c] of lane (g, j) at buf[176 g + 17 c + j] (17: the nine readers of a row start in
-// different banks; 176 = 16 mod 32: so do the rows); lane (g, c < 9) adds the 16 entries of component c.
-// -> the total of component (lane & 15) of splat lane >> 4, in lanes with (lane & 15) < 9.
-[[maybe_unused]] __device__ __forceinline__ float fold_lanes_lds(const float (&R)[9], float *buf, int lane) {
-  const int g = lane >> 4, j = lane & 15;
-  __syncthreads();  // (the readers of fold_rows_lds are done with the buffer)
-#pragma unroll
-  for (int c = 0; c < 9; ++c) buf[176 * g + 17 * c + j] = R[c];
-  __syncthreads();
-  const float *v = buf + 176 * g + 17 * (j < 9 ? j : 0);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-  for (int t = 0; t < 16; t += 4) a0 += v[t], a1 += v[t + 1], a2 += v[t + 2], a3 += v[t + 3];
-  return (a0 + a1) + (a2 + a3);
-}
-
 // G == 4 with a tenth component (RGBD): same lane roles for components 0-7, and
 // components 8, 9 of splat l>>4 in `extra_v`, `extra2_v` (all 16 lanes of the row).
 struct Butterfly4x10 {
@@ -344,7 +256,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(
 // segment as a product of segment products instead of one chain: equal to the single walk to rounding, not bitwise.
 
 template <int G, bool RGBD, bool SEG = false>
-__global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kernel(
+__global__ __launch_bounds__(64) void raster_bwd_tile16_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
     const float2 *__restrict__ xys, const float *__restrict__ conics,
@@ -367,8 +279,6 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
   __shared__ SplatC sC[kChunk];
   __shared__ int sId[kChunk];
   using BF = Butterfly<G>;
-  constexpr int kFold = (G == 4 && !RGBD) ? GSR_BWD_FOLD : 0;  // (the A/B variants exist for the default kernel only)
-  __shared__ float sFold[kFold >= 2 ? kFoldWords : 1];
 
   int2 range = make_int2(0, 0);
   unsigned blk = blockIdx.x;
@@ -384,7 +294,6 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
   const int tile = job.tile, allowed = job.allowed;  // allowed: the sub-tiles this wave owns (raster_common.h)
   if (tile < 0) return;
   const int trace_len = range.y - range.x;
-  job_priority(job, trace_len, deep_threshold);
   int seg_behind = 0;  // segments behind this one whose maps are applied first
   if constexpr (SEG) {
     const int len = range.y - range.x;
@@ -482,16 +391,12 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
   const int max_top = max(max(topp[0], topp[1]), max(topp[2], topp[3]));
 
   // lane-constant destination of the `main` value
-  // (kFold == 3: lane (g, c) owns component c < 9 of splat g, the opacity's among them)
-  const int comp = kFold == 3 ? (lane & 15) : BF::comp_of_lane(lane);
+  const int comp = BF::comp_of_lane(lane);
   float *const dst_base = comp < 2 ? v_xy : (comp < 5 ? v_conic : (comp < 8 ? v_colors : v_opacity));
   const int dst_stride = comp < 2 ? 2 : (comp < 8 ? 3 : 1);
   const int dst_off = comp < 2 ? comp : (comp < 5 ? comp - 2 : (comp < 8 ? comp - 5 : 0));
-  const bool owns_main = kFold == 3 ? comp < 9 : BF::owns_main(lane);
-  const bool owns_extra = kFold == 3 ? comp == 8 : BF::owns_extra(lane);
-  float fold_sel[16];  // kFold == 1: the one-hot row selectors of fold_rows_mfma
-#pragma unroll
-  for (int m = 0; m < 16; ++m) fold_sel[m] = (lane & 15) == m ? 1.f : 0.f;
+  const bool owns_main = BF::owns_main(lane);
+  const bool owns_extra = BF::owns_extra(lane);
   // lane-constant selectors of the moment -> gradient map for this lane's component
   const float sel_ha = comp == 0 ? 1.f : 0.f, sel_hc = comp == 1 ? 1.f : 0.f, sel_b = comp < 2 ? 1.f : 0.f;
   const float sel_no = (comp == 2 || comp == 4) ? 0.5f : (comp == 3 ? 1.f : 0.f);
@@ -557,16 +462,12 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
             const float vis0 = __expf(-sigma);
             const float alpha0 = fminf(GSR_ALPHA_MAX_BWD, B.opac * vis0);
             const bool valid = (C.sidx <= binf[p]) && !(sigma < 0.f || alpha0 < GSR_ALPHA_MIN);
-#if GSR_BWD_FOLD_VALID
             // An invalid (pixel, splat) pair runs the same arithmetic on alpha = vis = 0: ra = 1 / (1 - 0) = 1, T * 1 = T
             // and alpha * T = 0 EXACTLY, so T, K and every sum come out as with the three selects this replaces (two
             // v_cndmask, 4.2 issue cycles each on gfx950, instead of three: DESIGN.md section 4.17).  v_alpha stays finite
             // (T, K and the cotangents are: NaN cotangents of undrawn pixels were zeroed at the load), so 0 * v_alpha = 0.
             const float alpha = valid ? alpha0 : 0.f;
             const float vis = valid ? vis0 : 0.f;
-#else
-            const float alpha = alpha0, vis = vis0;
-#endif
             const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
             const float Tn = T[p] * ra;
             // sum_c (rgb_c*T - buffer_c*ra) v_out_c + T_final*ra*(v_out_alpha - bg.v_out)
@@ -576,15 +477,9 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
             float d = B.r * vr[p] + B.g * vg[p] + C.blue * vb[p];
             if constexpr (RGBD) d += C.extra * ve[p];  // (a literal "+ 0.f" in the 3-channel case is a real v_add: -0 semantics)
             const float v_alpha = Tn * d + ra * K[p];
-#if GSR_BWD_FOLD_VALID
             const float w = vis * v_alpha;
             const float fac = alpha * Tn;
             T[p] = Tn;
-#else
-            const float w = valid ? vis * v_alpha : 0.f;
-            const float fac = valid ? alpha * Tn : 0.f;
-            T[p] = valid ? Tn : T[p];
-#endif
             K[p] -= fac * d;
             sr += fac * vr[p];
             sg += fac * vg[p];
@@ -619,19 +514,8 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
       float main_v, extra_v, extra2_v = 0.f;
       if constexpr (RGBD) {
         Butterfly4x10::run(P, lane, main_v, extra_v, extra2_v);
-      } else if constexpr (kFold == 0) {
-        BF::run(P, lane, main_v, extra_v);
       } else {
-        float R[9];
-        if constexpr (kFold == 1) fold_rows_mfma(P, fold_sel, R);
-        else fold_rows_lds(P, sFold, lane, R);
-        if constexpr (kFold == 3) {
-          main_v = fold_lanes_lds(R, sFold, lane);
-          extra_v = main_v;  // (the lane with comp == 8 holds the opacity's sum as its main value)
-          __syncthreads();   // the next group's stores come after these loads
-        } else {
-          Butterfly<4>::finish(R, lane, main_v, extra_v);
-        }
+        BF::run(P, lane, main_v, extra_v);
       }
       // v_sigma = -opac * w:  v_xy = -opac (a Sx + b Sy, b Sx + c Sy),
       // v_conic = -opac (Sxx/2, Sxy, Syy/2),  v_rgb = the colour sums,  v_opacity = S0
@@ -650,15 +534,10 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
           // rows are summed per Gaussian in a fixed order by reduce_partials_kernel
           const int sx = sC[t].sidx;
           float *row = partials + (size_t)sx * kPartialStride;
-          if constexpr (kFold == 3) {
-            if (owns_main) row[comp] = grad;
-            if (owns_extra) pflags[sx] = 1;
-          } else {
           if (owns_main) row[comp] = grad;
           if (owns_extra) {
             row[8] = extra_v;
             pflags[sx] = 1;
-          }
           }
           if constexpr (RGBD) {
             if ((lane & 15) == 1) row[9] = extra2_v;
@@ -666,9 +545,7 @@ __global__ __launch_bounds__(64, GSR_BWD_MIN_WAVES) void raster_bwd_tile16_kerne
         } else {
         if (owns_main && grad != 0.f)
           unsafeAtomicAdd(dst_base + (size_t)g * dst_stride + dst_off, grad);
-        if constexpr (kFold != 3) {
-          if (owns_extra && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
-        }
+        if (owns_extra && extra_v != 0.f) unsafeAtomicAdd(v_opacity + g, extra_v);
         if constexpr (RGBD) {
           if ((lane & 15) == 1 && extra2_v != 0.f) unsafeAtomicAdd(v_extra + g, extra2_v);
         }

@@ -170,33 +170,8 @@ __device__ __forceinline__ TileJob tile_job(const unsigned b, const unsigned bas
   return j;
 }
 
-// ISSUE PRIORITY by estimated work (GSR_WAVE_PRIO): the longest jobs start first, but each then shares its SIMD with
-// up to seven (forward) or three (backward) co-residents, round robin -- tools/exp/wave_trace.py on the trained model:
-// the forward's span (188 us) IS the duration of the sub-tile waves of its longest tiles, started at t = 0 and given an
-// eighth of the issue slots all their life, while the launch's work would fit in ~115 us.  s_setprio (0-3, the SIMD's
-// arbiter prefers the higher) gives the critical walks the slots they can use -- one wave issues at most one VALU
-// instruction per ~5 cycles, so a preferred wave leaves most of the pipe to the others.  Tiers by effective length (a
-// sub-tile wave's list counts a quarter) against the launch's split threshold: > 1/2, > 1/4, > 1/8 of it.  Lists all
-// alike land in one tier: nothing changes for them.
-// MEASURED (profiles/r05_wave_priority_ab.txt, -DGSR_WAVE_PRIO=1 against the default build on one lease): nothing.
-// Trained model forward 0.187 -> 0.199 ms, backward 0.342 -> 0.337; long-tail cloud 0.290 / 0.587 -> 0.283 / 0.580;
-// the trainer's ball 0.322 / 0.549 -> 0.343 / 0.588; uniform, 4K, small grids, config 3's rate: within noise.  The
-// arbiter's preference does not turn into a shorter critical walk -- off by default, kept for the next attempt at
-// the forward's critical path (which is the depth segments' job, on every grid: DESIGN section 8).
-#ifndef GSR_WAVE_PRIO
-#define GSR_WAVE_PRIO 0
-#endif
-__device__ __forceinline__ void job_priority(const TileJob &j, const int len, const int deep_arg) {
-#if GSR_WAVE_PRIO
-  const int thr = gsr_deep_threshold(deep_arg);
-  if (thr <= 0) return;
-  const int eff = j.allowed == 15 ? len : (len >> 2);
-  if (8 * eff <= thr) return;
-  if (2 * eff > thr) __builtin_amdgcn_s_setprio(3);
-  else if (4 * eff > thr) __builtin_amdgcn_s_setprio(2);
-  else __builtin_amdgcn_s_setprio(1);
-#endif
-}
+// (s_setprio tiers by estimated work were built and measured -- no gain: tools/exp/wave_prio.patch,
+//  profiles/r05_wave_priority_ab.txt)
 
 // The job order of one launch: one workgroup of 1024 lanes per XCD.  Items: every tile the static map gives this XCD
 // -- one job (tile, 15) keyed by its list length, or, above the threshold, four jobs (tile, 1 << p) keyed by
@@ -222,7 +197,7 @@ __device__ __forceinline__ int job_bucket(const int key) {  // larger keys -> sm
 // instructions -- the butterfly per sub-tile wave -- and it loses what the drain gains.)
 // The sort is STABLE and deterministic: inside a bucket the jobs keep the static map's order (ranks by wave-wide key
 // matching, a per-(wave chunk, bucket) table, one prefix down the chunks) -- spatial neighbours stay neighbours in time.
-constexpr int kJobChunks = 64;  // wave chunks of 64 slots per XCD: up to 4 096 tiles per XCD (32 768 tiles: 8K x 4K)
+constexpr int kJobChunks = 64;  // wave chunks of 64 slots per XCD: up to 4 096 tile slots per XCD (32 768 in all: 3840 x 2160 is 32 400 tiles)
 static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_x, const int tiles_y,
                                                                 const unsigned base_grid,
                                                                 const int2 *__restrict__ tile_bins,
@@ -410,7 +385,7 @@ static __global__ __launch_bounds__(1024) void tile_jobs_kernel(const int tiles_
   }
 }
 
-float *gsr_job_stats_buffer();  // capi.hip: this device's JobStats[2] (nullptr if it cannot be had)
+float *gsr_job_stats_buffer(hipStream_t s);  // capi.hip: this device's JobStats[2] (nullptr if it cannot be had)
 float gsr_job_split_ratio();    // capi.hip: GSR_DEEP_SPLIT_KEY (0 = measured)
 
 // (host) build the job order behind tile_bins when deep_arg asks for it (and gsr_tile_jobs_build has not already);
@@ -423,7 +398,7 @@ static inline int gsr_prepare_jobs(const int deep_arg, const int tiles_x, const 
   if (deep_arg & GSR_DEEP_PREBUILT) return deep_arg;
   int *jobs = const_cast<int *>(tile_bins) + 2 * (size_t)tiles_x * tiles_y;
   hipLaunchKernelGGL(tile_jobs_kernel, dim3(8), dim3(1024), 0, s, tiles_x, tiles_y, base,
-                     reinterpret_cast<const int2 *>(tile_bins), deep_arg, 0, jobs, gsr_job_stats_buffer(),
+                     reinterpret_cast<const int2 *>(tile_bins), deep_arg, 0, jobs, gsr_job_stats_buffer(s),
                      gsr_job_split_ratio());
   return deep_arg;
 }

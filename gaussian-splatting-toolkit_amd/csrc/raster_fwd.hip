@@ -48,13 +48,18 @@ __device__ gsr::WaveTrace g_fwd_trace = {nullptr, 0u};
 // RGBD: a fourth channel (one scalar per Gaussian, e.g. its depth) is composited in the
 // same pass into its own [H,W] image over background `bg_extra` (the
 // models run a second full pass for the depth image, vanilla_gs.py:840-855).
-// ---- depth segments ------------------------------------------------------------------
+// ---- depth segments (one walk since round 6) ------------------------------------------------------
 // On a tile grid that cannot fill the chip the kernel lasts as long as its deepest tile's serial walk.  The list of a
-// tile that is split over four waves is therefore also cut into up to `seg_count` runs: a PRE-PASS
-// (raster_fwd_segtau_kernel) computes, per pixel, the transmittance product of every run but the last; run k then
-// starts from the product of the runs in front of it and composites its own entries with the unchanged rule -- the
-// stop test `T (1 - alpha) <= 1e-4` sees the true incoming T -- leaving its RAW state (colour sums, signed T, last
-// drawn index); a combine pass adds the runs' colours in list order up to the run in which the pixel finished.
+// tile that is split over four waves is therefore also cut into up to `seg_count` runs, and compositing is ASSOCIATIVE in
+// (C, T): a run walked from T = 1 yields its colour sums C_k and its transmittance product P_k, and the pixel is
+// C = sum_k (prod_{j<k} P_j) C_k.  Every run is walked ONCE, from T = 1, by its own wave (raster_fwd_tile16_kernel<.,
+// true>), leaving its raw state (colour sums, signed T, last drawn index).  raster_fwd_segresolve_kernel then, per
+// pixel, multiplies the prefixes and finds the first run k* in which  prefix x P_k  comes down to the stop rule's 1e-4
+// (or which finished on its own): in front of k* no splat can have tripped `T (1 - alpha) <= 1e-4` (T only falls), so
+// those runs' sums enter scaled by their prefix; from the start of run k* a wave of its own RE-WALKS the list with the
+// true incoming T -- the unchanged rule, the exact stop and final_idx (forward.cu:360-380) -- for the pixels that
+// cross there (raster_fwd_segrewalk_kernel: one block per flagged (sub-tile, run), the runs in parallel).  A translucent model (what the small grids of the coarse-to-fine schedule render) almost never crosses: one
+// walk.  Rounds 4-5 walked every list twice (a transmittance pre-pass, then the runs from their true T).
 // Equal to the single walk to rounding (T and C are sums / products of run-wise partial results), not bitwise.
 
 template <bool RGBD, bool SEG = false>
@@ -68,8 +73,8 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     const float bg_extra, float *__restrict__ out_extra, const int deep_threshold, const unsigned base_grid,
     float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr, const unsigned zero_words,
     const int round, int *__restrict__ tile_flags, const int idx_base, const int seg_count = 1, const int seg_min = 0,
-    const float *__restrict__ seg_tau = nullptr, float4 *__restrict__ seg_raw = nullptr,
-    int *__restrict__ seg_last = nullptr, float *__restrict__ seg_extra = nullptr) {
+    float4 *__restrict__ seg_raw = nullptr, int *__restrict__ seg_last = nullptr,
+    float *__restrict__ seg_extra = nullptr) {
   // Two-round compositing (gsr_rasterize_forward_round): the lists of the nearest
   // Gaussians are a PREFIX of every tile's list.  round 1 composites such prefix lists and leaves the per-pixel
   // state of a wave that still has a live pixel RAW -- final_Ts = signed T (< 0: finished), out_img / out_extra = C
@@ -105,7 +110,6 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   int allowed = job.allowed;
   if (tile < 0) return;
   const int trace_len = range.y - range.x;
-  job_priority(job, trace_len, deep_threshold);
   bool split = false;
   if constexpr (SEG) {
     const int len = range.y - range.x;
@@ -151,17 +155,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       if constexpr (RGBD) ce[p] = out_extra[pid];
       last[p] = final_idx[pid];
     }
-    if constexpr (SEG) {
-      if (split && inside && seg_k > 0) {  // the transmittance the runs in front of this one leave (0: finished
-        // there): ONE load -- raster_fwd_segprefix_kernel has turned the runs' products into prefix products
-        const size_t pixels = (size_t)img_w * img_h, pid = (size_t)row * img_w + col;
-        // (a prefix of 0 -- the pixel finished in front of this run: raster_fwd_segprefix_kernel -- enters DEAD, with a
-        //  negative marker, so that the combine pass sees a finished pixel here even if rounding kept the run that
-        //  really finished it from noticing)
-        const float tin = seg_tau[(size_t)(seg_k - 1) * pixels + pid];
-        T[p] = tin > 0.f ? tin : -1.17549435e-38f;
-      }
-    }
+    // (SEG: every run starts from T = 1 -- raster_fwd_segresolve_kernel scales its sums by the runs in front of it)
   }
 
   // sub-tiles that still have a live pixel (wave-uniform)
@@ -307,14 +301,113 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   job_stats_end(job, 0, stats_t0, trace_len);
 }
 
-// Pre-pass of the depth segments: the transmittance product of run seg_k = block / (4 base_grid) (every run but a
-// tile's last) for the pixels of a split tile's sub-tile -> seg_tau[seg_k pixels + pixel]; 0 = the pixel finishes
-// inside this run even when it enters it with T = 1 (then it finishes there, or earlier, for any incoming T).
-__global__ __launch_bounds__(64) void raster_fwd_segtau_kernel(
+// The crossing test's margin: prefix x P_k against 1e-4 (1 + margin).  The single walk's T at the end of run k and the
+// product of run products differ by rounding (~1e-7 per factor); a pixel within the margin is re-walked from the start
+// of that run with its true incoming T, and the re-walk -- the unchanged rule -- is the arbiter.
+#define GSR_SEG_CROSS (GSR_T_EPS * 1.001f)
+
+// Resolve pass of the depth segments: one wave per (split tile, sub-tile), lane = one pixel of the 8x8 sub-tile.  Per
+// pixel, over the runs in list order: prefix = product of the runs' T in front of run k; the FIRST run whose own walk
+// finished (signed T < 0) or whose prefix x T falls to the stop rule's threshold is the pixel's crossing run k*; the
+// colour sums of the runs in front of k* enter scaled by their prefix, `last` is the largest drawn index.
+//  * a pixel without a crossing run is FINAL here: C = the scaled sums, T = the full product;
+//  * the others leave their state at the start of k* -- (C so far, incoming T) in the pixel's record of run 0, the
+//    last drawn index and the extra channel's sum likewise, k* in `seg_kstar` (-1: final) -- and the wave leaves the
+//    set of crossing runs of its sub-tile as a bit mask in seg_flags[4 tile + sub-tile]: what the re-walk launch reads.
+template <bool RGBD>
+__global__ __launch_bounds__(64) void raster_fwd_segresolve_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h, const int2 *__restrict__ tile_bins,
+    const float *__restrict__ background, float *__restrict__ out_img, float *__restrict__ final_Ts,
+    int *__restrict__ final_idx, const float bg_extra, float *__restrict__ out_extra, const int deep_threshold,
+    const unsigned base_grid, float *__restrict__ out_alpha, const int seg_count, const int seg_min,
+    float4 *__restrict__ seg_raw, int *__restrict__ seg_last, float *__restrict__ seg_extra,
+    int *__restrict__ seg_kstar, int *__restrict__ seg_flags) {
+  int2 range = make_int2(0, 0);
+  const TileJob job = tile_job(blockIdx.x, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
+  const int tile = job.tile, allowed = job.allowed;
+  if (tile < 0) return;
+  const int len = range.y - range.x;
+  if (allowed == 15 || len <= seg_min) return;  // not split: the run kernel's block 0 wrote the final values
+  const int sl = seg_len_of(len, seg_count);
+  const int nseg = min(seg_count, (len + sl - 1) / sl);
+  const int sub = __builtin_ctz(allowed);
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int lane = threadIdx.x;
+  const int col = tx * 16 + 8 * (sub & 1) + (lane & 7), row = ty * 16 + 8 * (sub >> 1) + (lane >> 3);
+  const bool inside = col < img_w && row < img_h;
+  const size_t pixels = (size_t)img_w * img_h, pid = inside ? (size_t)row * img_w + col : 0;
+
+  float cr = 0.f, cg = 0.f, cb = 0.f, ce = 0.f, prefix = 1.f;
+  int last = 0, kstar = -1;
+  for (int k = 0; k < nseg; ++k) {  // (nseg is wave-uniform; the loads do not depend on one another)
+    const float4 r = seg_raw[(size_t)k * pixels + pid];
+    const int l = seg_last[(size_t)k * pixels + pid];
+    float e = 0.f;
+    if constexpr (RGBD) e = seg_extra[(size_t)k * pixels + pid];
+    const bool open = kstar < 0;
+    const bool cross = open && (r.w < 0.f || prefix * r.w <= GSR_SEG_CROSS);
+    kstar = cross ? k : kstar;
+    const bool take = open && !cross;
+    const float w = take ? prefix : 0.f;
+    cr += w * r.x;
+    cg += w * r.y;
+    cb += w * r.z;
+    if constexpr (RGBD) ce += w * e;
+    last = take ? max(last, l) : last;
+    prefix = take ? prefix * r.w : prefix;  // stays at the crossing run's incoming T
+  }
+  if (!inside) kstar = -1;  // (a lane outside the image read pixel 0's records: nothing of it is used)
+  unsigned mask = kstar >= 0 ? (1u << kstar) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mask |= __shfl_xor(mask, o);
+  if (lane == 0) seg_flags[4 * tile + sub] = (int)mask;
+  if (!inside) return;
+  seg_kstar[pid] = kstar;
+  if (kstar >= 0) {
+    seg_raw[pid] = make_float4(cr, cg, cb, prefix);
+    seg_last[pid] = last;
+    if constexpr (RGBD) seg_extra[pid] = ce;
+    return;
+  }
+  final_Ts[pid] = prefix;
+  if (out_alpha) out_alpha[pid] = 1.f - prefix;
+  final_idx[pid] = last;
+  out_img[3 * pid] = cr + prefix * background[0];
+  out_img[3 * pid + 1] = cg + prefix * background[1];
+  out_img[3 * pid + 2] = cb + prefix * background[2];
+  if constexpr (RGBD) out_extra[pid] = ce + prefix * bg_extra;
+}
+
+// sigma in the operation order of the tile16 kernel's compiled code, pinned: two products each way, their ROUNDED sum,
+// one fused multiply-add for the cross term -- left to the compiler the single-pixel form contracts `ax + cy` into an
+// fma (cy is used once here, twice there) and sigma comes out one ulp apart.
+__device__ __forceinline__ float sigma_in_tile16_order(const float ha, const float b, const float hc, const float dx,
+                                                       const float dy) {
+#pragma clang fp contract(off)
+  const float ax = (ha * dx) * dx;
+  const float cy = (hc * dy) * dy;
+  const float s = ax + cy;
+  const float bx = b * dx;
+  return __builtin_fmaf(bx, dy, s);
+}
+
+// Re-walk of the depth segments: block = run * (4 base_grid) + the (tile, sub-tile) block of the unsegmented launch; it
+// leaves at once unless the resolve pass flagged its run for its sub-tile.  Its pixels are those whose crossing run is
+// THIS run: they start from the state the resolve pass left (the sums of the runs in front, the true incoming T, > 1e-4
+// by construction) and are composited with the unchanged rule from the start of the run until they finish -- normally
+// inside the run; a pixel the margin flagged for nothing simply walks on with its true T, to the end of the list if
+// need be.  Every crossing pixel is finished by exactly one block.  The per-splat expressions are those of
+// raster_fwd_tile16_kernel, operand for operand.
+template <bool RGBD>
+__global__ __launch_bounds__(64) void raster_fwd_segrewalk_kernel(
     const int tiles_x, const int num_tiles, const int img_w, const int img_h, const int *__restrict__ ids_sorted,
     const int2 *__restrict__ tile_bins, const float2 *__restrict__ xys, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const int deep_threshold,
-    const unsigned base_grid, const int seg_count, const int seg_min, float *__restrict__ seg_tau) {
+    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ background,
+    float *__restrict__ out_img, float *__restrict__ final_Ts, int *__restrict__ final_idx,
+    const float *__restrict__ extra, const float bg_extra, float *__restrict__ out_extra, const int deep_threshold,
+    const unsigned base_grid, float *__restrict__ out_alpha, const int seg_count, const int seg_min,
+    const float4 *__restrict__ seg_raw, const int *__restrict__ seg_last, const float *__restrict__ seg_extra,
+    const int *__restrict__ seg_kstar, const int *__restrict__ seg_flags) {
   __shared__ SplatA sA[kChunk];
   __shared__ SplatB sB[kChunk];
   __shared__ SplatC sC[kChunk];
@@ -327,148 +420,64 @@ __global__ __launch_bounds__(64) void raster_fwd_segtau_kernel(
   if (tile < 0) return;
   const int len = range.y - range.x;
   if (allowed == 15 || len <= seg_min) return;
+  const int sub = __builtin_ctz(allowed);
+  if (!((seg_flags[4 * tile + sub] >> seg_k) & 1)) return;
   const int sl = seg_len_of(len, seg_count);
-  if (seg_k >= min(seg_count, (len + sl - 1) / sl) - 1) return;  // (nobody needs the last run's product)
-  range.x += seg_k * sl;
-  range.y = min(range.x + sl, range.y);
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int lane = threadIdx.x;
-  const int qx = tx * 16 + (lane & 7), qy = ty * 16 + (lane >> 3);
-  const float fx0 = (float)qx, fx1 = (float)(qx + 8);
-  const float fy0 = (float)qy, fy1 = (float)(qy + 8);
+  const int col = tx * 16 + 8 * (sub & 1) + (lane & 7), row = ty * 16 + 8 * (sub >> 1) + (lane >> 3);
+  const bool inside = col < img_w && row < img_h;
+  const size_t pid = inside ? (size_t)row * img_w + col : 0;
+  const float fx = (float)col, fy = (float)row;
   const float tx0 = (float)(tx * 16), ty0 = (float)(ty * 16);
-  float T[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
-    T[p] = (col < img_w && row < img_h && ((allowed >> p) & 1)) ? 1.f : -1.f;
-  }
-  auto live_subtiles = [&]() {
-    int m = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) m |= __any(T[p] > 0.f) ? (1 << p) : 0;
-    return m;
-  };
-  int live = live_subtiles();
-  for (int base = range.x; base < range.y && live != 0; base += kChunk) {
+  const bool mine = inside && seg_kstar[pid] == seg_k;
+  const float4 st = seg_raw[pid];
+  float cr = st.x, cg = st.y, cb = st.z, ce = 0.f;
+  float T = mine ? st.w : -1.f;
+  int last = seg_last[pid];
+  if constexpr (RGBD) ce = seg_extra[pid];
+  bool live = __any(T > 0.f);
+  for (int base = range.x + seg_k * sl; base < range.y && live; base += kChunk) {
     const int sidx = base + lane;
-#if GSR_STAGE_AHEAD
-    const int count = stage_chunk_flat(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics, nullptr, opacities,
-                                       sA, sB, sC, nullptr, allowed);
-#else
-    const int count = stage_chunk(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics, colors, opacities, sA,
-                                  sB, sC, nullptr, nullptr, nullptr, allowed);
-#endif
+    const int count = stage_chunk_flat(lane, sidx < range.y, sidx, tx0, ty0, ids_sorted, xys, conics, colors, opacities, sA,
+                                       sB, sC, RGBD ? extra : nullptr, allowed);
     __syncthreads();
     for (int t = 0; t < count; ++t) {
-      if ((t & 7) == 7) {
-        live = live_subtiles();
-        if (live == 0) break;
-      }
-      const SplatC C = sC[t];
-      const int m = C.mask & live;
-      if (m == 0) continue;
+      if ((t & 7) == 7 && !__any(T > 0.f)) break;
       const SplatA A = sA[t];
       const SplatB B = sB[t];
-      const float dx0 = A.x - fx0, dx1 = A.x - fx1;
-      const float dy0 = A.y - fy0, dy1 = A.y - fy1;
-      const float ax0 = A.ha * dx0 * dx0, ax1 = A.ha * dx1 * dx1;
-      const float cy0 = B.hc * dy0 * dy0, cy1 = B.hc * dy1 * dy1;
-      const float bx0 = A.b * dx0, bx1 = A.b * dx1;
-      const float sig[4] = {(ax0 + cy0) + bx0 * dy0, (ax1 + cy0) + bx1 * dy0,
-                            (ax0 + cy1) + bx0 * dy1, (ax1 + cy1) + bx1 * dy1};
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        if (!(m & (1 << p))) continue;
-        const float sigma = sig[p];
-        const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
-        const float Tp = T[p];
-        const float next_T = Tp * (1.f - alpha);
-        const bool hit = !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
-        const bool go = next_T > GSR_T_EPS;
-        const float dead = __uint_as_float(__float_as_uint(Tp) | 0x80000000u);
-        T[p] = hit ? (go ? next_T : dead) : Tp;
-      }
+      const SplatC C = sC[t];
+      const float dx = A.x - fx, dy = A.y - fy;
+      const float sigma = sigma_in_tile16_order(A.ha, A.b, B.hc, dx, dy);
+      const float alpha = fminf(GSR_ALPHA_MAX_FWD, B.opac * __expf(-sigma));
+      const float Tp = T;
+      const float next_T = Tp * (1.f - alpha);
+      const bool hit = !(sigma < 0.f || alpha < GSR_ALPHA_MIN);
+      const bool go = next_T > GSR_T_EPS;
+      const bool draw = hit && go;
+      const float dead = __uint_as_float(__float_as_uint(Tp) | 0x80000000u);  // -|T|
+      const float upd = go ? next_T : dead;
+      const float vis = draw ? alpha * Tp : 0.f;
+      cr += B.r * vis;
+      cg += B.g * vis;
+      cb += C.blue * vis;
+      if constexpr (RGBD) ce += C.extra * vis;
+      last = draw ? C.sidx : last;
+      T = hit ? upd : Tp;
     }
     __syncthreads();
-    live = live_subtiles();
+    live = __any(T > 0.f);
   }
-  const size_t pixels = (size_t)img_w * img_h;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int col = qx + 8 * (p & 1), row = qy + 8 * (p >> 1);
-    if (col < img_w && row < img_h && ((allowed >> p) & 1))
-      seg_tau[(size_t)seg_k * pixels + (size_t)row * img_w + col] = T[p] > 0.f ? T[p] : 0.f;
+  if (mine) {
+    const float Tp = fabsf(T);
+    final_Ts[pid] = Tp;
+    if (out_alpha) out_alpha[pid] = 1.f - Tp;
+    final_idx[pid] = last;
+    out_img[3 * pid] = cr + Tp * background[0];
+    out_img[3 * pid + 1] = cg + Tp * background[1];
+    out_img[3 * pid + 2] = cb + Tp * background[2];
+    if constexpr (RGBD) out_extra[pid] = ce + Tp * bg_extra;
   }
-}
-
-// Between the pre-pass and the runs: per pixel of a split tile, the runs' products tau_0 .. tau_{n-2} become the prefix
-// products P_1 .. P_{n-1} in place (P_k = tau_0 ... tau_{k-1}, multiplied in list order: what run k starts from).  A
-// wave of run k then needs one load per pixel instead of k dependent ones -- 15 L2 round trips per pixel for the
-// last of 16 runs, more than its whole walk takes.
-__global__ __launch_bounds__(256) void raster_fwd_segprefix_kernel(
-    const int tiles_x, const int img_w, const int img_h, const int2 *__restrict__ tile_bins, const int deep_threshold,
-    const int seg_count, const int seg_min, float *__restrict__ seg_tau) {
-  const size_t pixels = (size_t)img_w * img_h;
-  const size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= pixels) return;
-  const int row = (int)(pid / img_w), col = (int)(pid - (size_t)row * img_w);
-  const int2 range = tile_bins[(row >> 4) * tiles_x + (col >> 4)];
-  const int len = range.y - range.x;
-  if (!(deep_threshold > 0 && len > deep_threshold) || len <= seg_min) return;
-  const int sl = seg_len_of(len, seg_count);
-  const int nseg = min(seg_count, (len + sl - 1) / sl);
-  float t = 1.f;
-  for (int k = 0; k + 1 < nseg; ++k) {
-    float *q = seg_tau + (size_t)k * pixels + pid;
-    t *= *q;
-    // The single walk never carries T <= 1e-4 (the splat that would take it there is not drawn: the pixel finishes
-    // in front of it), so a prefix that small means "finished in an earlier run" -- written as 0: the runs behind skip
-    // the pixel instead of walking it from a denormal T, and a prefix can no longer underflow into a +0 that is
-    // neither live nor finished.
-    if (t <= GSR_T_EPS) t = 0.f;
-    *q = t;
-  }
-}
-
-// Combine pass of the depth segments: one thread per pixel of a split tile adds the runs' colour sums in list order
-// up to and including the run in which the pixel finished (signed T < 0), takes that run's T and the largest drawn
-// index, and writes the final values as the single walk does.
-__global__ __launch_bounds__(256) void raster_fwd_segcombine_kernel(
-    const int tiles_x, const int img_w, const int img_h, const int2 *__restrict__ tile_bins,
-    const float *__restrict__ background, const int deep_threshold, const int seg_count, const int seg_min,
-    const float4 *__restrict__ seg_raw, const int *__restrict__ seg_last, float *__restrict__ out_img,
-    float *__restrict__ final_Ts, int *__restrict__ final_idx, float *__restrict__ out_alpha,
-    const float *__restrict__ seg_extra, const float bg_extra, float *__restrict__ out_extra) {
-  const size_t pixels = (size_t)img_w * img_h;
-  const size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= pixels) return;
-  const int row = (int)(pid / img_w), col = (int)(pid - (size_t)row * img_w);
-  const int2 range = tile_bins[(row >> 4) * tiles_x + (col >> 4)];
-  const int len = range.y - range.x;
-  if (!(deep_threshold > 0 && len > deep_threshold) || len <= seg_min) return;
-  const int sl = seg_len_of(len, seg_count);
-  const int nseg = min(seg_count, (len + sl - 1) / sl);
-  float cr = 0.f, cg = 0.f, cb = 0.f, ce = 0.f, T = 1.f;
-  int last = 0;
-  for (int k = 0; k < nseg; ++k) {
-    const float4 r = seg_raw[(size_t)k * pixels + pid];
-    cr += r.x;
-    cg += r.y;
-    cb += r.z;
-    if (seg_extra) ce += seg_extra[(size_t)k * pixels + pid];
-    T = r.w;
-    last = max(last, seg_last[(size_t)k * pixels + pid]);
-    if (T < 0.f) break;
-  }
-  const float Tp = fabsf(T);
-  final_Ts[pid] = Tp;
-  if (out_alpha) out_alpha[pid] = 1.f - Tp;
-  final_idx[pid] = last;
-  out_img[3 * pid] = cr + Tp * background[0];
-  out_img[3 * pid + 1] = cg + Tp * background[1];
-  out_img[3 * pid + 2] = cb + Tp * background[2];
-  if (seg_extra) out_extra[pid] = ce + Tp * bg_extra;
 }
 
 // ------------------------------------------------------------- scan mapping
@@ -775,9 +784,10 @@ GSR_EXPORT int gsr_rasterize_forward_ex(int tiles_x, int tiles_y, unsigned block
 GSR_EXPORT size_t gsr_rasterize_forward_seg_workspace_bytes(unsigned img_height, unsigned img_width, int segments) {
   if (segments < 2) return 0;
   const size_t px = (size_t)img_height * img_width;
-  // run products (segments - 1 floats, padded to 16 bytes) | raw states (segments float4) | last drawn indices |
-  // the extra channel's sums
-  return (((size_t)(segments - 1) * px * 4 + 15) & ~(size_t)15) + (size_t)segments * px * (16 + 4 + 4);
+  const size_t tiles = (size_t)gsr_cdiv(img_width, 16) * gsr_cdiv(img_height, 16);
+  // per run: raw states (float4) | last drawn indices | the extra channel's sums; then per pixel its crossing run,
+  // per (tile, sub-tile) the mask of runs to re-walk
+  return (size_t)segments * px * (16 + 4 + 4) + px * 4 + tiles * 16;
 }
 
 GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
@@ -819,32 +829,34 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
   deep_tile_threshold = gsr_deep_threshold(deep_tile_threshold);
   const int seg_min = segment_min_entries > deep_tile_threshold ? segment_min_entries : deep_tile_threshold;
   char *ws = static_cast<char *>(workspace);
-  float *tau = reinterpret_cast<float *>(ws);
-  float4 *raw = reinterpret_cast<float4 *>(ws + (((size_t)(segments - 1) * px * 4 + 15) & ~(size_t)15));
-  int *lastp = reinterpret_cast<int *>(reinterpret_cast<char *>(raw) + (size_t)segments * px * 16);
-  float *extrap = extra ? reinterpret_cast<float *>(lastp + (size_t)segments * px) : nullptr;
-  hipLaunchKernelGGL(raster_fwd_segtau_kernel, dim3((unsigned)(segments - 1) * 4u * base), dim3(64), 0, s, tiles_x,
-                     num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
-                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
-                     opacities, deep_arg, base, segments, seg_min, tau);
-  hipLaunchKernelGGL(raster_fwd_segprefix_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, tiles_x,
-                     (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), deep_tile_threshold,
-                     segments, seg_min, tau);
+  float4 *raw = reinterpret_cast<float4 *>(ws);
+  int *lastp = reinterpret_cast<int *>(ws + (size_t)segments * px * 16);
+  float *extrap = reinterpret_cast<float *>(lastp + (size_t)segments * px);  // (written and read with `extra` only)
+  int *kstarp = reinterpret_cast<int *>(extrap + (size_t)segments * px);
+  int *flagsp = kstarp + px;
 #define GSR_LAUNCH_FWD_SEG(RGBD_)                                                                                       \
   hipLaunchKernelGGL((raster_fwd_tile16_kernel<RGBD_, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,      \
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,   \
                      opacities, background, out_img, final_Ts, final_idx, extra, extra_background, out_extra,           \
                      deep_arg, base, out_alpha, static_cast<unsigned *>(zero_ptr),                                       \
-                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, (const float *)tau, raw,      \
-                     lastp, extrap)
-  if (extra) GSR_LAUNCH_FWD_SEG(true);
-  else GSR_LAUNCH_FWD_SEG(false);
+                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, raw, lastp, extrap);          \
+  hipLaunchKernelGGL(raster_fwd_segresolve_kernel<RGBD_>, dim3(4u * base), dim3(64), 0, s, tiles_x, num_tiles,          \
+                     (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), background, out_img,    \
+                     final_Ts, final_idx, extra_background, out_extra, deep_arg, base, out_alpha, segments, seg_min,    \
+                     raw, lastp, extrap, kstarp, flagsp);                                                                \
+  hipLaunchKernelGGL(raster_fwd_segrewalk_kernel<RGBD_>, dim3((unsigned)segments * 4u * base), dim3(64), 0, s,          \
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,   \
+                     opacities, background, out_img, final_Ts, final_idx, extra, extra_background, out_extra, deep_arg, \
+                     base, out_alpha, segments, seg_min, (const float4 *)raw, (const int *)lastp,                       \
+                     (const float *)extrap, (const int *)kstarp, (const int *)flagsp)
+  if (extra) {
+    GSR_LAUNCH_FWD_SEG(true);
+  } else {
+    GSR_LAUNCH_FWD_SEG(false);
+  }
 #undef GSR_LAUNCH_FWD_SEG
-  hipLaunchKernelGGL(raster_fwd_segcombine_kernel, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, s, tiles_x,
-                     (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), background,
-                     deep_tile_threshold, segments, seg_min, (const float4 *)raw, (const int *)lastp, out_img, final_Ts,
-                     final_idx, out_alpha, (const float *)extrap, extra_background, out_extra);
   GSR_CHECK_LAUNCH("rasterize_forward_seg");
   return GSR_OK;
 }
@@ -939,8 +951,12 @@ GSR_EXPORT int gsr_rasterize_forward_round(int round, int tiles_x, int tiles_y, 
 }
 
 GSR_EXPORT size_t gsr_tile_jobs_ints(int tiles_x, int tiles_y) {
-  // two arrays of 4 base_grid + the address of the statistics
-  return tiles_x > 0 && tiles_y > 0 ? 8 * (size_t)gsr_xcd_grid(tiles_x, tiles_y) + 2 : 0;
+  // two arrays of 4 base_grid + the address of the statistics; 0 = this grid has no job order (beyond the sort's
+  // tables -- more than 4 096 tile slots per XCD, i.e. above 3840 x 2160: the launches run in the static order)
+  if (tiles_x <= 0 || tiles_y <= 0) return 0;
+  const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
+  if (base / 8u > (unsigned)gsr::kJobChunks * 64u) return 0;
+  return 8 * (size_t)base + 2;
 }
 
 GSR_EXPORT int gsr_tile_jobs_build(int tiles_x, int tiles_y, int32_t *tile_bins, int deep_arg_first, int deep_arg_second,
@@ -951,11 +967,13 @@ GSR_EXPORT int gsr_tile_jobs_build(int tiles_x, int tiles_y, int32_t *tile_bins,
   GSR_REQUIRE(deep_arg_second <= 0 || gsr_deep_second(deep_arg_first) != gsr_deep_second(deep_arg_second),
               "tile_jobs_build: both orders name the same array");
   const unsigned base = gsr_xcd_grid(tiles_x, tiles_y);
-  GSR_REQUIRE(base / 8u <= (unsigned)gsr::kJobChunks * 64u, "tile_jobs_build: tile grid beyond the sort's tables");
+  // beyond the sort's tables (4096 x 2160 and larger): nothing to build -- gsr_prepare_jobs hands such a grid's launches
+  // the plain threshold before it looks at GSR_DEEP_PREBUILT, and nobody reads the tail
+  if (base / 8u > (unsigned)gsr::kJobChunks * 64u) return GSR_OK;
   int *jobs = tile_bins + 2 * (size_t)tiles_x * tiles_y;
   hipLaunchKernelGGL(gsr::tile_jobs_kernel, dim3(deep_arg_second > 0 ? 16 : 8), dim3(1024), 0, (hipStream_t)stream, tiles_x,
                      tiles_y, base, reinterpret_cast<const int2 *>(tile_bins), deep_arg_first, deep_arg_second, jobs,
-                     gsr::gsr_job_stats_buffer(), gsr::gsr_job_split_ratio());
+                     gsr::gsr_job_stats_buffer((hipStream_t)stream), gsr::gsr_job_split_ratio());
   GSR_CHECK_LAUNCH("tile_jobs_build");
   return GSR_OK;
 }

@@ -85,9 +85,12 @@ def render_view(
     )
     if caller_syncs and (radii).sum() == 0:  # vanilla_gs.py:784-794: nothing on screen, the background
         rgb = background.repeat(H, W, 1)
+        # (`depth_acc`: the accumulated, un-normalised depth the fused depth loss takes together with the alpha -- zeros
+        #  over a zero alpha, so that loss trains on the reference's constant image for this view instead of meeting a
+        #  None)
         return {"rgb": rgb, "alpha": background.new_zeros(H, W, 1), "depth": background.new_ones(H, W, 1) * 10,
-                "depth_acc": None, "xys": xys, "radii": radii, "depths": depths, "conics": conics, "num_tiles_hit": num_tiles_hit,
-                "rgbs": None}
+                "depth_acc": background.new_zeros(H, W, 1), "xys": xys, "radii": radii, "depths": depths, "conics": conics,
+                "num_tiles_hit": num_tiles_hit, "rgbs": None}
     if retain_xys_grad and xys.requires_grad:
         xys.retain_grad()  # densification reads xys.grad (vanilla_gs.py:352-353,797-798)
 

@@ -385,6 +385,7 @@ class TrainConfig:
     # gradient is all-reduced.  "views" needs the hook-driven exchange and the separate-ops render path.
     sh_exchange: str = "views"
     phase_every: int = 0                  # HIP events around render / loss / backward / optimizer on every k-th iteration
+    phase_series: bool = False            # also return every sample (`phase_ms_series`: step, resolution divisor, 4 phases)
     scene_scale: tuple = (0.01, 0.06)     # range of the truth's Gaussian scales
     tex_cell: float = 0.04                # scene "objects": checker cell size in scene units
     scene_objects: tuple = (48, 0.18, 0.45)  # scene "objects": number of spheres, radius range
@@ -909,8 +910,10 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
     finally:
         gc.unfreeze()
     psnr1 = evaluate()
-    phases = phases_by_res = phases_by_depth = None
+    phases = phases_by_res = phases_by_depth = phase_series = None
     if phase_marks:
+        if cfg.phase_series:
+            phase_series = [[dd] + [round(m[i].elapsed_time(m[i + 1]), 4) for i in range(4)] for dd, m, _ in phase_marks]
         names = ("render", "loss", "backward", "stats_exchange_optimizer")
 
         def med(marks):
@@ -941,6 +944,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
             "render": ("hip graph per view" if cfg.use_graph else "one fused op") if use_fused else "separate ops",
             "list_overflow_views": overflow_views + (_list_rebuilds() - rebuilds0), "phase_ms_median": phases,
             "phase_ms_median_by_resolution": phases_by_res, "phase_ms_median_by_depth_loss": phases_by_depth,
+            "phase_ms_series": phase_series,
             "depth_segments": _depth_segments_record(device),
             "schedule": {"num_downscales": cfg.num_downscales, "resolution_schedule": cfg.resolution_schedule,
                          "background_color": cfg.background_color, "caller_syncs": cfg.caller_syncs},

@@ -676,7 +676,7 @@ def alloc_tile_bins(tile_bounds, dev) -> Tensor:
         ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
     nt = key[0] * key[1]
     bins = torch.empty((2 * nt + ints,), dtype=_i32, device=dev)[:2 * nt].view(nt, 2)
-    bins._gsr_job_tail = True
+    bins._gsr_job_tail = ints > 0
     return bins
 
 
@@ -692,14 +692,21 @@ def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, bac
     # order, and the step is bound by the host, where one more launch costs what it costs
     if num_tiles <= (_order_cache["grid"] if _order_cache["grid"] >= 0 else _deep_knobs()[4]):
         return deep
+    key = (int(tile_bounds[0]), int(tile_bounds[1]))
+    ints = _jobs_ints_cache.get(key)
+    if ints is None:
+        ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
+    if ints == 0:
+        return deep  # (a grid beyond the order kernel's tables -- above 3840 x 2160: the static order)
     ok = getattr(tile_bins, "_gsr_job_tail", None)  # (decided once per tensor object)
     if ok is None:
-        key = (int(tile_bounds[0]), int(tile_bounds[1]))
-        ints = _jobs_ints_cache.get(key)
-        if ints is None:
-            ints = _jobs_ints_cache[key] = tile_jobs_ints(key)
-        have = tile_bins.untyped_storage().nbytes() // 4 - tile_bins.storage_offset()
-        ok = tile_bins.dtype == _i32 and tile_bins.is_contiguous() and have >= 2 * num_tiles + ints
+        # A tensor that does not carry the attribute (unpacked from autograd's saved tensors: a new Python object over
+        # the same storage; or a caller's own bins) owns a job tail only if `alloc_tile_bins` made its storage: the
+        # whole storage is exactly  2 tiles + ints  int32 and the tensor starts at its beginning.  Room behind a slice
+        # of some larger live buffer is NOT a tail -- the order kernel would write over whatever follows.
+        ok = (tile_bins.dtype == _i32 and tile_bins.is_contiguous() and tile_bins.storage_offset() == 0
+              and tile_bins.numel() == 2 * num_tiles
+              and tile_bins.untyped_storage().nbytes() == 4 * (2 * num_tiles + ints))
         try:
             tile_bins._gsr_job_tail = ok
         except AttributeError:

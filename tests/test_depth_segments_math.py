@@ -1,5 +1,6 @@
 """CPU: the algebra of the depth segments on one pixel's list, in float64 numpy -- the run-wise forward
-(transmittance pre-pass, prefix products, runs from the true incoming T, combine in list order) and the run-wise
+(round 6: every run once from T = 1, scaled by the prefix products, a re-walk from the run in which the pixel crosses
+the stop rule's threshold) and the run-wise
 backward (each run's affine map of (T, K), composed maps, runs from their start states) against the sequential walks
 they replace (forward.cu:278-395, backward.cu:133-303 as restated in csrc/raster_fwd.hip / raster_bwd.hip).  What the
 HIP kernels do per pixel, without the kernels: exact equality of every decision, values to float64 rounding."""
@@ -25,24 +26,28 @@ def forward_walk(alpha_raw, rgb, T0=1.0):
     return C, (-T if done else T), last
 
 
-def forward_runs(alpha_raw, rgb, bounds):
-    taus = []
-    for lo, hi in bounds[:-1]:                       # pre-pass: every run but the last, from T = 1
-        _, t, _ = forward_walk(alpha_raw[lo:hi], rgb[lo:hi])
-        taus.append(t if t > 0 else 0.0)
-    prefix = np.concatenate([[1.0], np.cumprod(taus)])  # what run k starts from
-    C, T, last = np.zeros(3), 1.0, -1
-    for k, (lo, hi) in enumerate(bounds):             # the runs are independent; the combine walks them in order
-        if prefix[k] <= 0.0:                           # (a run that starts dead draws nothing; combine never gets here)
-            ck, tk, lk = np.zeros(3), -0.0, -1
-        else:
-            ck, tk, lk = forward_walk(alpha_raw[lo:hi], rgb[lo:hi], prefix[k])
-        C += ck
-        T = tk
-        last = max(last, lk + lo if lk >= 0 else -1)
-        if tk < 0 or (tk == 0 and np.signbit(tk)):
+def forward_runs(alpha_raw, rgb, bounds, margin=1.001, stats=None):
+    """Round 6 (raster_fwd_segresolve_kernel): every run is walked ONCE from T = 1 -> (C_k, signed T_k, last_k);
+    compositing is associative in (C, T), so the runs in front of the first run k* whose prefix x T_k comes down to the
+    stop rule's threshold (or which finished on its own) enter as prefix_k C_k; from the start of k* the list is
+    re-walked with the true incoming T -- the unchanged rule -- until the pixel finishes."""
+    raws = [forward_walk(alpha_raw[lo:hi], rgb[lo:hi]) for lo, hi in bounds]
+    prefix, C, last, kstar = 1.0, np.zeros(3), -1, None
+    for k, ((lo, _), (ck, tk, lk)) in enumerate(zip(bounds, raws)):
+        if tk < 0 or prefix * tk <= T_EPS * margin:
+            kstar = k
             break
-    return C, T, last
+        C += prefix * ck
+        last = max(last, lk + lo if lk >= 0 else -1)
+        prefix *= tk
+    if stats is not None:
+        stats["kstar"] = kstar
+    if kstar is None:
+        return C, prefix, last
+    lo = bounds[kstar][0]
+    assert prefix > T_EPS  # a pixel joins the re-walk live, by construction
+    ck, tk, lk = forward_walk(alpha_raw[lo:], rgb[lo:], prefix)
+    return C + ck, tk, max(last, lk + lo if lk >= 0 else -1)
 
 
 def backward_walk(alpha_raw, d, lo, hi, last, T, K):
@@ -103,3 +108,36 @@ def test_runs_reproduce_the_sequential_walks(seed, n, runs, opaque):
     scale = np.abs(w_ref).max()
     assert scale > 0 and np.abs(w - w_ref).max() <= 1e-11 * scale
     assert np.array_equal(w != 0, w_ref != 0)          # the same entries are valid
+
+
+def test_a_pixel_the_margin_flags_for_nothing_walks_on():
+    """prefix x T_k inside the crossing margin but above 1e-4, and nothing behind takes it below: the re-walk starts at
+    that run, never finishes, and the result is the single walk's."""
+    n = 256
+    alpha_raw = np.zeros(n)
+    # run 0 (entries 0-63) takes T to 1.0005e-4 exactly-ish: one entry of alpha 1 - 1.0005e-4 is clamped, so use many
+    k = 40
+    alpha_raw[:k] = 1.0 - (1.0005e-4) ** (1.0 / k)
+    alpha_raw[100] = 0.002  # below 1/255: a miss
+    rgb = np.full((n, 3), 0.5)
+    bounds = [(lo, lo + 64) for lo in range(0, n, 64)]
+    st = {}
+    C0, T0, last0 = forward_walk(alpha_raw, rgb)
+    C1, T1, last1 = forward_runs(alpha_raw, rgb, bounds, stats=st)
+    assert st["kstar"] == 0 and T0 > 0 and T1 > 0 and last1 == last0 == k - 1
+    assert abs(T1 - T0) <= 1e-15 and np.abs(C1 - C0).max() <= 1e-13
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_crossing_run_is_found_where_the_single_walk_finishes(seed):
+    rng = np.random.default_rng(100 + seed)
+    n, runs = 640, 10
+    alpha_raw = rng.uniform(0.0, 0.25, n) * (rng.uniform(0, 1, n) < 0.8)
+    rgb = rng.uniform(0, 1, (n, 3))
+    bounds = [(lo, lo + 64) for lo in range(0, n, 64)]
+    C0, T0, last0 = forward_walk(alpha_raw, rgb)
+    st = {}
+    C1, T1, last1 = forward_runs(alpha_raw, rgb, bounds, stats=st)
+    assert T0 < 0 and T1 < 0 and last1 == last0
+    assert st["kstar"] is not None and bounds[st["kstar"]][0] <= last0 + 1  # the re-walk starts at or before the finish
+    assert abs(T1 - T0) <= 1e-13 and np.abs(C1 - C0).max() <= 1e-12

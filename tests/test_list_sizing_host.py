@@ -161,3 +161,40 @@ def test_the_backwards_split_threshold_is_one_wave_slots_share_of_the_launch(mon
         assert not C.deep_arg(_Bins(), e, 60 * 34, backward=True, tile_bounds=tb(60, 34)) & C.GSR_DEEP_ORDERED
     finally:
         knobs()
+
+
+def test_grids_beyond_the_order_kernels_tables_run_in_the_static_order():
+    """3840 x 2160 is the largest grid the job-order kernel sorts (32 768 slots); 4096 x 2160, 5K and 8K
+    must render in the static order instead of raising 'tile grid beyond the sort's tables'."""
+    import torch
+
+    import rasterizer.cuda as C
+
+    tb = lambda w, h: ((w + 15) // 16, (h + 15) // 16, 1)
+    assert C.tile_jobs_ints(tb(3840, 2160)) > 0
+    for w, h in ((4096, 2160), (5120, 2880), (7680, 4320)):
+        t = tb(w, h)
+        assert C.tile_jobs_ints(t) == 0
+        bins = C.alloc_tile_bins(t, "cpu")
+        assert bins.shape == (t[0] * t[1], 2) and bins._gsr_job_tail is False
+        for bwd in (False, True):
+            arg = C.deep_arg(bins, 40_000_000, t[0] * t[1], backward=bwd, tile_bounds=t)
+            assert arg > 0 and not (arg & C.GSR_DEEP_ORDERED)
+        assert not (C.forward_orders(bins, 40_000_000, t[0] * t[1], t, "cpu") & C.GSR_DEEP_ORDERED)  # (no native call made)
+
+
+def test_a_slice_of_a_larger_buffer_is_not_a_job_tail():
+    """room behind a caller's tile_bins is not ownership of it -- only a storage of exactly
+    2 tiles + gsr_tile_jobs_ints int32, entered at its start (what alloc_tile_bins makes), carries a job order."""
+    import torch
+
+    import rasterizer.cuda as C
+
+    t = (120, 68, 1)  # 1920 x 1080
+    nt, ints = t[0] * t[1], C.tile_jobs_ints(t)
+    own = C.alloc_tile_bins(t, "cpu")
+    resurfaced = torch.empty(0, dtype=torch.int32).set_(own.untyped_storage(), 0, (nt, 2))  # as autograd unpacks it
+    assert C.deep_arg(resurfaced, 8_000_000, nt, tile_bounds=t) & C.GSR_DEEP_ORDERED
+    big = torch.zeros(2 * nt + ints + 4096, dtype=torch.int32)
+    assert not C.deep_arg(big[: 2 * nt].view(nt, 2), 8_000_000, nt, tile_bounds=t) & C.GSR_DEEP_ORDERED
+    assert not C.deep_arg(big[64: 64 + 2 * nt].view(nt, 2), 8_000_000, nt, tile_bounds=t) & C.GSR_DEEP_ORDERED
