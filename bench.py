@@ -727,7 +727,7 @@ def main():
                          "float atomics")
     ap.add_argument("--scene", default="uniform",
                     help="uniform (SURVEY 8d's random cloud) | longtail: 10 %% of the tiles hold ~10x the list depth "
-                         "(clustered Gaussians) | ply:<path>: a TRAINED model in the toolkit's export format "
+                         "(clustered Gaussians) | room | floaters | needles: held-out families (harness/scene.py) | ply:<path>: a TRAINED model in the toolkit's export format "
                          "(gs_io/ply.py; scripts/exporter.py:88-147), seen from --ply-view of an orbit of radius "
                          "--ply-cam-radius (the cameras harness.train trains on)")
     ap.add_argument("--ply-cam-radius", type=float, default=5.0)
@@ -843,6 +843,11 @@ def main():
         sc = S.make_scene(N, cam0, sh_degree=deg, seed=42, scale_lo=args.scale_lo, scale_hi=args.scale_hi,
                           longtail=args.scene == "longtail")
         # rank r looks at the same cloud from a slightly different direction
+        cam = cam0 if rank == 0 else S.make_camera(W, H, yaw=0.02 * rank, pitch=0.01 * (rank % 3))
+    elif args.scene in S.HELDOUT_KINDS:
+        # scene families no dispatch constant was fitted on (harness.scene.make_heldout_scene)
+        cam0 = S.make_camera(W, H)
+        sc = S.make_heldout_scene(args.scene, N, cam0, sh_degree=deg)
         cam = cam0 if rank == 0 else S.make_camera(W, H, yaw=0.02 * rank, pitch=0.01 * (rank % 3))
     else:
         raise SystemExit(f"unknown --scene {args.scene!r}")
@@ -994,15 +999,18 @@ def main():
     # The product path builds a view's tile lists on a side stream, next to the caller's own work, and composites in
     # the same native call where it can: HIP events around "one stage" do not isolate anything there.  The per-stage
     # table therefore comes from a few extra UNTIMED steps that run the stages one after the other on one stream
-    # (GSR_SPECULATE=0, GSR_ONE_CALL=0: the same kernels, the same inputs); the compositing backward -- the
+    # (GSR_SPECULATE=0, `one_call` = 0: the same kernels, the same inputs); the compositing backward -- the
     # dominant kernel of `roofline` -- is bracketed inside the timed region as well, and that is the figure used.
     pairs_timed, iso_steps = timers.pairs, 0
     if args.event_every > 0:  # (every rank: a step carries the gradient exchange's collectives)
         from rasterizer import rasterize as _Riso
 
+        from rasterizer.cuda import _tuning as _Tune
+
         _Riso._speculation_mode()
-        saved_mode, saved_env = _Riso._spec_knobs["mode"], os.environ.get("GSR_ONE_CALL")
-        _Riso._spec_knobs["mode"], os.environ["GSR_ONE_CALL"] = "0", "0"
+        saved_mode, saved_over = _Riso._spec_knobs["mode"], _Tune.overrides()
+        _Riso._spec_knobs["mode"] = "0"
+        _Tune.set_overrides(dict(saved_over, one_call=0))
         timers.pairs = {k: [] for k in pairs_timed}
         try:
             step()
@@ -1013,10 +1021,7 @@ def main():
         finally:
             timers.enabled = False
             _Riso._spec_knobs["mode"] = saved_mode
-            if saved_env is None:
-                os.environ.pop("GSR_ONE_CALL", None)
-            else:
-                os.environ["GSR_ONE_CALL"] = saved_env
+            _Tune.set_overrides(saved_over)
         torch.cuda.synchronize()
         pairs_iso, timers.pairs = timers.pairs, pairs_timed
         for k_, v_ in pairs_iso.items():  # stages the timed region could not isolate: the sequential samples
@@ -1238,7 +1243,9 @@ def main():
             "config": {
                 "workload": (f"{N} Gaussians of a TRAINED model ({os.path.basename(args.scene[4:])}; view {args.ply_view} of "
                              f"the training orbit), " if args.scene.startswith("ply:") else
-                             f"{N} random Gaussians (SURVEY 8d, seed 42, scales log-U[{args.scale_lo},{args.scale_hi}]), ") +
+                             (f"{N} Gaussians of the held-out family '{args.scene}' (harness.scene.make_heldout_scene), "
+                              if args.scene in S.HELDOUT_KINDS else
+                              f"{N} random Gaussians (SURVEY 8d, seed 42, scales log-U[{args.scale_lo},{args.scale_hi}]), ")) +
                             f"SH degree {deg}, {W}x{H}, block 16, fwd+bwd through the rasterizer autograd API"
                             + ((" + depth image from the same compositing pass (gs_fused)" if args.fused_depth
                                else " + differentiable depth pass") if args.render_depth else "")
@@ -1276,7 +1283,7 @@ def main():
             "kernels": per_kernel,
             "kernel_events": (f"raster_bwd: HIP events around the native call on every {max(args.event_every, 1)}th TIMED step; the "
                               "other stages: HIP events over 8 extra untimed steps that run the stages one after the other "
-                              "on one stream (GSR_SPECULATE=0, GSR_ONE_CALL=0) -- in the timed steps the tile lists are built "
+                              "on one stream (GSR_SPECULATE=0, one_call = 0) -- in the timed steps the tile lists are built "
                               "on a side stream next to the SH evaluation, which no pair of events isolates"),
             "end_to_end_algorithmic_GBps": round(end_to_end, 1),
             "end_to_end_built_GBps": round(end_to_end_built, 1),
@@ -1319,6 +1326,8 @@ def main():
             r480n = g_(tr, "phase_ms_median_by_resolution")
             for k_ in (sorted(r480n, key=lambda k2: int(k2.split("x")[0])) if isinstance(r480n, dict) else []):
                 cfg_[f"render_{k_}_ms_no_readbacks"] = g_(r480n, k_, "render")
+            if keys:  # (the name VERDICT r5 asks for: the schedule's lowest resolution, 480 x 270 on config 3)
+                cfg_["render_480_ms"] = g_(r480, keys[0], "render")
             cfg_["render_480_slow_share"] = g_(tr, "with_caller_syncs", "render_slow_share_lowest_resolution")
             tp = g_(tr, "trained_raster", "parity_vs_oracle")
             cfg_.update({

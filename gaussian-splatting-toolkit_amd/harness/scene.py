@@ -113,6 +113,89 @@ def make_scene(n: int, cam: Camera, sh_degree: int = 3, seed: int = 42,
                 opacities=opac.astype(f32), sh_coeffs=sh.astype(f32))
 
 
+HELDOUT_KINDS = ("room", "floaters", "needles")
+
+
+def make_heldout_scene(kind: str, n: int, cam: Camera, sh_degree: int = 3, seed: int = 7) -> Dict[str, np.ndarray]:
+    """Scene families shaped like what captures produce and NOT used to fit any dispatch constant (VERDICT r5 item 3;
+    rasterizer/cuda/_tuning.py was fitted on the uniform / long-tail clouds, the trainer's ball and object scenes and
+    the model config 3 trains).  Same dictionary as `make_scene`.
+      room      a few thousand large, flat, nearly opaque splats on the walls of a box around the camera (every tile's
+                list ends in them) behind dense small detail on ~40 object surfaces: a spatially correlated heavy tail
+      floaters  the uniform cloud with 300 near-camera, faint, screen-filling splats in front of it (each covers
+                hundreds of tiles and heads their lists; nothing saturates behind them)
+      needles   axis ratio 1:20 to 1:60, random orientation: long thin footprints whose 3-sigma boxes hit many tiles
+                that the exact reach test then drops"""
+    if kind not in HELDOUT_KINDS:
+        raise ValueError(f"unknown held-out scene {kind!r}")
+    rng = np.random.default_rng(seed)
+    tanx, tany = 0.5 * cam.width / cam.fx, 0.5 * cam.height / cam.fy
+    R, t = cam.viewmat[:3, :3].astype(np.float64), cam.viewmat[:3, 3].astype(np.float64)
+    unit = lambda q: q / np.linalg.norm(q, axis=-1, keepdims=True)  # noqa: E731
+    if kind == "room":
+        n_wall = min(max(n // 100, 500), 4000)
+        n_obj = n - n_wall
+        # walls of the box x = +-6, y = +-3.5, z = 11 (camera space), flat splats lying in the wall
+        which = rng.integers(0, 5, n_wall)
+        u, v = rng.uniform(-1, 1, n_wall), rng.uniform(-1, 1, n_wall)
+        pw = np.empty((n_wall, 3))
+        qw = np.empty((n_wall, 4))
+        c45 = math.sqrt(0.5)
+        for w_, (pos, quat) in enumerate((
+                (lambda u_, v_: (6 * u_, 3.5 * v_, np.full_like(u_, 11.0)), (1, 0, 0, 0)),          # back wall (normal z)
+                (lambda u_, v_: (np.full_like(u_, -6.0), 3.5 * v_, 5.5 + 5.5 * u_), (c45, 0, c45, 0)),  # left (normal x)
+                (lambda u_, v_: (np.full_like(u_, 6.0), 3.5 * v_, 5.5 + 5.5 * u_), (c45, 0, c45, 0)),   # right
+                (lambda u_, v_: (6 * u_, np.full_like(u_, 3.5), 5.5 + 5.5 * v_), (c45, c45, 0, 0)),     # floor (normal y)
+                (lambda u_, v_: (6 * u_, np.full_like(u_, -3.5), 5.5 + 5.5 * v_), (c45, c45, 0, 0)))):  # ceiling
+            m = which == w_
+            x_, y_, z_ = pos(u[m], v[m])
+            pw[m] = np.stack([x_, y_, z_], -1)
+            qw[m] = quat
+        sw = np.stack([rng.uniform(0.25, 0.8, n_wall), rng.uniform(0.25, 0.8, n_wall), np.full(n_wall, 0.01)], -1)
+        ow = rng.uniform(0.85, 0.995, (n_wall, 1))
+        # objects: small splats on sphere surfaces in front of the walls
+        n_cl = 40
+        cz = rng.uniform(3.0, 8.0, n_cl)
+        centres = np.stack([rng.uniform(-0.9, 0.9, n_cl) * tanx * cz, rng.uniform(-0.9, 0.9, n_cl) * tany * cz, cz], -1)
+        rad = rng.uniform(0.2, 0.7, n_cl)
+        cl = rng.integers(0, n_cl, n_obj)
+        d = unit(rng.standard_normal((n_obj, 3)))
+        po = centres[cl] + d * rad[cl, None]
+        so = np.exp(rng.uniform(math.log(0.004), math.log(0.025), (n_obj, 3)))
+        so[:, 2] *= 0.3  # flattened, as surface splats end up
+        qo = unit(rng.standard_normal((n_obj, 4)))
+        oo = rng.uniform(0.4, 0.99, (n_obj, 1))
+        p_cam, scales, q, opac = np.concatenate([pw, po]), np.concatenate([sw, so]), np.concatenate([qw, qo]), np.concatenate([ow, oo])
+    elif kind == "floaters":
+        n_fl = min(300, max(n // 20, 1))
+        base = make_scene(n - n_fl, cam, sh_degree=0, seed=seed + 1, scale_lo=0.0025, scale_hi=0.025)
+        pb = base["means3d"].astype(np.float64) @ R.T + t
+        z = rng.uniform(0.25, 0.9, n_fl)
+        pf = np.stack([rng.uniform(-1, 1, n_fl) * tanx * z, rng.uniform(-1, 1, n_fl) * tany * z, z], -1)
+        sf = (rng.uniform(0.03, 0.09, (n_fl, 1)) * z[:, None]) * rng.uniform(0.6, 1.4, (n_fl, 3))
+        p_cam = np.concatenate([pf, pb])
+        scales = np.concatenate([sf, base["scales"].astype(np.float64)])
+        q = np.concatenate([unit(rng.standard_normal((n_fl, 4))), base["quats"].astype(np.float64)])
+        opac = np.concatenate([rng.uniform(0.03, 0.25, (n_fl, 1)), base["opacities"].astype(np.float64)])
+    else:  # needles
+        z = rng.uniform(2.0, 10.0, n)
+        p_cam = np.stack([rng.uniform(-1, 1, n) * 1.1 * tanx * z, rng.uniform(-1, 1, n) * 1.1 * tany * z, z], -1)
+        long_ = np.exp(rng.uniform(math.log(0.04), math.log(0.4), n))
+        ratio = rng.uniform(20.0, 60.0, (n, 2))
+        scales = np.stack([long_, long_ / ratio[:, 0], long_ / ratio[:, 1]], -1)
+        q = unit(rng.standard_normal((n, 4)))
+        opac = rng.uniform(0.1, 0.9, (n, 1))
+    means = (p_cam - t) @ R
+    K = num_sh_bases(sh_degree)
+    sh = np.empty((n, K, 3))
+    sh[:, 0, :] = rng.uniform(-1, 1, (n, 3)) * 0.5 / SH_C0
+    if K > 1:
+        sh[:, 1:, :] = rng.standard_normal((n, K - 1, 3)) * 0.1
+    f32 = np.float32
+    return dict(means3d=means.astype(f32), scales=scales.astype(f32), quats=q.astype(f32),
+                opacities=opac.astype(f32), sh_coeffs=sh.astype(f32))
+
+
 def make_cotangents(cam: Camera, seed: int = 43):
     rng = np.random.default_rng(seed)
     v_img = rng.uniform(-1, 1, (cam.height, cam.width, 3)).astype(np.float32)

@@ -586,7 +586,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         from gs_fused import l1_ssim_loss
 
         # the clamp of the rendered image at 1 (vanilla_gs.py:857) is folded into the loss kernels
-        fused_clamp = os.environ.get("GSR_AB_LOSS_CLAMP", "1") != "0"
+        fused_clamp = True
         loss_fn = lambda pred, target: l1_ssim_loss(pred, target, cfg.ssim_lambda, clamp_pred=fused_clamp)
     else:
         loss_fn = lambda pred, target: ((1 - cfg.ssim_lambda) * (pred - target).abs().mean()
@@ -606,7 +606,7 @@ def train(cfg: TrainConfig, device, rank: int = 0, world: int = 1) -> Dict:
         else:
             depth_loss_fn = lambda out, gtd: cogs_depth_l1(out["depth"], gtd)
 
-    fused_stats = cfg.fused_activations and device.type == "cuda" and os.environ.get("GSR_AB_STATS", "1") != "0"
+    fused_stats = cfg.fused_activations and device.type == "cuda"
     if fused_stats:
         from gs_fused import densify_stats_
     n = n0 = model.num_points

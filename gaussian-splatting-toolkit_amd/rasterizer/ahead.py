@@ -64,7 +64,7 @@ def _speculation_mode() -> str:
     if not _spec_knobs:
         _spec_knobs["mode"] = {"0": "0", "off": "0", "sort": "sort", "lists": "lists"}.get(
             os.environ.get("GSR_SPECULATE", "auto"), "auto")
-        _spec_knobs["min_points"] = int(os.environ.get("GSR_SPECULATE_MIN", "65536"))
+        _spec_knobs["min_points"] = int(_C._tuning.get("speculate_min"))
     return _spec_knobs["mode"]
 
 

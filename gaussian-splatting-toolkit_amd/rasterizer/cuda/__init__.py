@@ -19,6 +19,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
+from . import _tuning
 from ._backend import lib as _lib
 
 _f32, _i32, _i64 = torch.float32, torch.int32, torch.int64
@@ -553,9 +554,9 @@ def _raster_inputs(gaussian_ids_sorted, tile_bins, xys, conics, colors, opacitie
 def depth_segments(list_entries: int, num_tiles: int):
     """-> (segments, minimum entries) for ``gsr_rasterize_forward_seg`` / ``gsr_rasterize_backward_seg``: into how many
     runs the lists of the tiles that are split over four waves are cut, each run walked by its own waves (DESIGN.md
-    4.16).  Only tile grids that cannot fill the chip gain: 16 runs (GSR_DEPTH_SEGMENTS; 1 = off) on grids of up to
-    GSR_DEPTH_SEGMENTS_GRID = 1 100 tiles (the grids on which forward and backward split every tile), for lists of more
-    than GSR_DEPTH_SEGMENTS_MIN = 512 entries.  Measured (tools/exp/seg_ab.py, profiles/r04_depth_segments.txt):
+    4.16).  Only tile grids that cannot fill the chip gain: 16 runs (`depth_segments` in _tuning.py; 1 = off) on grids of up to
+    `depth_segments_grid` = 1 100 tiles (the grids on which forward and backward split every tile), for lists of more
+    than `depth_segments_min` = 512 entries.  Measured (tools/exp/seg_ab.py, profiles/r04_depth_segments.txt):
     300 k Gaussians of the trainer's object scene at 480 x 270, compositing backward 436 -> 263 us with 8 runs
     (pre-pass 75 + walk 188), forward 338 -> 295 us with 4; config 3 (whose first 2 000 iterations run on this grid)
     818 / 825 -> 871 (8 runs) -> 885 iterations/s (16).  On larger grids the kernels are bound by their total work,
@@ -573,25 +574,16 @@ def depth_segments(list_entries: int, num_tiles: int):
 def _forward_segments(list_entries: int, num_tiles: int, H: int, W: int, dev):
     """-> (segments, minimum entries, workspace or None) of ``gsr_rasterize_forward_seg`` for this tile grid."""
     segs, seg_min = depth_segments(list_entries, num_tiles)
-    if segs > 1:
-        # GSR_DEPTH_SEGMENTS_FWD (16 = as the backward; 8 until the end of round 5): the forward's pre-pass walks
-        # every run from T = 1 to the run's own saturation: on a SATURATING scene that is most of the list, where the
-        # single walk stops early (300 k opaque Gaussians at 480 x 270: forward 338 us single, 295 with 4 runs, 340
-        # with 8, 432 with 16; the trainer's ball, 300 k: 0.30 / 0.37 / 0.44 ms with 4 / 8 / 16), while a translucent
-        # one gains all the way (the model config 3 ends with at 480 x 270: 0.54 / 0.39 / 0.34 / 0.31 ms with
-        # 4 / 8 / 12 / 16; long-tail cloud 0.46 / 0.30 / 0.24 / 0.21).  Small grids are what the reference's
-        # coarse-to-fine schedule renders EARLY in training -- young, translucent models (opacity 0.1 at the start,
-        # vanilla_gs.py:128-174): config 3 923 / 926 -> 957 (12) -> 966 (16) iterations/s on one lease, 952 -> 958-966
-        # on another (profiles/r05_smallgrid_fwd_segments.txt)
-        segs = min(segs, _segment_knobs()[3]) if _segment_knobs()[3] > 0 else segs
+    cap = _segment_knobs()[3]
+    if segs > 1 and cap > 0:
+        # `depth_segments_fwd` (_tuning.py): until round 6 the forward walked every list twice (a transmittance pre-pass
+        # from T = 1 to each run's own saturation, then the runs) and a saturating scene paid for many runs (300 k opaque
+        # Gaussians at 480 x 270: 338 us single, 295 with 4 runs, 432 with 16) while a translucent one gained all the way
+        # (the model config 3 ends with: 0.54 / 0.39 / 0.31 ms with 4 / 8 / 16).  The forward now walks every run once
+        # (csrc/raster_fwd.hip) and re-walks only the runs in which pixels cross the stop rule's threshold.
+        segs = min(segs, cap)
     if segs < 2:
-        # forward-only runs on larger grids, for the longest lists alone (GSR_DEPTH_SEGMENTS_FWD_GRID tiles, 0 = off;
-        # lists above GSR_DEPTH_SEGMENTS_FWD_FACTOR x the mean, not below _FWD_MIN entries): the forward's span on a
-        # trained model is the serial walk of its longest tiles' sub-tile waves (DESIGN 4.18 / 4.20)
-        k = _segment_knobs()
-        if len(k) < 8 or k[4] <= 0 or num_tiles <= 0 or num_tiles > k[4] or k[5] < 2:
-            return 0, 0, None
-        segs, seg_min = k[5], max(k[7], int(k[6] * list_entries / num_tiles))
+        return 0, 0, None
     nbytes = int(_lib().gsr_rasterize_forward_seg_workspace_bytes(C.c_uint(H), C.c_uint(W), C.c_int(segs)))
     return segs, seg_min, torch.empty((nbytes,), dtype=torch.uint8, device=dev)
 
@@ -601,36 +593,28 @@ _segment_cache = {}
 
 def _segment_knobs():
     if not _segment_cache:
-        import os
-
         # (the C entries take at most 16 runs -- GSR_REQUIRE(segments <= 16) -- and the backward calls them from inside
-        #  autograd: a larger value in the environment is clamped here instead of raising there)
-        _segment_cache["v"] = (min(16, max(1, int(os.environ.get("GSR_DEPTH_SEGMENTS", "16")))),
-                               int(os.environ.get("GSR_DEPTH_SEGMENTS_GRID", "1100")),
-                               int(os.environ.get("GSR_DEPTH_SEGMENTS_MIN", "512")),
-                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD", "16")))),
-                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_GRID", "0")),
-                               min(16, max(0, int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_RUNS", "4")))),
-                               float(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_FACTOR", "3.0")),
-                               int(os.environ.get("GSR_DEPTH_SEGMENTS_FWD_MIN", "512")))
+        #  autograd: a larger value in the table's overrides is clamped here instead of raising there)
+        _segment_cache["v"] = (min(16, max(1, int(_tuning.get("depth_segments")))), int(_tuning.get("depth_segments_grid")),
+                               int(_tuning.get("depth_segments_min")), min(16, max(0, int(_tuning.get("depth_segments_fwd")))))
     return _segment_cache["v"]
 
 
 def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = False) -> int:
     """List length above which a 16x16 tile is composited by four waves (one per 8x8
-    sub-tile) instead of one (include/gsraster.h, ``deep_tile_threshold``): GSR_DEEP_FACTOR
-    (default 1.2; 0 = off) times the mean list length, not below GSR_DEEP_MIN (256; 1024 until round 5).
+    sub-tile) instead of one (include/gsraster.h, ``deep_tile_threshold``): `deep_factor`
+    (default 1.2; 0 = off) times the mean list length, not below `deep_min` (256; 1024 until round 5).
     `list_entries` is normally the capacity of device-sized lists (~1.25x the real count), so
     the default splits tiles above ~1.5x the mean.  Measured on the long-tail bench scene
     (10 % of the tiles ~10x deeper): forward 357 -> 320 us, backward 664 -> 625 us; factors
     0.8-1.5 within 3 % of each other, 0.3 (nearly every tile split) 1.7x slower; no effect
     on the uniform scene (nothing above the threshold; the idle workgroups cost < 1 %).
-    Backward: GSR_DEEP_FACTOR_BWD (2.0, quoted on a 1080p grid) scaled by tiles / 8 160 on grids above
-    GSR_SMALL_GRID_BWD -- i.e. a tile is split when its list exceeds total entries / 4 096, the share of one of
-    the backward's resident wave slots (GSR_DEEP_FACTOR_BWD_SCALED=0: the fixed factor)."""
+    Backward: `deep_factor_bwd` (2.0, quoted on a 1080p grid) scaled by tiles / 8 160 on grids above
+    `small_grid_bwd` -- i.e. a tile is split when its list exceeds total entries / 4 096, the share of one of
+    the backward's resident wave slots (`deep_factor_bwd_scaled`=0: the fixed factor)."""
     factor, floor, small_grid, small_floor, small_grid_bwd = _deep_knobs()[:5]
     if backward and _deep_knobs()[5] > 0:
-        # GSR_DEEP_FACTOR_BWD (2.0; 0 = the forward's factor): with the longest jobs first, the backward gains from
+        # `deep_factor_bwd` (2.0; 0 = the forward's factor): with the longest jobs first, the backward gains from
         # splitting only its longest tiles (four sub-tile waves run four butterflies): trained model 0.405 (1.2) ->
         # 0.348 ms (2.0) -> 0.40 (3.0+); long-tail scene 0.588 -> 0.559 -> 0.504 (6.0)
         factor = _deep_knobs()[5]
@@ -651,7 +635,7 @@ def deep_tile_threshold(list_entries: int, num_tiles: int, backward: bool = Fals
         # (profiles/r04_small_grids.txt): 300 k Gaussians at 480 x 270, forward 0.32 -> 0.17 ms, backward 0.45 ->
         # 0.26 ms; 450 k at 960 x 540 (2 040 tiles), forward 0.19 -> 0.15 ms but backward 0.28 -> 0.35 ms (four
         # waves per tile also issue four times the atomics): the backward splits every tile only on grids of up to
-        # GSR_SMALL_GRID_BWD tiles.  1080p with every tile split: 1.57 ms instead of 1.00.
+        # `small_grid_bwd` tiles.  1080p with every tile split: 1.57 ms instead of 1.00.
         return small_floor
     return max(floor, int(factor * list_entries / num_tiles))
 
@@ -683,7 +667,7 @@ def alloc_tile_bins(tile_bounds, dev) -> Tensor:
 def deep_arg(tile_bins: Optional[Tensor], list_entries: int, num_tiles: int, backward: bool = False, tile_bounds=None) -> int:
     """The `deep_tile_threshold` argument of a compositing entry: the threshold (`deep_tile_threshold`), with
     GSR_DEEP_ORDERED set when `tile_bins` came from `alloc_tile_bins` (so the job order fits behind it), the grid
-    is not a small one and GSR_DEEP_ORDER is not 0 -- the entry then runs the launch's jobs longest first (DESIGN.md
+    is not a small one and `deep_order` is not 0 -- the entry then runs the launch's jobs longest first (DESIGN.md
     section 4.18)."""
     deep = deep_tile_threshold(list_entries, num_tiles, backward) if backward else deep_tile_threshold(list_entries, num_tiles)
     if deep <= 0 or tile_bins is None or tile_bounds is None or not _order_knob():
@@ -752,35 +736,34 @@ _order_cache = {}
 
 def _order_knob() -> bool:
     if not _order_cache:
-        import os
-
-        _order_cache["v"] = os.environ.get("GSR_DEEP_ORDER", "1") != "0"
+        _order_cache["v"] = bool(int(_tuning.get("deep_order")))
         # the share (in 1/64ths) of a launch's whole-tile jobs that run last as four sub-tile jobs each (csrc/raster_common.h)
-        # forward 8 / 64 (uniform bench scene: forward 0.233 -> 0.208 ms), backward 0 (a split tile costs the backward
-        # 1.7 x the instructions: 8 / 64 there 0.443 -> 0.461 ms) -- profiles/r05_lpt_tail_and_factors.txt
-        _order_cache["tail"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL", "8"))))
-        _order_cache["tail_bwd"] = min(63, max(0, int(os.environ.get("GSR_DEEP_TAIL_BWD", "0"))))
-        # grids of up to this many tiles run in the static order (-1: GSR_SMALL_GRID_BWD, the grids on which both
+        _order_cache["tail"] = min(63, max(0, int(_tuning.get("deep_tail"))))
+        _order_cache["tail_bwd"] = min(63, max(0, int(_tuning.get("deep_tail_bwd"))))
+        # grids of up to this many tiles run in the static order (-1: small_grid_bwd, the grids on which both
         # directions split every tile and cut the lists into depth segments)
-        _order_cache["grid"] = int(os.environ.get("GSR_DEEP_ORDER_GRID", "-1"))
+        _order_cache["grid"] = int(_tuning.get("deep_order_grid"))
     return _order_cache["v"]
 
 
 _deep_cache = {}
-_BWD_FACTOR_GRID = 8160.0  # (the grid GSR_DEEP_FACTOR_BWD is quoted on: 1920 x 1080)
+_BWD_FACTOR_GRID = 8160.0  # (the grid `deep_factor_bwd` is quoted on: 1920 x 1080)
 
 
 def _deep_knobs():
-    # (read once: two environment look-ups per compositing call are measurable on small scenes)
+    # (read once: table look-ups per compositing call are measurable on small scenes)
     if not _deep_cache:
-        import os
-
-        _deep_cache["v"] = (float(os.environ.get("GSR_DEEP_FACTOR", "1.2")), int(os.environ.get("GSR_DEEP_MIN", "256")),
-                            int(os.environ.get("GSR_SMALL_GRID", "2560")), int(os.environ.get("GSR_SMALL_GRID_MIN", "96")),
-                            int(os.environ.get("GSR_SMALL_GRID_BWD", "1100")),
-                            float(os.environ.get("GSR_DEEP_FACTOR_BWD", "2.0")),
-                            os.environ.get("GSR_DEEP_FACTOR_BWD_SCALED", "1") != "0")
+        g = _tuning.get
+        _deep_cache["v"] = (float(g("deep_factor")), int(g("deep_min")), int(g("small_grid")), int(g("small_grid_min")),
+                            int(g("small_grid_bwd")), float(g("deep_factor_bwd")), bool(int(g("deep_factor_bwd_scaled"))))
     return _deep_cache["v"]
+
+
+@_tuning.on_change
+def _drop_tuning_caches():
+    _segment_cache.clear()
+    _order_cache.clear()
+    _deep_cache.clear()
 
 
 class _RasterDesc(C.Structure):  # gsr_raster_desc (include/gsraster.h)

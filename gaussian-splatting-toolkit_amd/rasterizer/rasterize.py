@@ -25,6 +25,7 @@ from torch import Tensor
 from torch.autograd import Function
 
 import rasterizer.cuda as _C
+from rasterizer.cuda import _tuning
 
 # One entry, shared by every thread of the process.  Readers take a SNAPSHOT under `_state_lock`
 # and writers replace all four fields under it, so forwards interleaved on one device (an
@@ -92,7 +93,7 @@ _pinned_count = {}
 
 
 def _speculation_enabled() -> bool:
-    return os.environ.get("GSR_NO_SPECULATION", "0") in ("", "0") and \
+    return not int(_tuning.get("no_speculation")) and \
         os.environ.get("GSR_TILE_SORT", "s")[:1] not in ("r", "m")
 
 
@@ -135,14 +136,14 @@ def _speculative_capacity_locked(device, num_points, tile_bounds, exact):
 # every entry lies behind the depth at which its tile saturates.  Then: lists of the nearest Gaussians only (a
 # prefix of the depth order, sized for ~GSR_TWO_ROUND_LEN = 400 entries per tile), a first compositing round, a
 # per-Gaussian filter that drops what can only land in finished tiles, lists of the rest, a second round that
-# resumes.  Bit-identical images; GSR_TWO_ROUND=0 switches it off, =1 forces it (once a count is known).
+# resumes.  Bit-identical images; `two_round` = "0" (_tuning.py) switches it off, "1" forces it (once a count is known).
 _two_hint = {}
 
 
 def _records_and_order(xys, radii, conics, opacity, depths, tile_bounds, extra_rows=0):
-    """Reach records + depth order of the lists without counts: one native call (GSR_FUSED_RECORDS=0: the two calls
+    """Reach records + depth order of the lists without counts: one native call (`fused_records` = 0 in _tuning.py: the two calls
     it replaces, for A/B measurements)."""
-    if os.environ.get("GSR_FUSED_RECORDS", "1") == "0":
+    if not int(_tuning.get("fused_records")):
         _, records = _C.count_reach(xys, radii, conics, opacity, tile_bounds, counts=False, extra_rows=extra_rows)
         order, _ = _C.depth_order(depths, radii, None)
         return records, order
@@ -150,7 +151,7 @@ def _records_and_order(xys, radii, conics, opacity, depths, tile_bounds, extra_r
 
 
 def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
-    mode = os.environ.get("GSR_TWO_ROUND", "auto")
+    mode = str(_tuning.get("two_round"))
     if mode in ("0", "off") or not exact or _deterministic["on"] or not _speculation_enabled():
         return None
     if os.environ.get("GSR_TILE_SORT", "")[:1] in ("s", "b"):
@@ -178,7 +179,7 @@ def _two_round_plan(device, num_points, tile_bounds, exact, radii=None):
 def _two_round_candidate(device, num_points, tile_bounds) -> bool:
     """(under `_state_lock`; changes nothing) would `_two_round_plan` consider two rounds for this view?  The same
     switches and thresholds: lists built ahead of time (one round) must not pre-empt them on deep scenes."""
-    mode = os.environ.get("GSR_TWO_ROUND", "auto")
+    mode = str(_tuning.get("two_round"))
     if mode in ("0", "off") or os.environ.get("GSR_TILE_SORT", "")[:1] in ("s", "b"):
         return False
     hint = _count_hint.get((device, tile_bounds))
@@ -190,8 +191,8 @@ def _two_round_candidate(device, num_points, tile_bounds) -> bool:
         return True
     tiles = tile_bounds[0] * tile_bounds[1]
     full = hint[1] * (num_points / hint[0])
-    return not (full / tiles < float(os.environ.get("GSR_TWO_ROUND_DEPTH", "1500"))
-                or full - float(os.environ.get("GSR_TWO_ROUND_LEN", "500")) * tiles < float(os.environ.get("GSR_TWO_ROUND_SAVED", "45e6"))
+    return not (full / tiles < float(_tuning.get("two_round_depth"))
+                or full - float(_tuning.get("two_round_len")) * tiles < float(_tuning.get("two_round_saved"))
                 or num_points < 100_000)
 
 
@@ -207,12 +208,12 @@ def _two_round_plan_locked(device, num_points, tile_bounds, mode, asked=False):
     n_last, count_last = hint
     tiles = tile_bounds[0] * tile_bounds[1]
     full = count_last * (num_points / n_last)
-    min_depth = float(os.environ.get("GSR_TWO_ROUND_DEPTH", "1500"))
-    target = float(os.environ.get("GSR_TWO_ROUND_LEN", "500"))
+    min_depth = float(_tuning.get("two_round_depth"))
+    target = float(_tuning.get("two_round_len"))
     # two rounds cost ~0.3 ms (14 more launches, and the count check has little GPU work left to hide behind); a
     # list entry that is never built saves ~8 ps: worth it from ~45 M avoided entries on (3 M Gaussians at 1080p,
     # 33 M entries: break-even; 3 M at 4K, 98 M: -13 %)
-    min_saved = float(os.environ.get("GSR_TWO_ROUND_SAVED", "45e6"))
+    min_saved = float(_tuning.get("two_round_saved"))
     if mode != "1" and (full / tiles < min_depth or full - target * tiles < min_saved or num_points < 100_000):
         return None
     f = th.get("f")
@@ -328,7 +329,7 @@ def _two_round_feedback(plan, c1, c2, unfinished):
     return note
 
 
-_POLL_YIELD = os.environ.get("GSR_POLL_YIELD", "1") != "0"  # (A/B knob: 0 = spin without yielding the GIL)
+_POLL_YIELD = bool(int(_tuning.get("poll_yield")))  # (0 = spin without yielding the GIL)
 
 
 class _PendingCount:
@@ -647,7 +648,7 @@ def _build_fresh(xys, depths, radii, conics, num_tiles_hit, opacity, tile_bounds
     capacity = _speculative_capacity(xys.device, num_points, tile_bounds, exact) if speculate else None
 
     if fuse is not None and exact and capacity is not None and not banded and not det and \
-            os.environ.get("GSR_ONE_CALL", "1") != "0":
+            int(_tuning.get("one_call")):
         # records + depth order + device-sized lists + compositing: ONE native call (with or without counts, as
         # gsr_bin_sorted_needs_counts decides in there); the count comes back through the pinned slot
         pending = _PendingCount(xys.device)

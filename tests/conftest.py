@@ -28,3 +28,18 @@ def has_gpu() -> bool:
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def tune():
+    """Override rows of the dispatch rules' tuning table (rasterizer/cuda/_tuning.py) for one test:
+    ``tune(two_round="0", depth_segments=5)`` REPLACES the overrides; everything is restored afterwards."""
+    from rasterizer.cuda import _tuning
+
+    saved = _tuning.overrides()
+
+    def _set(**rows):
+        _tuning.set_overrides(rows)
+
+    yield _set
+    _tuning.set_overrides(saved)

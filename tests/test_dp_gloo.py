@@ -11,6 +11,11 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# The workers hand tensors back through a queue and leave: with the default descriptor-passing strategy the parent has
+# to reach the (still living) worker when it unpickles them, and a worker that has already exited resets the connection
+# (seen once the host got faster than the workers' barrier).  Named shared-memory files do not need the producer.
+# (spawned workers import this module: the setting applies on both sides)
+mp.set_sharing_strategy("file_system")
 
 
 def _free_port():

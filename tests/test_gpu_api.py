@@ -278,14 +278,14 @@ def test_random_view_sequences_equal_unspeculated_calls():
 
 
 def test_random_view_sequences_with_two_round_lists_forced():
-    """The same random sequences with GSR_TWO_ROUND=1: every view behind the first builds its lists in two rounds
+    """The same random sequences with `two_round` = "1" (GSR_TUNE): every view behind the first builds its lists in two rounds
     (whatever the scene: shallow, deep, nothing saturating, guessed sizes overflowing) and must still equal the
     unspeculated, uncached single walk."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GSR_TWO_ROUND="1", GSR_DEPTH_SEGMENTS="1")  # (two rounds resume ONE chain: bitwise only
+    env = dict(os.environ, GSR_TUNE='{"two_round": "1", "depth_segments": 1}')  # (two rounds resume ONE chain: bitwise only
     #                                                                     against the walk without depth segments)
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_sequence.py"), "80", "23"],
                          capture_output=True, text=True, timeout=900, env=env)
@@ -759,14 +759,14 @@ def test_binning_cache_tracks_opacity_and_conics():
     assert np.abs(c.cpu().numpy() - img)[ok].max() < 1e-4
 
 
-def test_speculative_list_sizing_never_changes_results(monkeypatch):
+def test_speculative_list_sizing_never_changes_results(monkeypatch, tune):
     """From the second view on the lists are sized from the previous count and the
     real count is checked after compositing was enqueued (rasterize.py): a right
     guess, a guess that is far too small (lists cut, then rebuilt) and the
     synchronous path give identical images and gradients."""
     import rasterizer.cuda as C
 
-    monkeypatch.setenv("GSR_TWO_ROUND", "0")  # (this scene is deep enough for two-round lists: not what is tested here)
+    tune(two_round="0")  # (this scene is deep enough for two-round lists: not what is tested here)
     from rasterizer import project_gaussians, rasterize_gaussians
     from rasterizer import rasterize as R
 
@@ -1197,7 +1197,7 @@ def test_interleaved_forwards_from_two_threads_keep_their_own_lists():
 
 
 @pytest.mark.parametrize("render_depth,fused_depth", [(False, False), (True, False), (True, True)])
-def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monkeypatch):
+def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monkeypatch, tune):
     """Deep scenes composite in two rounds (prefix lists, saturation filter, resumed walk): through
     `rasterize_gaussians` (and its cached depth pass, and the one-pass RGB + depth op) images are bit-identical to the
     single walk and gradients equal up to the order of the float atomics -- on the first two-round view and on the
@@ -1229,11 +1229,11 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
         torch.cuda.synchronize()
         return out, [p[k].grad.clone() for k in ("means3d", "scales", "quats", "opacities", "sh_coeffs")]
 
-    monkeypatch.setenv("GSR_TWO_ROUND", "0")
+    tune(two_round="0")
     R._bin_cache["key"] = None
     run()                      # first view: exact sizing, leaves the count hint
     ref, gref = run()
-    monkeypatch.setenv("GSR_TWO_ROUND", "1")
+    tune(two_round="1")
     R._two_hint.clear()
     seen = []
     orig = R._build_two_round
@@ -1253,7 +1253,7 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
     assert hint["count1"] > 0 and hint["count1"] + hint["count2"] < 0.9 * R._count_hint[(torch.device(DEV), ((W + 15) // 16, (H + 15) // 16, 1))][1]
     # a shallow view right behind a two-round one takes the single walk again -- with ITS lists (the per-call
     # state of the previous view must not leak into it: a regression test)
-    monkeypatch.setenv("GSR_TWO_ROUND", "auto")
+    tune(two_round="auto")
     sc2 = S.make_scene(5_000, cam, sh_degree=1, seed=4, scale_lo=0.003, scale_hi=0.02)
 
     def run_small():
@@ -1267,6 +1267,6 @@ def test_two_round_lists_through_the_public_ops(render_depth, fused_depth, monke
 
     a_img, a_g = run_small()
     assert len(seen) == 3
-    monkeypatch.setenv("GSR_TWO_ROUND", "0")
+    tune(two_round="0")
     b_img, b_g = run_small()
     assert torch.equal(a_img, b_img) and (a_g - b_g).abs().max().item() <= 3e-5 * b_g.abs().max().item() + 1e-12

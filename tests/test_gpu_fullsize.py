@@ -120,6 +120,13 @@ def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file
     W, H, deg = 1920, 1080, 3
     cam = S.make_camera(W, H)
     sc = S.make_scene(n, cam, sh_degree=deg, seed=42, scale_lo=scale_lo, scale_hi=scale_hi)
+    scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap)
+
+
+def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stable_pixels=0.99, within_floor=WITHIN_FLOOR):
+    """Any scene dictionary (harness.scene layout) from `cam` through the public ops against the oracle, with config 2's
+    assertions (tests/test_gpu_heldout.py runs the held-out families and a trained model through it)."""
+    W, H, n = cam.width, cam.height, sc["means3d"].shape[0]
     bg = np.array(S.BACKGROUND, np.float32)
     v_img, v_alpha = S.make_cotangents(cam)
 
@@ -153,7 +160,7 @@ def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file
     ref_img, ref_T, ref_idx, amb = O.rasterize_forward(tb, (16, 16, 1), (W, H, 1), vs, bins, gx, gc, rgbs,
                                                        sc["opacities"], bg, ambig_eps=1e-5)
     ok = ~amb
-    assert ok.mean() > 0.99
+    assert ok.mean() > min_stable_pixels
     img = npy(out["rgb"])
     assert np.abs(img - ref_img)[ok].max() < 1e-4
     assert np.abs((1 - npy(out["alpha"])[..., 0]) - ref_T)[ok].max() < 1e-4
@@ -197,7 +204,7 @@ def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file
     except (OSError, NameError):
         pass
     assert frac > stable_floor, report
-    assert ok_xy.mean() > WITHIN_FLOOR and ok_op.mean() > WITHIN_FLOOR, report
+    assert ok_xy.mean() > within_floor and ok_op.mean() > within_floor, report
     share = peak_pixel_share(gc)
     grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable, worst_cap=worst_cap, peak_share=share)
     grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable, worst_cap=worst_cap,

@@ -677,7 +677,7 @@ def test_compositing_kernels_on_random_shapes():
     assert out.stdout.count(" ok") >= 40
     # once more with the depth-segment kernels forced onto short lists (the fuzz's grids are all below the 1 100
     # tiles on which every tile above 96 entries is split): 5 runs for every list of more than one chunk
-    env = dict(os.environ, GSR_DEPTH_SEGMENTS="5", GSR_DEPTH_SEGMENTS_MIN="64", GSR_DEPTH_SEGMENTS_FWD="0")
+    env = dict(os.environ, GSR_TUNE='{"depth_segments": 5, "depth_segments_min": 64, "depth_segments_fwd": 0}')
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "fuzz_raster.py"), "40", "57"],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "mismatches: 0" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

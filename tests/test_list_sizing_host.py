@@ -11,12 +11,11 @@ TB = (120, 68, 1)          # 1920 x 1080 at 16 px
 
 
 @pytest.fixture(autouse=True)
-def clean_state(monkeypatch):
+def clean_state(monkeypatch, tune):
     for d in (R._count_hint, R._last_capacity, R._two_hint):
         d.clear()
-    for k in ("GSR_NO_SPECULATION", "GSR_TILE_SORT", "GSR_TWO_ROUND", "GSR_TWO_ROUND_DEPTH", "GSR_TWO_ROUND_LEN",
-              "GSR_TWO_ROUND_SAVED"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("GSR_TILE_SORT", raising=False)
+    tune()  # the table's defaults, whatever GSR_TUNE says
     yield
     for d in (R._count_hint, R._last_capacity, R._two_hint):
         d.clear()
@@ -38,9 +37,9 @@ def test_capacity_comes_from_the_previous_view_with_headroom_and_stays_put():
     assert R._speculative_capacity(DEV, 1_000_000, TB, True) is None                # would not fit int32 lists
 
 
-def test_no_speculation_switch(monkeypatch):
+def test_no_speculation_switch(tune):
     R._note_count(DEV, 1_000_000, TB, 4_000_000)
-    monkeypatch.setenv("GSR_NO_SPECULATION", "1")
+    tune(no_speculation=1)
     assert R._speculative_capacity(DEV, 1_000_000, TB, True) is None
 
 
@@ -86,20 +85,14 @@ def test_cached_two_segment_lists_are_a_miss_for_a_single_segment_caller():
     assert R._is_two(("two", object(), 123)) and not R._is_two(None) and not R._is_two((1, 2, 3))
 
 
-def test_depth_segments_only_where_every_tile_is_split_forward_and_backward(monkeypatch):
+def test_depth_segments_only_where_every_tile_is_split_forward_and_backward(tune):
     """rasterizer.cuda.depth_segments: runs on tile grids of up to 1 100 tiles -- the grids on which
     forward AND backward split every tile above the small-grid floor, so that which tiles are cut is a function of the
     tile's list alone and every route to the kernels rounds the same way -- and nowhere else, whatever the knobs say."""
     import rasterizer.cuda as C
 
-    def knobs(**env):
-        for k in ("GSR_DEPTH_SEGMENTS", "GSR_DEPTH_SEGMENTS_GRID", "GSR_DEPTH_SEGMENTS_MIN", "GSR_DEPTH_SEGMENTS_FWD",
-                  "GSR_SMALL_GRID", "GSR_SMALL_GRID_BWD", "GSR_SMALL_GRID_MIN", "GSR_DEEP_FACTOR", "GSR_DEEP_MIN"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, str(v))
-        C._segment_cache.clear()
-        C._deep_cache.clear()
+    def knobs(**env):  # (the rows carry the names of the environment variables they were until round 5)
+        tune(**{k[4:].lower(): v for k, v in env.items()})
 
     try:
         knobs()
@@ -121,7 +114,7 @@ def test_depth_segments_only_where_every_tile_is_split_forward_and_backward(monk
         knobs()
 
 
-def test_the_backwards_split_threshold_is_one_wave_slots_share_of_the_launch(monkeypatch):
+def test_the_backwards_split_threshold_is_one_wave_slots_share_of_the_launch(tune):
     """rasterizer.cuda.deep_tile_threshold(backward=True): GSR_DEEP_FACTOR_BWD is quoted on a 1080p grid
     and scaled by tiles / 8 160 above the small-grid limit -- the threshold is (entries) / 4 080 whatever the grid;
     GSR_DEEP_FACTOR_BWD_SCALED=0 restores the fixed factor; small grids keep their constant floor; the job order
@@ -129,13 +122,7 @@ def test_the_backwards_split_threshold_is_one_wave_slots_share_of_the_launch(mon
     import rasterizer.cuda as C
 
     def knobs(**env):
-        for k in ("GSR_DEEP_FACTOR", "GSR_DEEP_MIN", "GSR_DEEP_FACTOR_BWD", "GSR_DEEP_FACTOR_BWD_SCALED", "GSR_SMALL_GRID",
-                  "GSR_SMALL_GRID_BWD", "GSR_SMALL_GRID_MIN", "GSR_DEEP_ORDER_GRID", "GSR_DEEP_ORDER"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, str(v))
-        C._deep_cache.clear()
-        C._order_cache.clear()
+        tune(**{k[4:].lower(): v for k, v in env.items()})
 
     try:
         knobs()
@@ -198,3 +185,29 @@ def test_a_slice_of_a_larger_buffer_is_not_a_job_tail():
     big = torch.zeros(2 * nt + ints + 4096, dtype=torch.int32)
     assert not C.deep_arg(big[: 2 * nt].view(nt, 2), 8_000_000, nt, tile_bounds=t) & C.GSR_DEEP_ORDERED
     assert not C.deep_arg(big[64: 64 + 2 * nt].view(nt, 2), 8_000_000, nt, tile_bounds=t) & C.GSR_DEEP_ORDERED
+
+
+def test_the_tuning_table_rejects_unknown_rows_and_reads_gsr_tune_once(monkeypatch):
+    from rasterizer.cuda import _tuning as T
+
+    saved = T.overrides()
+    try:
+        with pytest.raises(ValueError):
+            T.set_overrides({"deep_facter": 1.5})
+        T.set_overrides({"deep_factor": 1.5})
+        import rasterizer.cuda as C
+
+        assert C.deep_tile_threshold(8_160_000, 8160) == 1500 and T.get("deep_min") == T.TABLE["deep_min"][0]
+        T.set_overrides()
+        assert C.deep_tile_threshold(8_160_000, 8160) == 1200
+        monkeypatch.setattr(T, "_over", None)
+        monkeypatch.setenv("GSR_TUNE", '{"depth_segments": 4}')
+        assert T.get("depth_segments") == 4
+        monkeypatch.setattr(T, "_over", None)
+        monkeypatch.setenv("GSR_TUNE", '{"nope": 1}')
+        with pytest.raises(ValueError):
+            T.get("depth_segments")
+    finally:
+        T.set_overrides(saved)
+    for name, (default, record) in T.TABLE.items():
+        assert isinstance(record, str) and len(record) > 20, name  # every row says where its value comes from

@@ -56,6 +56,22 @@ def _cpu():
     return [c, node]
 
 
+def round_trip_us(reps=400):
+    """One blocking read-back as the unchanged models issue it: a small kernel and `.item()` (hipMemcpy D2H + wait);
+    the median wall time of the pair with the queue otherwise empty -- the box / runtime, nothing of the rasterizer."""
+    x = torch.ones(1024, device=dev)
+    for _ in range(50):
+        (x.sum() == 0).item()
+    ts = []
+    for _ in range(reps):
+        a = time.perf_counter()
+        (x.sum() == 0).item()
+        ts.append(time.perf_counter() - a)
+    ts = np.array(ts) * 1e6
+    return {"p10": round(float(np.percentile(ts, 10)), 1), "p50": round(float(np.median(ts)), 1), "p90": round(float(np.percentile(ts, 90)), 1)}
+
+
+rt_before = round_trip_us()
 cpu_start = _cpu()
 t0 = time.perf_counter()
 res = train(cfg, dev, 0, 1)
@@ -66,6 +82,7 @@ from rasterizer import rasterize as _RZ  # noqa: E402
 
 out["counters"] = {k: v for k, v in _RZ.counters.items() if v}
 out["cpu_start_end"] = [cpu_start, _cpu()]
+out["round_trip_us_before_after"] = [rt_before, round_trip_us()]
 out["affinity"] = len(os.sched_getaffinity(0))
 try:
     out["gpu_numa_node"] = open("/sys/class/drm/card0/device/numa_node").read().strip()
