@@ -21,21 +21,18 @@
 // splat (72 per tile-splat).  Here a lane first folds its pixels into six
 // moments of w = vis*v_alpha (sum w, w dx, w dy, w dx^2, w dx dy, w dy^2) + the
 // rgb sums, turns them into the 9 gradient components, and then G splats x 9
-// components lane-partials (G = 4 by default, 8 selectable) are reduced together
+// components lane-partials (G = 4) are reduced together
 // with a halving butterfly: v_permlane32_swap / v_permlane16_swap (new on
 // gfx950) and DPP row ops, every step halving the number of live values, ~20
 // instructions per splat instead of 54.  The butterfly ends with one fully
 // reduced (splat, component) per lane, so one wave-wide global_atomic_add_f32
-// retires 32 (G=4) or 64 (G=8) components: 9 atomics per tile-splat instead of 72.
+// retires 32 components: 9 atomics per tile-splat instead of 72.
 #include <stdlib.h>
 
 #include <algorithm>
 
 #include "raster_common.h"
 
-#ifndef GSR_BWD_GROUP
-#define GSR_BWD_GROUP 4
-#endif
 // (the A/B variants of this kernel that lost -- the cross-row sum on the matrix pipe / through LDS, more resident waves,
 //  three selects instead of the validity fold -- live in tools/exp/bwd_variants.patch with their records)
 
@@ -79,49 +76,12 @@ __device__ __forceinline__ float halve(float x, float y, bool bit) {
 }
 
 // Wave-wide sums of G*9 lane-partials P[9*j + c] (splat j < G, component c < 9).
-//  G == 8: lane l ends with component comp_of_lane(l) of splat l>>3 in `main_v`
-//          and component 8 of splat l>>3 in `extra_v` (all 8 lanes of a group).
+//  (G == 8, one butterfly per eight splats, was selectable until round 6: tools/exp/bwd_variants.patch)
 //  G == 4: lane l ends with component comp_of_lane(l) of splat l>>4 in `main_v`
 //          (duplicated in lanes l and l^2) and component 8 of splat l>>4 in
 //          `extra_v` (all 16 lanes of the row).
 template <int G>
 struct Butterfly;
-
-template <>
-struct Butterfly<8> {
-  static __device__ __forceinline__ int splat_of_lane(int lane) { return lane >> 3; }
-  static __device__ __forceinline__ int comp_of_lane(int lane) {
-    return ((lane & 4) ? 4 : 0) + ((lane & 1) ? 2 : 0) + ((lane & 2) ? 1 : 0);
-  }
-  static __device__ __forceinline__ bool owns_main(int) { return true; }
-  static __device__ __forceinline__ bool owns_extra(int lane) { return (lane & 7) == 0; }
-  // component 0's holder receives component 1 of the same splat and vice versa
-  static __device__ __forceinline__ float swap01(float v) { return dpp<DPP_QUAD_XOR2>(v); }
-  static __device__ __forceinline__ void run(float (&P)[72], int lane, float &main_v, float &extra_v) {
-    float Q[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) Q[i] = fold32(P[i], P[i + 36]);  // lane bit 5 <-> splat bit 2
-    float R[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) R[i] = fold16(Q[i], Q[i + 18]);  // lane bit 4 <-> splat bit 1
-    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
-    float S[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) S[i] = halve<DPP_ROW_ROR8>(R[i], R[i + 9], b3);  // splat bit 0
-    float U[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) U[i] = halve<DPP_ROW_HALF_MIRROR>(S[i], S[i + 4], b2);
-    float V[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) V[i] = halve<DPP_QUAD_XOR1>(U[i], U[i + 2], b0);
-    main_v = halve<DPP_QUAD_XOR2>(V[0], V[1], b1);
-    float e = S[8];
-    e += dpp<DPP_ROW_HALF_MIRROR>(e);
-    e += dpp<DPP_QUAD_XOR1>(e);
-    e += dpp<DPP_QUAD_XOR2>(e);
-    extra_v = e;
-  }
-};
 
 template <>
 struct Butterfly<4> {
@@ -922,25 +882,14 @@ GSR_EXPORT int gsr_rasterize_backward_ex(
   }
   const int tiles_x = (int)gsr_cdiv(img_width, 16), tiles_y = (int)gsr_cdiv(img_height, 16);
   const int num_tiles = tiles_x * tiles_y;
-  // A/B knob for the reduction group size (4 or 8 splats per butterfly)
-  static const int group = [] {
-    const char *e = getenv("GSR_BWD_GROUP");
-    return (e && atoi(e) == 8) ? 8 : (e && atoi(e) == 4) ? 4 : GSR_BWD_GROUP;
-  }();
   const unsigned base = gsr_xcd_grid(tiles_x, num_tiles / tiles_x);
   const int deep = gsr_prepare_jobs(deep_tile_threshold, tiles_x, tiles_y, tile_bins, s);
-#define GSR_LAUNCH_T16(G)                                                                          \
-  hipLaunchKernelGGL((raster_bwd_tile16_kernel<G, false>), dim3(deep ? 4 * base : base),            \
-                     dim3(64), 0, s, tiles_x,                                                        \
-                     num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,               \
-                     reinterpret_cast<const int2 *>(tile_bins),                                     \
-                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background,  \
-                     final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,        \
-                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep, base, \
-                     (float *)nullptr, (unsigned char *)nullptr, (const int2 *)nullptr, 0)
-  if (group == 8) GSR_LAUNCH_T16(8);
-  else GSR_LAUNCH_T16(4);
-#undef GSR_LAUNCH_T16
+  hipLaunchKernelGGL((raster_bwd_tile16_kernel<4, false>), dim3(deep ? 4 * base : base), dim3(64), 0, s, tiles_x,
+                     num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,
+                     opacities, background, final_Ts, final_idx, v_output, v_output_alpha, v_xy, v_conic, v_colors,
+                     v_opacity, (const float *)nullptr, 0.f, (const float *)nullptr, (float *)nullptr, deep, base,
+                     (float *)nullptr, (unsigned char *)nullptr, (const int2 *)nullptr, 0);
   GSR_CHECK_LAUNCH("rasterize_backward(tile16)");
   return GSR_OK;
 }
