@@ -478,14 +478,9 @@ char tile_sort_mode(int tiles_x, int tiles_y, bool have_records, int num_bands, 
     const char *e = getenv("GSR_TILE_SORT");
     return e ? e[0] : '\0';
   }();
-  static const long long p2_min = [] {
-    const char *e = getenv("GSR_P2_MIN");
-    return e ? atoll(e) : 1000000ll;
-  }();
-  static const double p2_per_n = [] {
-    const char *e = getenv("GSR_P2_PER_N");
-    return e ? atof(e) : 0.0;
-  }();
+  // (from how many list entries the two-level partition is ahead of the single pass: measured in round 2, see above)
+  constexpr long long p2_min = 1000000ll;
+  constexpr double p2_per_n = 0.0;
   if (forced == 'r' || forced == 'm') return forced;
   const int bands = gsr_tile_band_rows(tiles_x, tiles_y, nullptr);
   const bool p2_ok = have_records && num_bands == 1 && !want_slots && gsr_tile_partition2_supported(tiles_x, tiles_y);

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
           if constexpr (RGBD) seg_extra[at] = ce[p];
         }
       }
+      trace_end(trace, trace_t0, tile, allowed, range.y - range.x);  // (a run's wave: the run's length)
       return;
     }
   }

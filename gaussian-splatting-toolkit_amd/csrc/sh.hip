@@ -587,15 +587,8 @@ GSR_EXPORT int gsr_sh_backward_views(unsigned num_points, unsigned degree, unsig
   return GSR_OK;
 }
 
-// A/B knob: waves per workgroup of the K = 16 kernels (GSR_SH_WAVES = 1 / 2 / 4)
-static int sh16_waves() {
-  static const int v = [] {
-    const char *e = getenv("GSR_SH_WAVES");
-    const int w = e ? atoi(e) : 4;
-    return (w == 1 || w == 2) ? w : 4;
-  }();
-  return v;
-}
+// waves per workgroup of the K = 16 kernels (1 / 2 / 4 measured in round 3: 4)
+static int sh16_waves() { return 4; }
 
 GSR_EXPORT int gsr_sh_forward(unsigned num_points, unsigned degree, unsigned degrees_to_use,
                               const float *viewdirs, const float *coeffs, float *colors,

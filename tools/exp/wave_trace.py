@@ -6,7 +6,7 @@ Every wave of the 16x16 compositing kernels records the constant 100-MHz clock a
 mask, the tile's list length and its hardware slot.  From that: the launch's span, how many waves were resident over
 time (the tail), how evenly the SIMDs were loaded, how duration relates to list length, and what a perfectly packed
 schedule of the same waves would take -- the attribution VERDICT r4 asked for before acting on the trained
-distribution's VALU-busy 0.52.  Environment knobs of the rasterizer (GSR_DEEP_MIN, GSR_DEEP_FACTOR ...) apply."""
+distribution's VALU-busy 0.52.  GSR_TUNE overrides of the tuning table apply."""
 import argparse
 import ctypes
 import os
@@ -125,8 +125,7 @@ def main():
     torch.cuda.synchronize()
     lib().gsr_debug_wave_trace(None, ctypes.c_uint(0))
     rec = buf.cpu().numpy().view(np.uint64)
-    print(f"scene {args.scene}, {sc['means3d'].shape[0]} Gaussians, {W}x{H} ({tiles} tiles); "
-          f"GSR_DEEP_MIN={os.environ.get('GSR_DEEP_MIN', 'default')} GSR_DEEP_FACTOR={os.environ.get('GSR_DEEP_FACTOR', 'default')}")
+    print(f"scene {args.scene}, {sc['means3d'].shape[0]} Gaussians, {W}x{H} ({tiles} tiles); GSR_TUNE={os.environ.get('GSR_TUNE', '{}')}")
     analyse("forward ", rec[:cap], 8)
     analyse("backward", rec[cap:], 4)
     if args.out:
