@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
     float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr, const unsigned zero_words,
     const int round, int *__restrict__ tile_flags, const int idx_base, const int seg_count = 1, const int seg_min = 0,
     float4 *__restrict__ seg_raw = nullptr, int *__restrict__ seg_last = nullptr,
-    float *__restrict__ seg_extra = nullptr) {
+    float *__restrict__ seg_extra = nullptr, float *__restrict__ seg_marks = nullptr) {
   // Two-round compositing (gsr_rasterize_forward_round): the lists of the nearest
   // Gaussians are a PREFIX of every tile's list.  round 1 composites such prefix lists and leaves the per-pixel
   // state of a wave that still has a live pixel RAW -- final_Ts = signed T (< 0: finished), out_img / out_extra = C
@@ -121,6 +121,27 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
       split = true;
       range.x += seg_k * sl;
       range.y = min(range.x + sl, range.y);
+      // SATURATION MARKS.  Every run walks from T = 1, so a scene that saturates early (a deep list of opaque splats:
+      // the single walk stops after a fraction of it) would be walked in full, run by run.  A run's wave therefore
+      // leaves the LARGEST transmittance any of its 64 pixels ends the run with (0 for a finished pixel) in
+      // seg_marks[16 (4 tile + sub-tile) + run], and a later run first multiplies the marks of the runs in front of it
+      // that have been written so far: a pixel's true incoming T is at most the product of its own runs' T, hence at
+      // most the product of the maxima -- at 1e-4 or below EVERY pixel of the sub-tile has crossed the stop rule in
+      // front of this run, which then draws nothing and is never read (raster_fwd_segresolve_kernel stops at the
+      // crossing run).  Exact: it only skips work whose result is unused.  Blocks start in block order (run-major) and
+      // all runs of a sub-tile sit on one XCD (4 base_grid is a multiple of 8), so with a grid beyond the chip's wave
+      // slots the later runs find the earlier marks; a mark not yet written (0) counts as 1.
+      if (seg_marks && seg_k > 0) {
+        const float *mk = seg_marks + 16 * (4 * (size_t)tile + __builtin_ctz(allowed));
+        float v = 1.f;
+        if ((int)threadIdx.x < seg_k) {
+          const float m = __hip_atomic_load(mk + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = m > 0.f ? m : 1.f;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v *= __shfl_xor(v, o);
+        if (__builtin_amdgcn_readfirstlane(__float_as_uint(v)) <= __float_as_uint(0.9f * GSR_T_EPS)) return;  // (v > 0)
+      }
     }
   }
   if (round == 2) {  // only the sub-tiles round 1 left raw
@@ -277,6 +298,15 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
           if constexpr (RGBD) seg_extra[at] = ce[p];
         }
       }
+      if (seg_marks) {
+        const int sub = __builtin_ctz(allowed);
+        float m = fmaxf(sub == 0 ? T[0] : sub == 1 ? T[1] : sub == 2 ? T[2] : T[3], 0.f);  // (finished / outside: 0)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0)
+          __hip_atomic_store(seg_marks + 16 * (4 * (size_t)tile + sub) + seg_k, fmaxf(m, 1.17549435e-38f), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
       trace_end(trace, trace_t0, tile, allowed, range.y - range.x);  // (a run's wave: the run's length)
       return;
     }
@@ -300,6 +330,11 @@ __global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
   }
   trace_end(trace, trace_t0, tile, allowed, trace_len);
   job_stats_end(job, 0, stats_t0, trace_len);
+}
+
+__global__ __launch_bounds__(256) void seg_marks_clear_kernel(float *__restrict__ marks, const unsigned n) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) marks[i] = 0.f;
 }
 
 // The crossing test's margin: prefix x P_k against 1e-4 (1 + margin).  The single walk's T at the end of run k and the
@@ -349,11 +384,11 @@ __global__ __launch_bounds__(64) void raster_fwd_segresolve_kernel(
     const bool cross = open && (r.w < 0.f || prefix * r.w <= GSR_SEG_CROSS);
     kstar = cross ? k : kstar;
     const bool take = open && !cross;
-    const float w = take ? prefix : 0.f;
-    cr += w * r.x;
-    cg += w * r.y;
-    cb += w * r.z;
-    if constexpr (RGBD) ce += w * e;
+    // (selects, not products with 0: the records of runs behind the crossing run may never have been written)
+    cr = take ? cr + prefix * r.x : cr;
+    cg = take ? cg + prefix * r.y : cg;
+    cb = take ? cb + prefix * r.z : cb;
+    if constexpr (RGBD) ce = take ? ce + prefix * e : ce;
     last = take ? max(last, l) : last;
     prefix = take ? prefix * r.w : prefix;  // stays at the crossing run's incoming T
   }
@@ -787,8 +822,8 @@ GSR_EXPORT size_t gsr_rasterize_forward_seg_workspace_bytes(unsigned img_height,
   const size_t px = (size_t)img_height * img_width;
   const size_t tiles = (size_t)gsr_cdiv(img_width, 16) * gsr_cdiv(img_height, 16);
   // per run: raw states (float4) | last drawn indices | the extra channel's sums; then per pixel its crossing run,
-  // per (tile, sub-tile) the mask of runs to re-walk
-  return (size_t)segments * px * (16 + 4 + 4) + px * 4 + tiles * 16;
+  // per (tile, sub-tile) the mask of runs to re-walk and the 16 saturation marks
+  return (size_t)segments * px * (16 + 4 + 4) + px * 4 + tiles * 16 + tiles * 4 * 16 * 4;
 }
 
 GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
@@ -835,13 +870,16 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
   float *extrap = reinterpret_cast<float *>(lastp + (size_t)segments * px);  // (written and read with `extra` only)
   int *kstarp = reinterpret_cast<int *>(extrap + (size_t)segments * px);
   int *flagsp = kstarp + px;
+  float *marksp = reinterpret_cast<float *>(flagsp + 4 * (size_t)num_tiles);
+  hipLaunchKernelGGL(seg_marks_clear_kernel, dim3((unsigned)((64 * (size_t)num_tiles + 255) / 256)), dim3(256), 0, s, marksp,
+                     64u * (unsigned)num_tiles);
 #define GSR_LAUNCH_FWD_SEG(RGBD_)                                                                                       \
   hipLaunchKernelGGL((raster_fwd_tile16_kernel<RGBD_, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,      \
                      tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \
                      reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,   \
                      opacities, background, out_img, final_Ts, final_idx, extra, extra_background, out_extra,           \
                      deep_arg, base, out_alpha, static_cast<unsigned *>(zero_ptr),                                       \
-                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, raw, lastp, extrap);          \
+                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, raw, lastp, extrap, marksp);  \
   hipLaunchKernelGGL(raster_fwd_segresolve_kernel<RGBD_>, dim3(4u * base), dim3(64), 0, s, tiles_x, num_tiles,          \
                      (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), background, out_img,    \
                      final_Ts, final_idx, extra_background, out_extra, deep_arg, base, out_alpha, segments, seg_min,    \

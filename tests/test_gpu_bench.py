@@ -76,7 +76,8 @@ def test_eight_ranks_as_the_driver_will_launch_them():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
-    assert abs(d["value"] - 8 * 320 * 180 / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    # (whole-job value: eight ranks' pixels over the slowest rank's time; the line rounds it to 0.01 Mpix/s)
+    assert abs(d["value"] - 8 * 320 * 180 / d["ms_per_step"] / 1e3) < 0.01 * d["value"] + 0.006
     assert d["allreduce_bytes"] > 0 and "dp8" in d["config"]["parallelism"]
     t = d["train"]
     assert t and "error" not in t, t

@@ -71,7 +71,20 @@ def round_trip_us(reps=400):
     return {"p10": round(float(np.percentile(ts, 10)), 1), "p50": round(float(np.median(ts)), 1), "p90": round(float(np.percentile(ts, 90)), 1)}
 
 
+def python_speed_us():
+    """A fixed piece of pure-Python work (no GPU): how fast THIS process's interpreter thread runs right now."""
+    best = 1e9
+    for _ in range(5):
+        a = time.perf_counter()
+        x = 0
+        for i in range(200_000):
+            x += i & 7
+        best = min(best, time.perf_counter() - a)
+    return round(best * 1e6, 1)
+
+
 rt_before = round_trip_us()
+py_before = python_speed_us()
 cpu_start = _cpu()
 t0 = time.perf_counter()
 res = train(cfg, dev, 0, 1)
@@ -83,6 +96,7 @@ from rasterizer import rasterize as _RZ  # noqa: E402
 out["counters"] = {k: v for k, v in _RZ.counters.items() if v}
 out["cpu_start_end"] = [cpu_start, _cpu()]
 out["round_trip_us_before_after"] = [rt_before, round_trip_us()]
+out["python_200k_loop_us_before_after"] = [py_before, python_speed_us()]
 out["affinity"] = len(os.sched_getaffinity(0))
 try:
     out["gpu_numa_node"] = open("/sys/class/drm/card0/device/numa_node").read().strip()

@@ -21,6 +21,8 @@ from rasterizer.cuda import _tuning as T  # noqa: E402
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 CELLS = [(480, 270, 300_000), (960, 540, 500_000), (1920, 1080, 1_000_000), (3840, 2160, 1_000_000)]
+if os.environ.get("REGRET_SMALL"):  # the split-all grids only
+    CELLS = [(480, 270, 300_000), (400, 300, 150_000)]
 if os.environ.get("REGRET_QUICK"):
     CELLS = [(480, 270, 100_000), (1920, 1080, 200_000)]
 ALTS = [("default", {}),
