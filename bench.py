@@ -122,6 +122,46 @@ CALIBRATION_REFERENCE_VALU_TOPS = 67.0
 FIXED_WARMUP_SECONDS = 0.35  # of the workload itself, ahead of the timed steps, whatever --warmup says
 
 
+def bind_cpus(dev_index, local_rank, mode="auto"):
+    """Bind this process (and everything it spawns) to a few cores of its GPU's NUMA node -- what `numactl
+    --cpunodebind` / a launcher's per-rank binding does on a multi-socket host.  Round 6 found the "second mode" of the
+    host-bound training phases here (profiles/r06_render480_modes.txt): on a 2 x 64-core box an UNBOUND process starts
+    on the far socket and has its threads (interpreter, HIP runtime, autograd engine) spread over 256 CPUs -- the 480x270
+    render phase with the models' read-backs then reads 0.41-0.61 ms from process to process; bound to eight cores of
+    the GPU's socket it reads 0.343-0.356 ms in six processes of six.  The GPU work is the same; only host turn-around
+    between read-backs changes.  -> the description for the line's `config.cpu_bind`, or None when nothing was bound
+    (`--cpu-bind off`, no sysfs, a single-node host, an affinity mask already narrowed by the launcher)."""
+    if mode == "off" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        have = sorted(os.sched_getaffinity(0))
+        if len(have) < os.cpu_count():  # somebody (taskset, numactl, the launcher) has already chosen: leave it
+            return f"inherited ({len(have)} CPUs)"
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            node = 0
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        # physical cores first (the first range of a node's cpulist; SMT siblings follow), skipping the first eight --
+        # where interrupts and housekeeping usually sit -- eight cores per local rank
+        first = [c for c in cpus if c in have]
+        per = 8
+        start = 8 + per * local_rank
+        if start + per > len(first):
+            start = (per * local_rank) % max(1, len(first) - per + 1)
+        chosen = first[start:start + per]
+        if len(chosen) < 2:
+            return None
+        os.sched_setaffinity(0, chosen)
+        return f"cpus {chosen[0]}-{chosen[-1]} of NUMA node {node} (GPU {bdf})"
+    except Exception as e:  # never cost the line
+        return f"not bound ({type(e).__name__})"
+
+
 def calibration(dev, repeats=5):
     """Two fixed workloads on the bench's stream, right after the timed region (same clock state): a VALU-bound fma
     loop and a 1 GB copy (gsr_calibrate_valu / gsr_calibrate_copy).  Best and median of `repeats`."""
@@ -329,6 +369,7 @@ def train_only(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dev_index = local_rank % torch.cuda.device_count()
+    cpu_bind = bind_cpus(dev_index, local_rank, args.cpu_bind)  # (a spawned N = 1 leg inherits the raster bench's binding)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = args.backend
@@ -435,6 +476,7 @@ def train_only(args):
             "allreduce_bytes_step_bytes": res["allreduce_bytes"] or None,
             "replicas_identical": res.get("replicas_identical"),
             "parallelism": (f"dp{world} per-view, {backend}" if world > 1 else "single"),
+            "cpu_bind": cpu_bind,
             "update": res["update"],
         }
         brief = lambda r: {"iters_per_s": round(r["iters_per_s"], 1), "gaussians_end": r["num_gaussians_end"],  # noqa: E731
@@ -525,10 +567,14 @@ def train_record(args, world):
     cmd = [sys.executable, os.path.abspath(__file__), "--train-only", "--gpus", str(world), "--train-iters",
            str(args.train_iters), "--backend", args.backend, "--cogs-iters", str(args.cogs_iters)] \
         + (["--train-small"] if args.train_small else []) + (["--no-cogs"] if args.no_cogs else []) \
+        + ["--cpu-bind", args.cpu_bind] \
         + (["--train-export-ply", ply] if ply else [])
     t0 = time.perf_counter()
     try:
-        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=args.train_timeout)
+        # (N > 1: the training leg spawns its own ranks, and each binds itself -- they must not all inherit rank 0's cores)
+        widen = (lambda: os.sched_setaffinity(0, range(os.cpu_count()))) if (world > 1 and hasattr(os, "sched_setaffinity")) else None
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=args.train_timeout,
+                             preexec_fn=widen)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:
             return {"error": f"rc {out.returncode}", "stderr_tail": out.stderr[-800:]}
@@ -702,6 +748,10 @@ def main():
     ap.add_argument("--no-cpu-one-thread", action="store_true",
                     help="skip the one-thread CPU baseline on the 60 k-Gaussian subset (10-30 s); the all-threads baseline "
                          "and `parity_vs_oracle` stay")
+    ap.add_argument("--cpu-bind", default="auto", choices=["auto", "off"],
+                    help="auto: bind each rank to eight cores of its GPU's NUMA node before anything runs (bench.bind_cpus: "
+                         "the host-bound training phases have two modes on a multi-socket host otherwise); off: leave the "
+                         "affinity as inherited")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter passes (HBM traffic, VALU busy) that rank 0 runs after the timed "
                          "region at N=1")
@@ -777,6 +827,7 @@ def main():
     if args.train_only:
         return train_only(args)
     dev_index = local_rank % torch.cuda.device_count()
+    cpu_bind = bind_cpus(dev_index, local_rank, args.cpu_bind)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = args.backend
@@ -1255,6 +1306,7 @@ def main():
                 "list_entries": list_entries,
                 "mean_gaussians_per_tile": round(num_intersects / tiles, 1),
                 "tile_list_length": tile_hist, "scene": args.scene, "two_round_lists": two_round,
+                "cpu_bind": cpu_bind,
                 # (inside `config` so that the driver's `parsed` keeps them)
                 "timing": {"ms_per_step_median": round(float(np.median(step_ms)), 4),
                            "ms_per_step_p10_p90": [round(float(np.percentile(step_ms, 10)), 4),

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Lease 7: the held-out / trained-model parity tests with their full output; the training record with and without the
+# CPU binding; kernel-time regret of the depth-segment rows on split-all grids (wall time is host-bound there).
+out=$PWD/gpurun_out/lease7; mkdir -p $out
+timeout 900 python -m pytest tests/test_gpu_heldout.py -q -x 2>&1 | tail -60 > $out/heldout.txt; tail -5 $out/heldout.txt
+timeout 900 python -m pytest tests/test_gpu_heldout.py -q 2>&1 | grep -E "^(FAILED|PASSED|E  |tests/)|passed|failed|AssertionError|assert " | head -80 > $out/heldout_all.txt
+for bind in auto off auto off; do
+  timeout 600 python bench.py --train-only --train-iters 7000 --no-cogs --cpu-bind $bind 2>$out/train_$bind.err | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('cpu-bind $bind:', d.get('cpu_bind'), '| config3', d['iters_per_s'], 'it/s; with read-backs', d['iters_per_s_with_caller_syncs'], '; render by res (read-backs)', {k: v['render'] for k, v in d['with_caller_syncs']['phase_ms_median_by_resolution'].items()}, 'slow share', d['with_caller_syncs'].get('render_slow_share_lowest_resolution'), '; unchanged caller', d.get('iters_per_s_unchanged_caller'), '; fixed 1M', d['fixed_1m']['iters_per_s'], '; one-op', d['one_op_path']['iters_per_s'])" | tee -a $out/cpu_bind_ab.txt
+done
+run() {  # label, env, args...
+  local label=$1; shift
+  python bench.py "$@" --steps 60 --warmup 10 --train-iters 0 --no-cpu-baseline --no-pmc --no-synced-regions 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); k = d['kernels']
+print('$label', 'fwd', k['raster_fwd']['ms'], 'bwd', k['raster_bwd']['ms'], 'sum', round(k['raster_fwd']['ms'] + k['raster_bwd']['ms'], 4), 'wall', d['ms_per_step'])"
+}
+for scene in room floaters needles; do
+  for res in "480 270 300000" "400 300 150000"; do
+    set -- $res
+    for t in '{}' '{"depth_segments": 1}' '{"depth_segments": 8}' '{"depth_segments_fwd": 8}' '{"depth_segments_fwd": 4}'; do
+      GSR_TUNE="$t" run "$scene $1x$2 $t" --scene $scene --gaussians $3 --width $1 --height $2
+    done
+  done
+done 2>&1 | tee $out/regret_small_kernel_time.txt
