@@ -25,3 +25,17 @@ for scene in room floaters needles; do
     done
   done
 done 2>&1 | tee $out/regret_small_kernel_time.txt
+# the wave trace's finding: the 480x270 launches end on ONE unsegmented walk (a 459-entry tile, below depth_segments_min = 512)
+young=/tmp/config3_young.ply; ply=/tmp/config3_trained.ply
+python tools/exp/config3_rate.py 1500 $young > $out/train_1500.json 2> $out/train.err
+python tools/exp/config3_rate.py 7000 $ply > $out/train_7000.json 2>> $out/train.err
+for scene in "ply:$young" "ply:$ply" uniform room; do
+  for m in 512 256 128 64; do
+    GSR_TUNE="{\"depth_segments_min\": $m}" run "$scene 480x270 depth_segments_min=$m" --scene $scene --gaussians 300000 --width 480 --height 270
+  done
+done 2>&1 | tee $out/segments_min.txt
+for m in 512 128; do
+  GSR_TUNE="{\"depth_segments_min\": $m}" python tools/exp/config3_rate.py 7000 2>/dev/null | tail -1 | cut -c1-400 | sed "s/^/config3 depth_segments_min=$m: /" | tee -a $out/segments_min.txt
+  GSR_TUNE="{\"depth_segments_min\": $m}" python tools/exp/config3_rate.py 7000 2>/dev/null | tail -1 | cut -c1-400 | sed "s/^/config3 depth_segments_min=$m: /" | tee -a $out/segments_min.txt
+done
+GSR_TUNE='{"depth_segments_min": 128}' timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_api.py -q -k "segment or compositing or oracle" 2>&1 | tail -3 | tee -a $out/segments_min.txt
