@@ -39,3 +39,12 @@ for m in 512 128; do
   GSR_TUNE="{\"depth_segments_min\": $m}" python tools/exp/config3_rate.py 7000 2>/dev/null | tail -1 | cut -c1-400 | sed "s/^/config3 depth_segments_min=$m: /" | tee -a $out/segments_min.txt
 done
 GSR_TUNE='{"depth_segments_min": 128}' timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_api.py -q -k "segment or compositing or oracle" 2>&1 | tail -3 | tee -a $out/segments_min.txt
+# are the short kernels of the 480x270 phase clock-bound?  (a run wave lives 17.8 us for 64 entries, the launch is paced at ~520 workgroups/us)
+( rocm-smi --showclocks 2>&1 | grep -i "sclk\|mclk\|fclk" | head -8
+  run "young 480x270 default power policy" --scene ply:$young --width 480 --height 270
+  rocm-smi --setperflevel high 2>&1 | tail -2
+  rocm-smi --showclocks 2>&1 | grep -i "sclk\|mclk\|fclk" | head -8
+  run "young 480x270 perflevel high" --scene ply:$young --width 480 --height 270
+  run "uniform 1M 1080p perflevel high" --scene uniform
+  rocm-smi --setperflevel auto 2>&1 | tail -1 ) 2>&1 | tee $out/clocks.txt
+tools/exp/dispatch_bench 2>&1 | tee $out/dispatch_bench.txt
