@@ -386,9 +386,6 @@ class ViewGraph:
         torch.cuda.current_stream(self.device).wait_stream(side)
         for t in self.params.values():
             t.grad = None
-        from rasterizer import ahead as _ahead
-
-        _ahead.drain()  # (nothing of the lists-ahead helper thread may launch or allocate while the capture is open)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out, self.loss = self._step()

@@ -14,8 +14,6 @@ The prediction reads the previous call's autograd graph -- ``type(opacity.grad_f
 """
 import logging
 import os
-import queue
-import threading
 import weakref
 
 import torch
@@ -60,75 +58,6 @@ _spec = {}
 _UNARY_FN = {"SigmoidBackward0": torch.sigmoid, "ExpBackward0": torch.exp, "TanhBackward0": torch.tanh,
              "AbsBackward0": torch.abs, "NegBackward0": torch.neg}
 _spec_knobs = {}
-
-
-# ---- the launches come from a helper thread (round 6) ------------------------------------------------------------------
-# Building a view's lists is one native call that launches a dozen kernels: 60-160 us of HOST time, spent inside
-# `project_gaussians` -- i.e. in front of the unchanged models' first read-back (`radii.sum() == 0`), whose kernels could
-# not even be queued until it was over, while the caller's stream sat idle behind the projection (the merged timeline of
-# profiles/r06_render480_modes.txt).  The job therefore goes to a worker thread: `project_gaussians` returns at once, the
-# caller queues its read-back, and the worker launches on the side stream while the caller waits for that read-back (the
-# native call and the caller's blocking wait both release the GIL).  `_entry_done` joins the job before anybody looks at
-# what it produced.  `speculate_thread` = 0 in the tuning table: launch in line, as rounds 4-5 did.
-_jobs = queue.SimpleQueue()
-_worker = {"thread": None}
-
-
-class _Job:
-    __slots__ = ("fn", "finished", "error")
-
-    def __init__(self, fn):
-        self.fn, self.finished, self.error = fn, threading.Event(), None
-
-    def run(self):
-        try:
-            self.fn()
-        except BaseException as e:  # the caller's thread decides what to do with it (a miss)
-            self.error = e
-        finally:
-            self.fn = None
-            self.finished.set()
-
-
-def _worker_loop():
-    while True:
-        _jobs.get().run()
-
-
-def _submit(fn) -> _Job:
-    job = _Job(fn)
-    if not int(_C._tuning.get("speculate_thread")):
-        job.run()
-        return job
-    if _worker["thread"] is None or not _worker["thread"].is_alive():
-        with _R()._state_lock:
-            if _worker["thread"] is None or not _worker["thread"].is_alive():
-                _worker["thread"] = threading.Thread(target=_worker_loop, name="gsr-lists-ahead", daemon=True)
-                _worker["thread"].start()
-    _jobs.put(job)
-    return job
-
-
-def drain() -> None:
-    """Wait until the helper thread has nothing left to launch (callers that are about to CAPTURE a stream: a launch or
-    an allocation from another thread would invalidate a global-mode capture)."""
-    if _worker["thread"] is not None and _worker["thread"].is_alive():
-        job = _Job(lambda: None)
-        _jobs.put(job)
-        job.finished.wait()
-
-
-def _entry_done(entry):
-    """Join the job that fills `entry` -> its `done` event, or None when the job failed (the entry is then useless)."""
-    job = entry.get("job")
-    if job is not None:
-        job.finished.wait()
-        if job.error is not None:
-            if not entry.get("error_logged"):
-                entry["error_logged"] = True
-                log.warning("rasterizer: building a view's tile lists ahead of time failed (%r); built the ordinary way", job.error)
-            return None
-    return entry.get("done")
 
 
 def _speculation_mode() -> str:
@@ -197,22 +126,16 @@ def speculate_lists(xys, depths, radii, conics, num_tiles_hit, img_height, img_w
     if torch.cuda.is_current_stream_capturing():
         return
     tile_bounds = ((img_width + 15) // 16, (img_height + 15) // 16, 1)
-    stale, off = None, False
     with _R()._state_lock:
         st = _spec.setdefault(dev, {"stream": None, "recipe": None, "entry": None})
         recipe = st["recipe"]
         if mode == "auto":
             if st.get("idle", 1.0) <= 0.5:  # the caller keeps the queue full: nothing to hide work behind
                 stale, st["entry"], st["retired"] = st["entry"], None, None  # (an entry nobody took: let go of its tensors)
-                off = True
+                if stale is not None:
+                    torch.cuda.current_stream(dev).wait_event(stale["done"])
+                return
             mode = "lists"
-    if off:
-        if stale is not None:  # (joined OUTSIDE the lock: the helper thread's job takes it too)
-            done = _entry_done(stale)
-            if done is not None:
-                torch.cuda.current_stream(dev).wait_event(done)
-        return
-    with _R()._state_lock:
         # deep scenes take two-round lists, whose first launch writes the reach records while
         # it sorts: nothing is built ahead there (a ready-made order would cost them a records launch of their own:
         # 3 M Gaussians at 4K, 2.71 -> 2.76 ms)
@@ -244,47 +167,38 @@ def speculate_lists(xys, depths, radii, conics, num_tiles_hit, img_height, img_w
         with torch.cuda.device(dev):
             entry["outs"] = (torch.empty((img_height, img_width, 3), dtype=torch.float32, device=dev),
                              torch.empty((3, img_height, img_width), dtype=torch.float32, device=dev))
-    behind = torch.cuda.Event()
-    behind.record(main)  # behind the projection (and whatever the caller queued before it)
-    grad_free = (opacity_src[1].detach() if opacity_src is not None else None)
-
-    def launch():
-        with torch.no_grad(), torch.cuda.device(dev), torch.cuda.stream(side):
-            side.wait_event(behind)
-            if opacity_src is not None and capacity is not None:
-                if opacity_src[0] == "same":
-                    opac = grad_free
-                    oversion = opacity_src[1]._version
-                else:
-                    opac = _UNARY_FN[opacity_src[2]](grad_free).reshape(opacity_src[3]).contiguous()
-                    oversion = opac._version
-                pending = _R()._PendingCount(dev)
-                ids, bins = _C.rasterize_gaussians_forward(xys, depths, radii, conics, None, opac.view(n, 1), None, img_height,
-                                                           img_width, capacity, pending.buf, composite=False, checked=True)
-                entry.update(ids=ids, bins=bins, pending=pending, capacity=capacity,
-                             reach=(conics.detach(), opac, conics._version, oversion, None, osig))
-                _R().counters["list_builds_ahead"] += 1
+    side.wait_stream(main)  # behind the projection (and whatever the caller queued before it)
+    with torch.no_grad(), torch.cuda.stream(side):
+        if opacity_src is not None and capacity is not None:
+            if opacity_src[0] == "same":
+                opac = opacity_src[1].detach()
+                oversion = opacity_src[1]._version
             else:
-                entry["order"], _ = _C.depth_order(depths, radii, None)
-            done = torch.cuda.Event()
-            done.record(side)
-        if "pending" in entry:
-            entry["pending"].event = done
-        entry["done"] = done
-
-    # The inputs were allocated on the caller's stream and are read on the side stream.  Instead of `record_stream` on each
+                opac = _UNARY_FN[opacity_src[2]](opacity_src[1].detach()).reshape(opacity_src[3]).contiguous()
+                oversion = opac._version
+            pending = _R()._PendingCount(dev)
+            ids, bins = _C.rasterize_gaussians_forward(xys, depths, radii, conics, None, opac.view(n, 1), None, img_height,
+                                                       img_width, capacity, pending.buf, composite=False, checked=True)
+            entry.update(ids=ids, bins=bins, pending=pending, capacity=capacity,
+                         reach=(conics.detach(), opac, conics._version, oversion, None, osig))
+            _R().counters["list_builds_ahead"] += 1
+        else:
+            entry["order"], _ = _C.depth_order(depths, radii, None)
+        done = torch.cuda.Event()
+        done.record(side)
+    entry["done"] = done
+    if "pending" in entry:
+        entry["pending"].event = done
+    # The inputs were allocated on the caller's stream and are read on this one.  Instead of `record_stream` on each
     # (five calls per view) the entry -- and `retired`, once it has been taken -- holds references to them until
     # the NEXT view's call, and by then the caller's stream has waited for `done` (when the entry was taken, or
     # below): memory handed back after that point cannot be reused ahead of the side stream's reads.
     entry["keep"] += (opacity_src[1],) if opacity_src is not None else ()
-    entry["job"] = _submit(launch)
     with _R()._state_lock:
         old, st["entry"] = st["entry"], entry
         st["retired"] = None
     if old is not None:
-        done = _entry_done(old)
-        if done is not None:
-            main.wait_event(done)  # an entry nobody took: whatever follows on the caller's stream stays behind it
+        main.wait_event(old["done"])  # an entry nobody took: whatever follows on the caller's stream stays behind it
 
 
 def _take_speculation(device, key):
@@ -294,8 +208,6 @@ def _take_speculation(device, key):
             return None
         entry, st["entry"] = st["entry"], None
         st["retired"] = entry["keep"]
-    if _entry_done(entry) is None:  # (joins the helper thread's job; a failed one is a miss)
-        return None
     return entry
 
 

@@ -64,9 +64,6 @@ TABLE = {
     "fused_records": (1, "1: the reach records ride in the depth sort's first launch (r03: 20 -> 10 launches)"),
     "one_call": (1, "1: lists + compositing of a view in ONE native call (gsr_rasterize_gaussians_forward; r04)"),
     "poll_yield": (1, "1: the pinned-count poll releases the GIL between looks (INTEGRATION.md, threads)"),
-    "speculate_thread": (1, "1: the side stream's launches come from a helper thread, so that project_gaussians returns before "
-                            "them and the caller's first read-back is queued 60-160 us earlier (r06: "
-                            "profiles/r06_render480_modes.txt, merged timeline; A/B in profiles/r06_lists_from_a_thread.txt)"),
     "speculate_min": (65536, "below this many Gaussians nothing is built ahead of time (the side stream's launches cost "
                              "more than they hide)"),
 }

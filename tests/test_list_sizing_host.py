@@ -211,35 +211,3 @@ def test_the_tuning_table_rejects_unknown_rows_and_reads_gsr_tune_once(monkeypat
         T.set_overrides(saved)
     for name, (default, record) in T.TABLE.items():
         assert isinstance(record, str) and len(record) > 20, name  # every row says where its value comes from
-
-
-def test_lists_ahead_jobs_run_on_the_helper_thread_and_are_joined(tune):
-    """rasterizer.ahead (round 6): the side stream's launches come from a helper thread; whoever looks at an entry joins
-    its job first; a job that raised is a miss, logged once; `speculate_thread` = 0 runs it in line; `drain` is a
-    barrier for callers about to capture a stream."""
-    import threading
-    import time
-
-    from rasterizer import ahead as A
-
-    tune()
-    seen = {}
-
-    def fill(entry):
-        def fn():
-            time.sleep(0.02)
-            seen["thread"] = threading.current_thread().name
-            entry["done"] = "event"
-        return fn
-
-    e = {"key": 1}
-    e["job"] = A._submit(fill(e))
-    assert A._entry_done(e) == "event" and seen["thread"] == "gsr-lists-ahead"
-    bad = {"key": 2}
-    bad["job"] = A._submit(lambda: (_ for _ in ()).throw(RuntimeError("boom")))
-    assert A._entry_done(bad) is None and bad["error_logged"] and A._entry_done(bad) is None
-    A.drain()
-    tune(speculate_thread=0)
-    e2 = {"key": 3}
-    e2["job"] = A._submit(fill(e2))
-    assert e2["job"].finished.is_set() and seen["thread"] == threading.current_thread().name and A._entry_done(e2) == "event"
