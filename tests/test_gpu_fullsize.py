@@ -62,7 +62,8 @@ def peak_pixel_share(conics):
     return np.minimum(1.0, np.sqrt(det) / (2.0 * np.pi))
 
 
-def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, peak_share=None):
+def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, peak_share=None, stable_rel=1e-3,
+               unstable_fraction=1e-4):
     """Per-Gaussian gradients are sums over up to ~1e4 pixels with heavy cancellation.
       * STABLE Gaussians (see `stable_gaussians`): north_star's bar, |err| <= 1e-3 |ref|
         elementwise, with |ref| floored at 1e-4 max|ref| (elements that cancel to ~0);
@@ -73,11 +74,11 @@ def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, pe
     err = np.abs(mine - ref)
     if stable is not None:
         rel = err[stable] / np.maximum(np.abs(ref[stable]), 1e-4 * np.abs(ref).max())
-        assert rel.max() <= 1e-3, f"{name}: stable Gaussians differ by {rel.max():.3e} relative"
+        assert rel.max() <= stable_rel, f"{name}: stable Gaussians differ by {rel.max():.3e} relative"
     if abs_sum is not None:
         bound = 1e-3 * np.abs(ref) + 5e-4 * abs_sum
         ratio = err / np.maximum(bound, 1e-30)
-        assert (ratio > 1).mean() <= 1e-4, f"{name}: {(ratio > 1).sum()} elements exceed 1e-3|ref| + 5e-4*abs_sum"
+        assert (ratio > 1).mean() <= unstable_fraction, f"{name}: {(ratio > 1).sum()} elements exceed 1e-3|ref| + 5e-4*abs_sum"
         if peak_share is None:
             assert ratio.max() < worst_cap, f"{name}: worst element {ratio.max():.2f}x the bound"
         else:
@@ -123,7 +124,8 @@ def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file
     scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap)
 
 
-def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stable_pixels=0.99, within_floor=WITHIN_FLOOR):
+def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stable_pixels=0.99, within_floor=WITHIN_FLOOR,
+                    stable_rel=1e-3, unstable_fraction=1e-4):
     """Any scene dictionary (harness.scene layout) from `cam` through the public ops against the oracle, with config 2's
     assertions (tests/test_gpu_heldout.py runs the held-out families and a trained model through it)."""
     W, H, n = cam.width, cam.height, sc["means3d"].shape[0]
@@ -206,18 +208,19 @@ def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stab
     assert frac > stable_floor, report
     assert ok_xy.mean() > within_floor and ok_op.mean() > within_floor, report
     share = peak_pixel_share(gc)
-    grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable, worst_cap=worst_cap, peak_share=share)
+    kw = dict(stable_rel=stable_rel, unstable_fraction=unstable_fraction)
+    grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable, worst_cap=worst_cap, peak_share=share, **kw)
     grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable, worst_cap=worst_cap,
-               peak_share=share)
+               peak_share=share, **kw)
     vsh = O.compute_sh_backward(n, deg, deg, dirs, (vcol * (sh + 0.5 > 0)).astype(np.float32))
-    grad_close(npy(params["sh_coeffs"].grad), vsh, name="sh_coeffs", stable=stable)
+    grad_close(npy(params["sh_coeffs"].grad), vsh, name="sh_coeffs", stable=stable, **kw)
     zeros = np.zeros(n, np.float32)
     _, _, vmean, vscale, vquat = O.project_gaussians_backward(
         n, sc["means3d"], sc["scales"], 1.0, sc["quats"], cam.viewmat[:3], cam.projmat, cam.fx, cam.fy,
         cam.cx, cam.cy, H, W, cov3d, g_radii, gc, comp, vxy, zeros, vconic, zeros)
-    grad_close(npy(params["means3d"].grad), vmean, name="means3d", stable=stable)
-    grad_close(npy(params["scales"].grad), vscale, name="scales", stable=stable)
-    grad_close(npy(params["quats"].grad), vquat, name="quats", stable=stable)
+    grad_close(npy(params["means3d"].grad), vmean, name="means3d", stable=stable, **kw)
+    grad_close(npy(params["scales"].grad), vscale, name="scales", stable=stable, **kw)
+    grad_close(npy(params["quats"].grad), vquat, name="quats", stable=stable, **kw)
 
 
 @pytest.fixture(scope="module")
