@@ -567,14 +567,11 @@ def train_record(args, world):
     cmd = [sys.executable, os.path.abspath(__file__), "--train-only", "--gpus", str(world), "--train-iters",
            str(args.train_iters), "--backend", args.backend, "--cogs-iters", str(args.cogs_iters)] \
         + (["--train-small"] if args.train_small else []) + (["--no-cogs"] if args.no_cogs else []) \
-        + ["--cpu-bind", args.cpu_bind] \
+        + ["--cpu-bind", args.cpu_bind] + (["--cpu-bind-reset"] if world > 1 else []) \
         + (["--train-export-ply", ply] if ply else [])
     t0 = time.perf_counter()
     try:
-        # (N > 1: the training leg spawns its own ranks, and each binds itself -- they must not all inherit rank 0's cores)
-        widen = (lambda: os.sched_setaffinity(0, range(os.cpu_count()))) if (world > 1 and hasattr(os, "sched_setaffinity")) else None
-        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=args.train_timeout,
-                             preexec_fn=widen)
+        out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=args.train_timeout)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:
             return {"error": f"rc {out.returncode}", "stderr_tail": out.stderr[-800:]}
@@ -752,6 +749,8 @@ def main():
                     help="auto: bind each rank to eight cores of its GPU's NUMA node before anything runs (bench.bind_cpus: "
                          "the host-bound training phases have two modes on a multi-socket host otherwise); off: leave the "
                          "affinity as inherited")
+    ap.add_argument("--cpu-bind-reset", action="store_true", help=argparse.SUPPRESS)  # (the N > 1 training leg: its ranks
+    # bind themselves and must not all inherit the cores of the rank that spawned the leg)
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter passes (HBM traffic, VALU busy) that rank 0 runs after the timed "
                          "region at N=1")
@@ -807,6 +806,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.cpu_bind_reset and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, range(os.cpu_count()))
+        except OSError:
+            pass
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched plainly (`python bench.py --gpus N`): spawn one rank per GPU ourselves, as the
         # reference's launcher does (gs_toolkit/scripts/train.py:169, torch.multiprocessing.spawn)

@@ -42,6 +42,9 @@ def test_single_gpu_line_has_the_contract_fields():
     assert abs(d["value_normalised"] - d["value"] * cal["reference_valu_Tops"] / cal["valu_Tops"]) < 0.01 * d["value"]
     assert tim["fixed_warmup_s"] >= 0.3 and tim["fixed_warmup_steps"] > 0 and tim["ms_per_step_median"] > 0
     assert d["end_to_end_built_GBps"] < 8000
+    # the rank was bound to cores of its GPU's NUMA node (or says why not): round 6, bench.bind_cpus
+    assert "cpu_bind" in d["config"] and (d["config"]["cpu_bind"] is None or isinstance(d["config"]["cpu_bind"], str))
+    assert d["config"]["ms_per_step_median"] > 0 and d["config"]["calib_valu_Tops"] > 0 and d["config"]["parity_meets"] is True
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
