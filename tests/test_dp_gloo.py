@@ -11,11 +11,29 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# The workers hand tensors back through a queue and leave: with the default descriptor-passing strategy the parent has
-# to reach the (still living) worker when it unpickles them, and a worker that has already exited resets the connection
-# (seen once the host got faster than the workers' barrier).  Named shared-memory files do not need the producer.
-# (spawned workers import this module: the setting applies on both sides)
-mp.set_sharing_strategy("file_system")
+
+
+def _plain(obj):
+    """Tensors -> numpy arrays, recursively, for the result queue: a torch tensor crosses a multiprocessing queue as a
+    shared-memory handle that the parent can only open while the worker still lives (a worker that had already left
+    reset the connection once the host got faster than the workers' barrier); a numpy array travels by value."""
+    if isinstance(obj, torch.Tensor):
+        return ("__tensor__", obj.detach().cpu().numpy())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_plain(o) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _plain(v) for k, v in obj.items()}
+    return obj
+
+
+def _tensors(obj):
+    if isinstance(obj, tuple) and len(obj) == 2 and isinstance(obj[0], str) and obj[0] == "__tensor__":
+        return torch.from_numpy(obj[1])
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_tensors(o) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _tensors(v) for k, v in obj.items()}
+    return obj
 
 
 def _free_port():
@@ -81,7 +99,7 @@ def _worker(rank, world, port, q):
     inplace_ok = all(torch.allclose(p.grad * world, s_, rtol=1e-6, atol=1e-7) for p, s_ in zip(params, summed))
     for p, s_ in zip(params, summed):
         p.grad = s_
-    q.put((rank, view, [p.grad.clone() for p in params], flat.numel(), gn, vc, mx, inplace_ok))
+    q.put(_plain((rank, view, [p.grad.clone() for p in params], flat.numel(), gn, vc, mx, inplace_ok)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -94,7 +112,7 @@ def test_two_rank_gradient_allreduce_equals_accumulation():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    results = sorted([_tensors(q.get(timeout=240)) for _ in range(2)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -160,7 +178,7 @@ def _exchange_worker(rank, world, port, q):
         nbytes = ex.finish()
         out[active] = (nbytes, named["means"].grad.clone(), named["features_rest"].grad.clone(),
                        named["unused"].grad.clone())
-    q.put((rank, out))
+    q.put(_plain((rank, out)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -173,7 +191,7 @@ def test_two_rank_hooked_exchange_skips_inactive_sh_bands():
     procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = sorted([q.get(timeout=240) for _ in range(2)], key=lambda x: x[0])
+    results = sorted([_tensors(q.get(timeout=240)) for _ in range(2)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -265,7 +283,7 @@ def _views_worker(rank, world, port, q):
     assert dc.grad is None and rest.grad is None      # nothing went through the SH backward
     nbytes = ex.finish()
     views = [t.grad.clone() for t in (dc, rest, other)]
-    q.put((rank, dense, views, nbytes))
+    q.put(_plain((rank, dense, views, nbytes)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -282,7 +300,7 @@ def test_sh_gradient_from_gathered_colour_cotangents_equals_the_all_reduced_one(
     procs = [ctx.Process(target=_views_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    res = sorted([_tensors(q.get(timeout=120)) for _ in range(world)], key=lambda x: x[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
