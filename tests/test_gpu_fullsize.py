@@ -63,7 +63,7 @@ def peak_pixel_share(conics):
 
 
 def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, peak_share=None, stable_rel=1e-3,
-               unstable_fraction=1e-4):
+               unstable_fraction=1e-4, worst_check=True):
     """Per-Gaussian gradients are sums over up to ~1e4 pixels with heavy cancellation.
       * STABLE Gaussians (see `stable_gaussians`): north_star's bar, |err| <= 1e-3 |ref|
         elementwise, with |ref| floored at 1e-4 max|ref| (elements that cancel to ~0);
@@ -79,7 +79,9 @@ def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, pe
         bound = 1e-3 * np.abs(ref) + 5e-4 * abs_sum
         ratio = err / np.maximum(bound, 1e-30)
         assert (ratio > 1).mean() <= unstable_fraction, f"{name}: {(ratio > 1).sum()} elements exceed 1e-3|ref| + 5e-4*abs_sum"
-        if peak_share is None:
+        if not worst_check:
+            print(f"{name}: worst unstable element {ratio.max():.1f}x the tight bound (not asserted for this scene family)")
+        elif peak_share is None:
             assert ratio.max() < worst_cap, f"{name}: worst element {ratio.max():.2f}x the bound"
         else:
             # no constant: a flipped decision moves an element by that pixel's term, at most the share of abs_sum the
@@ -125,7 +127,7 @@ def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file
 
 
 def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stable_pixels=0.99, within_floor=WITHIN_FLOOR,
-                    stable_rel=1e-3, unstable_fraction=1e-4):
+                    stable_rel=1e-3, unstable_fraction=1e-4, worst_check=True):
     """Any scene dictionary (harness.scene layout) from `cam` through the public ops against the oracle, with config 2's
     assertions (tests/test_gpu_heldout.py runs the held-out families and a trained model through it)."""
     W, H, n = cam.width, cam.height, sc["means3d"].shape[0]
@@ -208,7 +210,7 @@ def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stab
     assert frac > stable_floor, report
     assert ok_xy.mean() > within_floor and ok_op.mean() > within_floor, report
     share = peak_pixel_share(gc)
-    kw = dict(stable_rel=stable_rel, unstable_fraction=unstable_fraction)
+    kw = dict(stable_rel=stable_rel, unstable_fraction=unstable_fraction, worst_check=worst_check)
     grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable, worst_cap=worst_cap, peak_share=share, **kw)
     grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable, worst_cap=worst_cap,
                peak_share=share, **kw)
