@@ -63,7 +63,7 @@ def peak_pixel_share(conics):
 
 
 def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, peak_share=None, stable_rel=1e-3,
-               unstable_fraction=1e-4, worst_check=True):
+               unstable_fraction=1e-4, worst_check=True, global_max=1e-3, global_l2=1e-4):
     """Per-Gaussian gradients are sums over up to ~1e4 pixels with heavy cancellation.
       * STABLE Gaussians (see `stable_gaussians`): north_star's bar, |err| <= 1e-3 |ref|
         elementwise, with |ref| floored at 1e-4 max|ref| (elements that cancel to ~0);
@@ -92,9 +92,10 @@ def grad_close(mine, ref, abs_sum=None, name="", stable=None, worst_cap=20.0, pe
             worst = float((err / np.maximum(outer, 1e-30)).max())
             print(f"{name}: worst unstable element {ratio.max():.1f}x the tight bound, {worst:.3f} of the footprint bound")
             assert worst <= 1.0, f"{name}: an element is off by more than {FLIPPED_PIXELS} peak pixels' terms ({worst:.2f}x)"
-    assert err.max() <= 1e-3 * np.abs(ref).max(), f"{name}: max abs err {err.max():.3e} vs max|ref| {np.abs(ref).max():.3e}"
     l2 = np.linalg.norm(mine - ref) / max(np.linalg.norm(ref), 1e-30)
-    assert l2 <= 1e-4, f"{name}: L2 relative error {l2:.3e}"
+    print(f"{name}: max |err| / max |ref| = {err.max() / max(np.abs(ref).max(), 1e-30):.3e}, L2 relative = {l2:.3e}")
+    assert err.max() <= global_max * np.abs(ref).max(), f"{name}: max abs err {err.max():.3e} vs max|ref| {np.abs(ref).max():.3e}"
+    assert l2 <= global_l2, f"{name}: L2 relative error {l2:.3e}"
 
 
 @pytest.mark.timeout(900)
@@ -127,7 +128,7 @@ def _forward_backward_vs_oracle(n, scale_lo, scale_hi, stable_floor, report_file
 
 
 def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stable_pixels=0.99, within_floor=WITHIN_FLOOR,
-                    stable_rel=1e-3, unstable_fraction=1e-4, worst_check=True):
+                    stable_rel=1e-3, unstable_fraction=1e-4, worst_check=True, global_max=1e-3, global_l2=1e-4):
     """Any scene dictionary (harness.scene layout) from `cam` through the public ops against the oracle, with config 2's
     assertions (tests/test_gpu_heldout.py runs the held-out families and a trained model through it)."""
     W, H, n = cam.width, cam.height, sc["means3d"].shape[0]
@@ -210,7 +211,8 @@ def scene_vs_oracle(sc, cam, deg, stable_floor, report_file, worst_cap, min_stab
     assert frac > stable_floor, report
     assert ok_xy.mean() > within_floor and ok_op.mean() > within_floor, report
     share = peak_pixel_share(gc)
-    kw = dict(stable_rel=stable_rel, unstable_fraction=unstable_fraction, worst_check=worst_check)
+    kw = dict(stable_rel=stable_rel, unstable_fraction=unstable_fraction, worst_check=worst_check, global_max=global_max,
+              global_l2=global_l2)
     grad_close(npy(out["xys"].grad), vxy, axy, name="xys.grad", stable=stable, worst_cap=worst_cap, peak_share=share, **kw)
     grad_close(npy(params["opacities"].grad), vop, aop, name="opacities", stable=stable, worst_cap=worst_cap,
                peak_share=share, **kw)
