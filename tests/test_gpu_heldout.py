@@ -44,7 +44,11 @@ def test_held_out_families_against_the_oracle(family, W, H, n):
     # the cap is printed, not asserted, there.
     scene_vs_oracle(sc, cam, 3, -1.0, f"heldout_{family}_{W}x{H}.json", 60.0, min_stable_pixels=0.95, within_floor=0.99,
                     stable_rel=5e-3 if family == "floaters" else 1e-3,
-                    unstable_fraction=1e-3 if family == "needles" else 1e-4, worst_check=family != "needles")
+                    unstable_fraction=1e-3 if family == "needles" else 1e-4, worst_check=family != "needles",
+                    # needles: every tensor's max |err| is 0.6e-4 ... 4.2e-4 of max |ref| EXCEPT the projection's quaternion
+                    # and scale gradients (1.2e-3 / 4.7e-4 L2 at 960 x 540: the covariance of a 1:40 splat is
+                    # ill-conditioned in its rotation, fp32 atomics against the oracle's doubles); bars 2e-3 / 1e-3 there
+                    global_max=2e-3 if family == "needles" else 1e-3, global_l2=1e-3 if family == "needles" else 1e-4)
 
 
 @pytest.mark.timeout(900)
