@@ -63,8 +63,8 @@ __device__ gsr::WaveTrace g_fwd_trace = {nullptr, 0u};
 // Equal to the single walk to rounding (T and C are sums / products of run-wise partial results), not bitwise.
 
 template <bool RGBD, bool SEG = false>
-__device__ __forceinline__ void fwd_tile16_block(
-    unsigned blk, SplatA *sA, SplatB *sB, SplatC *sC, const int tiles_x, const int num_tiles, const int img_w, const int img_h,
+__global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h,
     const int *__restrict__ ids_sorted, const int2 *__restrict__ tile_bins,
     const float2 *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities,
@@ -86,8 +86,17 @@ __device__ __forceinline__ void fwd_tile16_block(
   // (gsr_rasterize_forward_ex) the launch also clears `zero_words` words at `zero_ptr` -- the gradient
   // accumulators of the coming backward: 36 MB of stores that vanish inside this VALU-bound kernel
   // instead of a bandwidth-bound launch of their own -- every workgroup its slice, before any exit
-  // (the clearing itself: raster_fwd_tile16_kernel / raster_fwd_tile16_queue_kernel below, before any exit)
+  if (zero_ptr) {
+    const unsigned per = (zero_words + gridDim.x - 1) / gridDim.x;
+    const unsigned w0 = blockIdx.x * per, w1 = min(w0 + per, zero_words);
+    for (unsigned i = w0 + threadIdx.x; i < w1; i += 64) zero_ptr[i] = 0u;
+  }
+  __shared__ SplatA sA[kChunk];
+  __shared__ SplatB sB[kChunk];
+  __shared__ SplatC sC[kChunk];
+
   int2 range = make_int2(0, 0);
+  unsigned blk = blockIdx.x;
   int seg_k = 0;
   if constexpr (SEG) {  // block = run * (4 base_grid) + the block of the unsegmented launch
     seg_k = (int)(blk / (4u * base_grid));
@@ -323,66 +332,6 @@ __device__ __forceinline__ void fwd_tile16_block(
   job_stats_end(job, 0, stats_t0, trace_len);
 }
 
-#define GSR_FWD16_PARAMS                                                                                                \
-  const int tiles_x, const int num_tiles, const int img_w, const int img_h, const int *__restrict__ ids_sorted,        \
-      const int2 *__restrict__ tile_bins, const float2 *__restrict__ xys, const float *__restrict__ conics,            \
-      const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ background,     \
-      float *__restrict__ out_img, float *__restrict__ final_Ts, int *__restrict__ final_idx,                          \
-      const float *__restrict__ extra, const float bg_extra, float *__restrict__ out_extra, const int deep_threshold,  \
-      const unsigned base_grid, float *__restrict__ out_alpha, unsigned *__restrict__ zero_ptr,                         \
-      const unsigned zero_words, const int round, int *__restrict__ tile_flags, const int idx_base
-#define GSR_FWD16_ARGS                                                                                                  \
-  tiles_x, num_tiles, img_w, img_h, ids_sorted, tile_bins, xys, conics, colors, opacities, background, out_img,        \
-      final_Ts, final_idx, extra, bg_extra, out_extra, deep_threshold, base_grid, out_alpha, zero_ptr, zero_words,     \
-      round, tile_flags, idx_base
-
-__device__ __forceinline__ void clear_slice(unsigned *__restrict__ zero_ptr, const unsigned zero_words) {
-  if (zero_ptr) {
-    const unsigned per = (zero_words + gridDim.x - 1) / gridDim.x;
-    const unsigned w0 = blockIdx.x * per, w1 = min(w0 + per, zero_words);
-    for (unsigned i = w0 + threadIdx.x; i < w1; i += 64) zero_ptr[i] = 0u;
-  }
-}
-
-// one workgroup (= one wave) per block of the launch's block -> (tile, sub-tile[, run]) map
-template <bool RGBD, bool SEG = false>
-__global__ __launch_bounds__(64) void raster_fwd_tile16_kernel(
-    GSR_FWD16_PARAMS, const int seg_count = 1, const int seg_min = 0, float4 *__restrict__ seg_raw = nullptr,
-    int *__restrict__ seg_last = nullptr, float *__restrict__ seg_extra = nullptr, float *__restrict__ seg_marks = nullptr) {
-  clear_slice(zero_ptr, zero_words);
-  __shared__ SplatA sA[kChunk];
-  __shared__ SplatB sB[kChunk];
-  __shared__ SplatC sC[kChunk];
-  fwd_tile16_block<RGBD, SEG>(blockIdx.x, sA, sB, sC, GSR_FWD16_ARGS, seg_count, seg_min, seg_raw, seg_last, seg_extra, seg_marks);
-}
-
-// The depth segments' run launch as a QUEUE (round 6).  A segment grid is runs x 4 x (padded tile slots) one-wave
-// workgroups of which a third to a half have something to do (480 x 270: 49 152 blocks, 17 005 run waves), and gfx950
-// starts workgroups of this register footprint at ~600 per microsecond whether they have work or not
-// (tools/exp/dispatch_bench.hip: 4 300 / us for a 4-VGPR kernel, 596 / us at 62 VGPRs): the launch was paced by the
-// dispatcher at 2.5 resident waves per SIMD (profiles/r06_run_kernel_pacing.txt).  Here the grid is the chip's wave slots
-// and every wave takes blocks from a counter until none is left -- the same blocks, in the same order per XCD
-// (block b runs on XCD b % 8 as before: a wave on XCD x takes blocks 8 n + x from XCD x's own counter, so the runs of a
-// sub-tile still share an L2 and the saturation marks still see earlier runs first).
-template <bool RGBD>
-__global__ __launch_bounds__(64) void raster_fwd_tile16_queue_kernel(
-    GSR_FWD16_PARAMS, const int seg_count, const int seg_min, float4 *__restrict__ seg_raw, int *__restrict__ seg_last,
-    float *__restrict__ seg_extra, float *__restrict__ seg_marks, unsigned *__restrict__ queue, const unsigned total_blocks) {
-  clear_slice(zero_ptr, zero_words);
-  __shared__ SplatA sA[kChunk];
-  __shared__ SplatB sB[kChunk];
-  __shared__ SplatC sC[kChunk];
-  const unsigned xcd = blockIdx.x & 7u;
-  for (;;) {
-    unsigned n = 0;
-    if (threadIdx.x == 0) n = atomicAdd(queue + 16u * xcd, 1u);
-    const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)n) * 8u + xcd;
-    if (b >= total_blocks) break;
-    fwd_tile16_block<RGBD, true>(b, sA, sB, sC, GSR_FWD16_ARGS, seg_count, seg_min, seg_raw, seg_last, seg_extra, seg_marks);
-    __syncthreads();  // (the next block's staging writes the records this one may still be reading)
-  }
-}
-
 __global__ __launch_bounds__(256) void seg_marks_clear_kernel(float *__restrict__ marks, const unsigned n) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i < n) marks[i] = 0.f;
@@ -486,9 +435,8 @@ __device__ __forceinline__ float sigma_in_tile16_order(const float ha, const flo
 // need be.  Every crossing pixel is finished by exactly one block.  The per-splat expressions are those of
 // raster_fwd_tile16_kernel, operand for operand.
 template <bool RGBD>
-__device__ __forceinline__ void fwd_segrewalk_block(
-    unsigned blk, SplatA *sA, SplatB *sB, SplatC *sC, const int tiles_x, const int num_tiles, const int img_w, const int img_h,
-    const int *__restrict__ ids_sorted,
+__global__ __launch_bounds__(64) void raster_fwd_segrewalk_kernel(
+    const int tiles_x, const int num_tiles, const int img_w, const int img_h, const int *__restrict__ ids_sorted,
     const int2 *__restrict__ tile_bins, const float2 *__restrict__ xys, const float *__restrict__ conics,
     const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ background,
     float *__restrict__ out_img, float *__restrict__ final_Ts, int *__restrict__ final_idx,
@@ -496,7 +444,11 @@ __device__ __forceinline__ void fwd_segrewalk_block(
     const unsigned base_grid, float *__restrict__ out_alpha, const int seg_count, const int seg_min,
     const float4 *__restrict__ seg_raw, const int *__restrict__ seg_last, const float *__restrict__ seg_extra,
     const int *__restrict__ seg_kstar, const int *__restrict__ seg_flags) {
+  __shared__ SplatA sA[kChunk];
+  __shared__ SplatB sB[kChunk];
+  __shared__ SplatC sC[kChunk];
   int2 range = make_int2(0, 0);
+  unsigned blk = blockIdx.x;
   const int seg_k = (int)(blk / (4u * base_grid));
   blk -= (unsigned)seg_k * (4u * base_grid);
   const TileJob job = tile_job(blk, base_grid, tiles_x, num_tiles / tiles_x, tile_bins, deep_threshold, range);
@@ -561,34 +513,6 @@ __device__ __forceinline__ void fwd_segrewalk_block(
     out_img[3 * pid + 1] = cg + Tp * background[1];
     out_img[3 * pid + 2] = cb + Tp * background[2];
     if constexpr (RGBD) out_extra[pid] = ce + Tp * bg_extra;
-  }
-}
-
-// (a queue over the segment grid's blocks, as raster_fwd_tile16_queue_kernel: nearly all of them leave at once)
-template <bool RGBD>
-__global__ __launch_bounds__(64) void raster_fwd_segrewalk_kernel(
-    const int tiles_x, const int num_tiles, const int img_w, const int img_h, const int *__restrict__ ids_sorted,
-    const int2 *__restrict__ tile_bins, const float2 *__restrict__ xys, const float *__restrict__ conics,
-    const float *__restrict__ colors, const float *__restrict__ opacities, const float *__restrict__ background,
-    float *__restrict__ out_img, float *__restrict__ final_Ts, int *__restrict__ final_idx,
-    const float *__restrict__ extra, const float bg_extra, float *__restrict__ out_extra, const int deep_threshold,
-    const unsigned base_grid, float *__restrict__ out_alpha, const int seg_count, const int seg_min,
-    const float4 *__restrict__ seg_raw, const int *__restrict__ seg_last, const float *__restrict__ seg_extra,
-    const int *__restrict__ seg_kstar, const int *__restrict__ seg_flags, unsigned *__restrict__ queue,
-    const unsigned total_blocks) {
-  __shared__ SplatA sA[kChunk];
-  __shared__ SplatB sB[kChunk];
-  __shared__ SplatC sC[kChunk];
-  const unsigned xcd = blockIdx.x & 7u;
-  for (;;) {
-    unsigned n = 0;
-    if (threadIdx.x == 0) n = atomicAdd(queue + 16u * xcd, 1u);
-    const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)n) * 8u + xcd;
-    if (b >= total_blocks) break;
-    fwd_segrewalk_block<RGBD>(b, sA, sB, sC, tiles_x, num_tiles, img_w, img_h, ids_sorted, tile_bins, xys, conics, colors,
-                              opacities, background, out_img, final_Ts, final_idx, extra, bg_extra, out_extra, deep_threshold,
-                              base_grid, out_alpha, seg_count, seg_min, seg_raw, seg_last, seg_extra, seg_kstar, seg_flags);
-    __syncthreads();
   }
 }
 
@@ -899,8 +823,7 @@ GSR_EXPORT size_t gsr_rasterize_forward_seg_workspace_bytes(unsigned img_height,
   const size_t tiles = (size_t)gsr_cdiv(img_width, 16) * gsr_cdiv(img_height, 16);
   // per run: raw states (float4) | last drawn indices | the extra channel's sums; then per pixel its crossing run,
   // per (tile, sub-tile) the mask of runs to re-walk and the 16 saturation marks
-  // ... and two block queues of eight 64-byte counters (one per XCD)
-  return (size_t)segments * px * (16 + 4 + 4) + px * 4 + tiles * 16 + tiles * 4 * 16 * 4 + 2 * 8 * 64;
+  return (size_t)segments * px * (16 + 4 + 4) + px * 4 + tiles * 16 + tiles * 4 * 16 * 4;
 }
 
 GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_width, unsigned img_height,
@@ -948,30 +871,25 @@ GSR_EXPORT int gsr_rasterize_forward_seg(int tiles_x, int tiles_y, unsigned img_
   int *kstarp = reinterpret_cast<int *>(extrap + (size_t)segments * px);
   int *flagsp = kstarp + px;
   float *marksp = reinterpret_cast<float *>(flagsp + 4 * (size_t)num_tiles);
-  unsigned *queues = reinterpret_cast<unsigned *>(marksp + 64 * (size_t)num_tiles);  // [2][8][16]: runs, re-walk
-  // (the marks and the two queues are contiguous: one clearing launch)
-  hipLaunchKernelGGL(seg_marks_clear_kernel, dim3((unsigned)((64 * (size_t)num_tiles + 256 + 255) / 256)), dim3(256), 0, s,
-                     marksp, 64u * (unsigned)num_tiles + 256u);
-  const unsigned total = (unsigned)segments * 4u * base;
-  // as many waves as the chip holds at this kernel's register footprint (8 per SIMD, 1 024 SIMDs), a multiple of 8
-  const unsigned waves = total < 8192u ? total : 8192u;
+  hipLaunchKernelGGL(seg_marks_clear_kernel, dim3((unsigned)((64 * (size_t)num_tiles + 255) / 256)), dim3(256), 0, s, marksp,
+                     64u * (unsigned)num_tiles);
 #define GSR_LAUNCH_FWD_SEG(RGBD_)                                                                                       \
-  hipLaunchKernelGGL((raster_fwd_tile16_queue_kernel<RGBD_>), dim3(waves), dim3(64), 0, s, tiles_x, num_tiles,          \
-                     (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),    \
-                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, out_img, final_Ts,    \
-                     final_idx, extra, extra_background, out_extra, deep_arg, base, out_alpha,                           \
-                     static_cast<unsigned *>(zero_ptr), (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments,     \
-                     seg_min, raw, lastp, extrap, marksp, queues, total);                                                \
+  hipLaunchKernelGGL((raster_fwd_tile16_kernel<RGBD_, true>), dim3((unsigned)segments * 4u * base), dim3(64), 0, s,      \
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,   \
+                     opacities, background, out_img, final_Ts, final_idx, extra, extra_background, out_extra,           \
+                     deep_arg, base, out_alpha, static_cast<unsigned *>(zero_ptr),                                       \
+                     (unsigned)(zero_bytes >> 2), 0, (int *)nullptr, 0, segments, seg_min, raw, lastp, extrap, marksp);  \
   hipLaunchKernelGGL(raster_fwd_segresolve_kernel<RGBD_>, dim3(4u * base), dim3(64), 0, s, tiles_x, num_tiles,          \
                      (int)img_width, (int)img_height, reinterpret_cast<const int2 *>(tile_bins), background, out_img,    \
                      final_Ts, final_idx, extra_background, out_extra, deep_arg, base, out_alpha, segments, seg_min,    \
                      raw, lastp, extrap, kstarp, flagsp);                                                                \
-  hipLaunchKernelGGL(raster_fwd_segrewalk_kernel<RGBD_>, dim3(waves), dim3(64), 0, s, tiles_x, num_tiles,               \
-                     (int)img_width, (int)img_height, gaussian_ids_sorted, reinterpret_cast<const int2 *>(tile_bins),    \
-                     reinterpret_cast<const float2 *>(xys), conics, colors, opacities, background, out_img, final_Ts,    \
-                     final_idx, extra, extra_background, out_extra, deep_arg, base, out_alpha, segments, seg_min,        \
-                     (const float4 *)raw, (const int *)lastp, (const float *)extrap, (const int *)kstarp,                \
-                     (const int *)flagsp, queues + 128, total)
+  hipLaunchKernelGGL(raster_fwd_segrewalk_kernel<RGBD_>, dim3((unsigned)segments * 4u * base), dim3(64), 0, s,          \
+                     tiles_x, num_tiles, (int)img_width, (int)img_height, gaussian_ids_sorted,                          \
+                     reinterpret_cast<const int2 *>(tile_bins), reinterpret_cast<const float2 *>(xys), conics, colors,   \
+                     opacities, background, out_img, final_Ts, final_idx, extra, extra_background, out_extra, deep_arg, \
+                     base, out_alpha, segments, seg_min, (const float4 *)raw, (const int *)lastp,                       \
+                     (const float *)extrap, (const int *)kstarp, (const int *)flagsp)
   if (extra) {
     GSR_LAUNCH_FWD_SEG(true);
   } else {
