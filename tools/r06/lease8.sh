@@ -1,6 +1,6 @@
 #!/bin/bash
 # Lease 8: the round's closing records -- the whole -m gpu suite and the driver-form line on the final code.
-out=$PWD/gpurun_out/lease8; mkdir -p $out
+out=$PWD/gpurun_out/${LEASE:-lease8}; mkdir -p $out
 ( timeout 1700 python -m pytest tests -m gpu -q --durations=12 2>&1 | tail -32 ) > $out/gpu_suite.txt
 tail -4 $out/gpu_suite.txt
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_form.json 2> $out/bench_driver_form.err; python - <<PY
