@@ -352,9 +352,11 @@ int gsr_rasterize_backward_ex(unsigned img_height, unsigned img_width,
 
 /* gsr_rasterize_forward_ex / _rgbd (16x16 tiles, 3 channels [+ one]) with DEPTH SEGMENTS: the list of every tile that is split over
  * four waves (deep_tile_threshold) and holds more than max(deep_tile_threshold, segment_min_entries) entries is cut
- * into `segments` (2..16) runs of whole 64-entry chunks.  A pre-pass computes every run's transmittance product per
- * pixel; each run is then composited by its own waves from the true incoming T (the stop rule of forward.cu:278-395
- * needs it) and a combine pass adds the runs' colours in list order.  For tile grids too small to fill the chip (the
+ * into `segments` (2..16) runs of whole 64-entry chunks.  Compositing is associative in (C, T): every run is walked
+ * ONCE from T = 1 by its own waves, a resolve pass scales the runs' colour sums by the products of the runs in front and
+ * finds the run in which each pixel crosses the stop rule's 1e-4, and only those (sub-tile, run) pairs are walked again
+ * from the true incoming T -- the exact stop rule and final_idx of forward.cu:278-395 (round 6; rounds 4-5 walked every
+ * list twice).  For tile grids too small to fill the chip (the
  * 480 x 270 phase of the reference's coarse-to-fine schedule, vanilla_gs.py:48-53, is 510 tiles).  Results equal
  * gsr_rasterize_forward_ex's to rounding.  workspace: gsr_rasterize_forward_seg_workspace_bytes(...) bytes, 16-byte
  * aligned.  segments < 2 or deep_tile_threshold <= 0: gsr_rasterize_forward_ex. */
