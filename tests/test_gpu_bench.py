@@ -116,11 +116,9 @@ def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks():
     base = [a for a in SMALL if a not in ("--train-iters", "0")]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     for extra in ([], ["--gpus", "2", "--backend", "gloo"]):
-        # (the co-gs leg rides at N = 1 only: at two ranks sharing one GPU it was 15 s of spawn and setup for code the
-        #  2-rank co-gs tests of tests/test_gpu_cogs.py / test_dp_train_gloo.py already run)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base + extra +
-                             ["--train-small", "--train-iters", "160", "--no-cpu-baseline"] + (["--no-cogs"] if extra else []),
-                             capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                             ["--train-small", "--train-iters", "160", "--no-cpu-baseline"], capture_output=True,
+                             text=True, timeout=900, env=env, cwd=ROOT)
         assert out.returncode == 0, out.stderr[-3000:]
         lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
         assert len(lines) == 1, out.stdout[-2000:]
@@ -133,12 +131,11 @@ def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks():
         assert len(t["phase_ms_median_by_resolution"]) == 3, t["phase_ms_median_by_resolution"]
         assert t["iters_per_s_with_caller_syncs"] > 0 and t["list_overflow_views"] == 0
         # BASELINE config 5's loop (co-gs) rides in the same record ...
-        if not extra:
-            c = t["cogs_3m_4k"]
-            assert "error" not in c and c["iters"] == 120 and c["iters_per_s"] > 0, c
-            assert c["depth"]["loss_from_step"] == 41 and c["depth"]["one_compositing_pass"] is True
-            assert set(c["phase_ms_median_by_depth_loss"]) == {"depth_loss_off", "depth_loss_on"}
-            assert c["peak_memory_GB"] > 0 and c["list_overflow_views"] == 0
+        c = t["cogs_3m_4k"]
+        assert "error" not in c and c["iters"] == 120 and c["iters_per_s"] > 0, c
+        assert c["depth"]["loss_from_step"] == 41 and c["depth"]["one_compositing_pass"] is True
+        assert set(c["phase_ms_median_by_depth_loss"]) == {"depth_loss_off", "depth_loss_on"}
+        assert c["peak_memory_GB"] > 0 and c["list_overflow_views"] == 0
         if extra:
             assert t["replicas_identical"] is True and t["allreduce_bytes_step_bytes"], t
         else:
