@@ -332,6 +332,12 @@ def _two_round_feedback(plan, c1, c2, unfinished):
 _POLL_YIELD = bool(int(_tuning.get("poll_yield")))  # (0 = spin without yielding the GIL)
 
 
+@_tuning.on_change
+def _refresh_poll_yield():
+    global _POLL_YIELD
+    _POLL_YIELD = bool(int(_tuning.get("poll_yield")))
+
+
 class _PendingCount:
     """One int32 on its way from a kernel to the host: the kernel (`gsr_bin_sorted_dev`'s count, `gsr_publish_int32`)
     writes it straight into pinned (device-mapped) host memory -- no copy operation in the stream -- and `resolve`
