@@ -22,48 +22,6 @@ def _run(extra):
     return json.loads(lines[0])
 
 
-_EIGHT = {}
-
-
-def _start_eight_ranks():
-    """`python bench.py --gpus 8 ...` started in the BACKGROUND: its 140 s are sixteen processes
-    importing torch and opening the one GPU -- host work that runs beside this module's other command tests (which check
-    the line's contract, not its speed); `test_eight_ranks_as_the_driver_will_launch_them`, the module's last test, joins it.
-    Output goes to files: a pipe nobody reads would stall the ranks after 64 KB of gloo chatter."""
-    if "proc" in _EIGHT:
-        return
-    import tempfile
-
-    # (the smallest workload that still exercises all of it: 12 k Gaussians at 320 x 180, two timed steps, twelve
-    #  training iterations)
-    base = ["--gaussians", "12000", "--width", "320", "--height", "180", "--steps", "2", "--warmup", "1", "--no-pmc"]
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
-    _EIGHT["out"], _EIGHT["err"] = tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")
-    _EIGHT["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + base +
-                                      ["--gpus", "8", "--backend", "gloo", "--train-small", "--train-iters", "12", "--no-cogs",
-                                       "--no-cpu-baseline", "--train-timeout", "1200"], stdout=_EIGHT["out"],
-                                      stderr=_EIGHT["err"], text=True, env=env, cwd=ROOT, start_new_session=True)
-
-
-@pytest.fixture
-def eight_ranks_in_the_background():
-    _start_eight_ranks()
-
-
-@pytest.fixture(scope="module", autouse=True)
-def _no_orphans():
-    """(a failure under `-x` before the joining test: the background job's own process group is ended, by its id)"""
-    yield
-    proc = _EIGHT.get("proc")
-    if proc is not None and proc.poll() is None:
-        import signal
-
-        try:
-            os.killpg(proc.pid, signal.SIGKILL)
-        except OSError:
-            pass
-
-
 def test_single_gpu_line_has_the_contract_fields():
     d = _run([])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -93,7 +51,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
 
 
-def test_plain_invocation_with_two_gpus_spawns_its_ranks(eight_ranks_in_the_background):
+def test_plain_invocation_with_two_gpus_spawns_its_ranks():
     d = _run(["--gpus", "2", "--backend", "gloo", "--no-cpu-baseline"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     # whole-job value: both ranks' pixels over the slowest rank's time
@@ -101,7 +59,36 @@ def test_plain_invocation_with_two_gpus_spawns_its_ranks(eight_ranks_in_the_back
     assert d["allreduce_bytes"] and d["allreduce_bytes"] > 0
 
 
-def test_the_drivers_torchrun_form(eight_ranks_in_the_background):
+@pytest.mark.timeout(1500)
+def test_eight_ranks_as_the_driver_will_launch_them():
+    """`python bench.py --gpus 8 ...` end to end once (VERDICT r4 item 8): the self-spawn of eight ranks, the port
+    selection, eight process groups, the timed region with every collective of the exchange, the other ranks leaving,
+    and the training leg's SECOND spawn of eight ranks (config 3 / 4's code on a scene that trains in seconds; the
+    co-gs leg rides in the two-rank test below -- eight ranks on one GPU took this test 11 of the suite's 17 minutes
+    with it) -- all eight sharing cuda:0 through gloo, which is not a measurement but is the exact command path of
+    the driver's N = 8 run."""
+    # (the smallest workload that still exercises all of that -- VERDICT r5 item 6: 12 k Gaussians at 320 x 180, two timed
+    #  steps, twelve training iterations; eight processes importing torch and opening the one GPU are what is left)
+    base = ["--gaussians", "12000", "--width", "320", "--height", "180", "--steps", "2", "--warmup", "1", "--no-pmc"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + base +
+                         ["--gpus", "8", "--backend", "gloo", "--train-small", "--train-iters", "12", "--no-cogs",
+                          "--no-cpu-baseline", "--train-timeout", "1200"], capture_output=True, text=True, timeout=1400, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    # (whole-job value: eight ranks' pixels over the slowest rank's time; the line rounds it to 0.01 Mpix/s)
+    assert abs(d["value"] - 8 * 320 * 180 / d["ms_per_step"] / 1e3) < 0.01 * d["value"] + 0.006
+    assert d["allreduce_bytes"] > 0 and "dp8" in d["config"]["parallelism"]
+    t = d["train"]
+    assert t and "error" not in t, t
+    assert t["n_gpus"] == 8 and t["iters"] == 12 and t["replicas_identical"] is True
+    assert t["views_per_s"] > 7.9 * t["iters_per_s"] and t["allreduce_bytes_step_bytes"]
+
+
+def test_the_drivers_torchrun_form():
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
     --gpus N ...`: the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
     import socket
@@ -121,7 +108,7 @@ def test_the_drivers_torchrun_form(eight_ranks_in_the_background):
     assert d["n_gpus"] == 2 and d["value"] > 0
 
 
-def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks(eight_ranks_in_the_background):
+def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks():
     """The second half of BASELINE's metric: `train` in the ONE JSON line, produced by a fresh process (its own
     process group) after the raster timing -- at N = 1, and at N = 2 self-spawned twice over (the bench's ranks,
     then the training leg's).  `--train-small` swaps config 3's scene for one that trains in seconds; the code
@@ -170,32 +157,3 @@ def test_the_training_record_rides_in_the_same_line_at_one_and_two_ranks(eight_r
             pv = r["parity_vs_oracle"]
             assert pv and "error" not in pv and pv["meets"]["image_1e-4_abs"] and pv["meets"]["gradients_1e-3_rel"], pv
             assert cf["trained_parity_meets"] is True and cf["trained_parity_image_max_abs"] < 1e-4
-
-
-@pytest.mark.timeout(1500)
-def test_eight_ranks_as_the_driver_will_launch_them():
-    """`python bench.py --gpus 8 ...` end to end once (VERDICT r4 item 8): the self-spawn of eight ranks, the port
-    selection, eight process groups, the timed region with every collective of the exchange, the other ranks leaving,
-    and the training leg's SECOND spawn of eight ranks (config 3 / 4's code on a scene that trains in seconds; the
-    co-gs leg rides in the two-rank test above -- eight ranks on one GPU took this test 11 of the suite's 17 minutes
-    with it) -- all eight sharing cuda:0 through gloo, which is not a measurement but is the exact command path of
-    the driver's N = 8 run."""
-    _start_eight_ranks()  # (already running when the module's other tests went first)
-    rc = _EIGHT["proc"].wait(timeout=1400)
-    _EIGHT["out"].seek(0), _EIGHT["err"].seek(0)
-    stdout, stderr = _EIGHT["out"].read(), _EIGHT["err"].read()
-    import types
-
-    out = types.SimpleNamespace(returncode=rc, stdout=stdout, stderr=stderr)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
-    # (whole-job value: eight ranks' pixels over the slowest rank's time; the line rounds it to 0.01 Mpix/s)
-    assert abs(d["value"] - 8 * 320 * 180 / d["ms_per_step"] / 1e3) < 0.01 * d["value"] + 0.006
-    assert d["allreduce_bytes"] > 0 and "dp8" in d["config"]["parallelism"]
-    t = d["train"]
-    assert t and "error" not in t, t
-    assert t["n_gpus"] == 8 and t["iters"] == 12 and t["replicas_identical"] is True
-    assert t["views_per_s"] > 7.9 * t["iters_per_s"] and t["allreduce_bytes_step_bytes"]
